@@ -1,0 +1,4 @@
+"""CPU oracle package — TEST INFRASTRUCTURE ONLY (see oracle/ssg_oracle.h).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""

@@ -1,0 +1,253 @@
+"""ctypes binding of the CPU oracle (oracle/ssg_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED at the pymunk boundary (see ssg_oracle.h).  Nothing under ship_sim_gym_amd/ may import
+this module; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libssg_oracle.so")
+
+MAX_VERTS, MAX_GOALS, MAX_BEAMS, MAX_HISTORY = 16, 8, 32, 8
+PEEK_LEN = 19
+PEEK_FIELDS = ("x", "y", "vx", "vy", "angle", "w", "rudder", "step_count", "n_goals_alive", "colliding",
+               "goal_reached", "map_id", "cumulative_reward", "alive_mask", "episodes", "bb_l", "bb_b", "bb_r",
+               "bb_t")
+
+
+class V2(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double)]
+
+
+class Poly(C.Structure):
+    _fields_ = [("count", C.c_int),
+                ("lv", V2 * MAX_VERTS), ("ln", V2 * MAX_VERTS), ("wv", V2 * MAX_VERTS), ("wn", V2 * MAX_VERTS),
+                ("bb_l", C.c_double), ("bb_b", C.c_double), ("bb_r", C.c_double), ("bb_t", C.c_double)]
+
+
+class SegInfo(C.Structure):
+    _fields_ = [("shape_hit", C.c_int), ("point", V2), ("normal", V2), ("alpha", C.c_double)]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_double), ("height", C.c_double), ("dt", C.c_double), ("space_damping", C.c_double),
+                ("max_steps", C.c_int), ("history", C.c_int), ("n_beams", C.c_int),
+                ("lidar_spread_deg", C.c_double), ("lidar_dist", C.c_double),
+                ("n_goals", C.c_int), ("goal_radius", C.c_double),
+                ("ship_w", C.c_double), ("ship_h", C.c_double), ("ship_mass", C.c_double), ("force_y", C.c_double),
+                ("rudder_step", C.c_int), ("rudder_max", C.c_int),
+                ("thrust_px0", C.c_double), ("thrust_py0", C.c_double),
+                ("spawn_x", C.c_double), ("spawn_y", C.c_double)]
+
+
+class Bank(C.Structure):
+    _fields_ = [("n_maps", C.c_int), ("polys", C.POINTER(C.c_double)), ("goals", C.POINTER(C.c_double))]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                              for f in ("ssg_oracle.c", "ssg_oracle.h", "Makefile"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.ora_convex_hull.restype = C.c_int
+        L.ora_convex_hull.argtypes = [C.c_int, dp, dp]
+        L.ora_moment_for_poly.restype = C.c_double
+        L.ora_moment_for_poly.argtypes = [C.c_double, C.c_int, dp]
+        L.ora_poly_init.argtypes = [C.POINTER(Poly), C.c_int, dp]
+        L.ora_poly_update.argtypes = [C.POINTER(Poly), V2, V2]
+        L.ora_poly_point_query.restype = C.c_double
+        L.ora_poly_point_query.argtypes = [C.POINTER(Poly), V2, C.POINTER(V2)]
+        L.ora_poly_segment_query.restype = C.c_int
+        L.ora_poly_segment_query.argtypes = [C.POINTER(Poly), V2, V2, C.c_double, C.POINTER(SegInfo)]
+        L.ora_polys_collide.restype = C.c_int
+        L.ora_polys_collide.argtypes = [C.POINTER(Poly), C.POINTER(Poly)]
+        L.ora_circle_poly_collide.restype = C.c_int
+        L.ora_circle_poly_collide.argtypes = [V2, C.c_double, C.POINTER(Poly)]
+        L.ora_default_config.argtypes = [C.POINTER(Config)]
+        L.ora_world_sizeof.restype = C.c_int
+        L.ora_world_init.argtypes = [C.c_void_p, C.POINTER(Config)]
+        L.ora_world_reset.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.ora_goal_x_range.restype = C.c_int
+        L.ora_goal_x_range.argtypes = [C.c_void_p, C.c_double, dp, dp]
+        L.ora_world_step.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(C.c_uint8)]
+        L.ora_world_peek.argtypes = [C.c_void_p, dp]
+        L.ora_world_at.restype = C.c_void_p
+        L.ora_world_at.argtypes = [C.c_void_p, C.c_int]
+        L.ora_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.ora_batch_reset.argtypes = [C.c_void_p, C.c_int, C.POINTER(Config), C.POINTER(Bank), C.POINTER(C.c_int32), dp]
+        L.ora_batch_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(Bank), C.POINTER(C.c_int32), dp, dp,
+                                     C.POINTER(C.c_uint8), C.c_int, C.c_int]
+        L.ora_action.restype = C.c_int32
+        L.ora_action.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ora_fill_actions.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int32)]
+        L.ora_rollout.restype = C.c_int64
+        L.ora_rollout.argtypes = [C.c_void_p, C.c_int, C.POINTER(Bank), C.c_uint64, C.c_int64, C.c_int, C.c_int, dp, dp,
+                                  C.POINTER(C.c_uint8)]
+        L.ora_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def default_config(**over):
+    c = Config()
+    lib().ora_default_config(C.byref(c))
+    if "width" in over and "spawn_x" not in over:
+        over["spawn_x"] = over["width"] / 2
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def convex_hull(verts):
+    v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 2)
+    out = np.empty_like(v)
+    n = lib().ora_convex_hull(len(v), _dp(v), _dp(out))
+    return out[:n].copy()
+
+
+def moment_for_poly(m, verts):
+    v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 2)
+    return lib().ora_moment_for_poly(float(m), len(v), _dp(v))
+
+
+def make_poly(verts, p=(0.0, 0.0), angle=0.0):
+    v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 2)
+    poly = Poly()
+    lib().ora_poly_init(C.byref(poly), len(v), _dp(v))
+    import math
+    lib().ora_poly_update(C.byref(poly), V2(*p), V2(math.cos(angle), math.sin(angle)))
+    return poly
+
+
+def segment_query(poly, a, b, radius=0.0):
+    info = SegInfo()
+    hit = lib().ora_poly_segment_query(C.byref(poly), V2(*a), V2(*b), float(radius), C.byref(info))
+    return bool(hit), (info.point.x, info.point.y), (info.normal.x, info.normal.y), info.alpha
+
+
+def point_query(poly, p):
+    return lib().ora_poly_point_query(C.byref(poly), V2(*p), None)
+
+
+class World:
+    """One reference-shaped env (ShipEnv + ShipGame) on the oracle."""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg if cfg is not None else default_config()
+        self._buf = C.create_string_buffer(lib().ora_world_sizeof())
+        self._p = C.cast(self._buf, C.c_void_p)
+        lib().ora_world_init(self._p, C.byref(self.cfg))
+        self.D = (6 + self.cfg.n_beams) * self.cfg.history
+
+    def reset(self, left, right, goals):
+        l = np.ascontiguousarray(left, dtype=np.float64).reshape(12, 2)
+        r = np.ascontiguousarray(right, dtype=np.float64).reshape(12, 2)
+        g = np.ascontiguousarray(goals, dtype=np.float64).reshape(self.cfg.n_goals, 2)
+        obs = np.empty(self.D)
+        lib().ora_world_reset(self._p, _dp(l), _dp(r), _dp(g), _dp(obs))
+        return obs
+
+    def set_banks_only(self, left, right):
+        """Install bank hulls (for goal_x_range during goal generation) without goals."""
+        return self.reset(left, right, np.zeros((self.cfg.n_goals, 2)))
+
+    def goal_x_range(self, y):
+        lo, hi = C.c_double(), C.c_double()
+        ok = lib().ora_goal_x_range(self._p, float(y), C.byref(lo), C.byref(hi))
+        return bool(ok), lo.value, hi.value
+
+    def step(self, action):
+        obs = np.empty(self.D)
+        r = C.c_double()
+        d = C.c_uint8()
+        lib().ora_world_step(self._p, int(action), _dp(obs), C.byref(r), C.byref(d))
+        return obs, r.value, bool(d.value)
+
+    def peek(self):
+        out = np.empty(PEEK_LEN)
+        lib().ora_world_peek(self._p, _dp(out))
+        return dict(zip(PEEK_FIELDS, out.tolist()))
+
+
+class Batch:
+    """N oracle worlds over a map bank with VecEnv auto-reset; mirrors the HIP path's bank mode."""
+
+    def __init__(self, n, cfg, polys, goals, map_ids=None):
+        self.n, self.cfg = int(n), cfg
+        self.polys = np.ascontiguousarray(polys, dtype=np.float64).reshape(-1, 2, 12, 2)
+        self.goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(len(self.polys), cfg.n_goals, 2)
+        self.bank = Bank(len(self.polys), _dp(self.polys), _dp(self.goals))
+        self.D = (6 + cfg.n_beams) * cfg.history
+        self._buf = C.create_string_buffer(lib().ora_world_sizeof() * self.n)
+        self._p = C.cast(self._buf, C.c_void_p)
+        self.obs = np.empty((self.n, self.D))
+        self.reward = np.empty(self.n)
+        self.done = np.zeros(self.n, dtype=np.uint8)
+        if map_ids is None:
+            map_ids = np.arange(self.n) % len(self.polys)
+        self.map_ids = np.ascontiguousarray(map_ids, dtype=np.int32)
+
+    def reset(self):
+        lib().ora_batch_reset(self._p, self.n, C.byref(self.cfg), C.byref(self.bank),
+                              self.map_ids.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self.obs))
+        return self.obs.copy()
+
+    def step(self, actions, auto_reset=True, n_threads=1):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        lib().ora_batch_step(self._p, self.n, C.byref(self.bank), a.ctypes.data_as(C.POINTER(C.c_int32)),
+                             _dp(self.obs), _dp(self.reward), self.done.ctypes.data_as(C.POINTER(C.c_uint8)),
+                             int(auto_reset), int(n_threads))
+        return self.obs.copy(), self.reward.copy(), self.done.copy()
+
+    def rollout(self, seed, env_base, K, n_threads=1):
+        return lib().ora_rollout(self._p, self.n, C.byref(self.bank), int(seed), int(env_base), int(K), int(n_threads),
+                                 _dp(self.obs), _dp(self.reward), self.done.ctypes.data_as(C.POINTER(C.c_uint8)))
+
+    def peek(self, i):
+        out = np.empty(PEEK_LEN)
+        lib().ora_world_peek(lib().ora_world_at(self._p, int(i)), _dp(out))
+        return dict(zip(PEEK_FIELDS, out.tolist()))
+
+    def peek_all(self):
+        out = np.empty((self.n, PEEK_LEN))
+        for i in range(self.n):
+            lib().ora_world_peek(lib().ora_world_at(self._p, i), _dp(out[i]))
+        return out
+
+
+def fill_actions(seed, step0, K, env_base, n):
+    out = np.empty((K, n), dtype=np.int32)
+    lib().ora_fill_actions(int(seed), int(step0), int(K), int(env_base), int(n), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().ora_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def max_threads():
+    return lib().ora_max_threads()

@@ -1,0 +1,143 @@
+/*
+ * ssg_oracle.h — CPU ORACLE for the ShipEnv step/reset path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call this
+ * code.  The product (ship_sim_gym_amd/ + libshipsim.so) never links or imports it.
+ *
+ * PARITY UNPINNED at the pymunk boundary: the arithmetic of the reference path lives in
+ * pymunk==5.4.0 (requirements.txt:78), a cffi wrapper around Chipmunk2D 7.0.x whose source is not
+ * under /root/reference and is not installed in the build container, and the reference's own test
+ * file (tests/test_ship_env.py) is stale against its API and holds no numeric vectors.  This file
+ * restates the published Chipmunk2D algorithms (cpSpaceStep, cpBodyUpdatePosition/Velocity,
+ * cpConvexHull, cpPolyShape* queries, cpMomentForPoly) for exactly the subset the reference's call
+ * sites reach, in the reference's operation order, double precision.  What IS pinned against the real
+ * reference: map polygons (game_map.gen_river_poly), config defaults, Curriculum (tests/golden/).
+ */
+#ifndef SSG_ORACLE_H
+#define SSG_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORA_MAX_VERTS 16
+#define ORA_MAX_GOALS 8
+#define ORA_MAX_BEAMS 32
+#define ORA_MAX_HISTORY 8
+#define ORA_MAX_SHIPS 4
+#define ORA_MAP_POLY_VERTS 12 /* game_map.py:22-73: N=10 jittered points + 2 corners */
+
+typedef struct { double x, y; } ora_v2;
+
+/* Convex polygon shape: Chipmunk cpPolyShape restated (local + world splitting planes). */
+typedef struct {
+    int count;
+    ora_v2 lv[ORA_MAX_VERTS], ln[ORA_MAX_VERTS]; /* local  planes: v0, n (cpPolyShape SetVerts) */
+    ora_v2 wv[ORA_MAX_VERTS], wn[ORA_MAX_VERTS]; /* world  planes (cpPolyShapeCacheData)        */
+    double bb_l, bb_b, bb_r, bb_t;               /* cached world AABB; zero until first update  */
+} ora_poly;
+
+typedef struct {
+    ora_v2 p, v, f, rot;
+    double a, w, t;
+    double m_inv, i_inv;
+} ora_body;
+
+typedef struct {
+    int shape_hit;   /* 0 = info->shape == NULL */
+    ora_v2 point, normal;
+    double alpha;
+} ora_seg_info;
+
+typedef struct {
+    /* GameConfig / EnvConfig / LiDAR constants */
+    double width, height;     /* GameConfig.BOUNDS                   config.py:24  */
+    double dt;                /* SPEED * base_dt                     game.py:27,194 */
+    double space_damping;     /* space.damping = 0.4                 game.py:270   */
+    int max_steps, history;   /* EnvConfig                           config.py:15-16 */
+    int n_beams;              /* LiDAR defaults                      models.py:29  */
+    double lidar_spread_deg, lidar_dist;
+    int n_goals;              /* N_GOALS                             game.py:17    */
+    double goal_radius;       /* add_goal radius                     game.py:82    */
+    double ship_w, ship_h;    /* player scale (2,3)                  game.py:275   */
+    double ship_mass;         /* Ship(mass=5)                        models.py:87  */
+    double force_y;           /* force_vector = (0,100)              models.py:107 */
+    int rudder_step, rudder_max; /* rotate(+-5), max_angle=10        game.py:149-151, models.py:110 */
+    double thrust_px0, thrust_py0; /* shape.bb.center() before space.add = (0,0)  models.py:109, App. A.3 */
+    double spawn_x, spawn_y;  /* (BOUNDS[0]/2, 25)                   game.py:274   */
+} ora_config;
+
+typedef struct {
+    ora_config cfg;
+    ora_body ship;
+    ora_poly ship_shape;
+    double ship_moment;
+    ora_poly bank[2];
+    int n_goals_alive;                 /* len(self.goals) */
+    ora_v2 goal_p[ORA_MAX_GOALS];      /* self.goals in list order (consumed ones are removed) */
+    int goal_id[ORA_MAX_GOALS];        /* original index of each remaining goal */
+    int rudder;
+    ora_v2 thrust_pt;
+    double lidar_vals[ORA_MAX_BEAMS];
+    int colliding, goal_reached;
+    int step_count;
+    double reward, cumulative_reward;
+    int n_states;                      /* 6 + n_beams */
+    double states[ORA_MAX_HISTORY * (6 + ORA_MAX_BEAMS)]; /* deque, oldest first */
+    /* bank mode (auto-reset) */
+    int map_id;
+    int64_t episodes;
+} ora_world;
+
+/* ---- geometry primitives (Chipmunk restated) ---- */
+int ora_convex_hull(int count, const double *verts_xy, double *out_xy);
+double ora_moment_for_poly(double m, int count, const double *verts_xy);
+void ora_poly_init(ora_poly *poly, int count, const double *verts_xy); /* hulls its input */
+void ora_poly_update(ora_poly *poly, ora_v2 p, ora_v2 rot);
+double ora_poly_point_query(const ora_poly *poly, ora_v2 p, ora_v2 *closest);
+int ora_poly_segment_query(const ora_poly *poly, ora_v2 a, ora_v2 b, double radius, ora_seg_info *info);
+int ora_polys_collide(const ora_poly *a, const ora_poly *b);
+int ora_circle_poly_collide(ora_v2 c, double r, const ora_poly *poly);
+
+/* ---- world ---- */
+void ora_default_config(ora_config *cfg);
+void ora_world_init(ora_world *w, const ora_config *cfg);
+/* ShipGame.reset + ShipEnv.reset given the map polygons and goal positions the host RNG produced. */
+void ora_world_reset(ora_world *w, const double *left_xy, const double *right_xy, const double *goals_xy,
+                     double *obs_out);
+/* goal placement helper, game.py:322-325: returns 1 and (lo,hi) for np.random.uniform(lo,hi); 0 = fallback */
+int ora_goal_x_range(const ora_world *w, double y, double *lo, double *hi);
+void ora_world_step(ora_world *w, int action, double *obs_out, double *reward, uint8_t *done);
+int ora_world_sizeof(void);
+/* debug/inspection dump: [x,y,vx,vy,angle,w,rudder,step_count,n_goals_alive,colliding,goal_reached,map_id,
+ * cumulative_reward,alive_mask,episodes,bb_l,bb_b,bb_r,bb_t] */
+#define ORA_PEEK_LEN 19
+void ora_world_peek(const ora_world *w, double *out);
+ora_world *ora_world_at(ora_world *ws, int i);
+void ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* ---- batched driver with a map bank and auto-reset (VecEnv semantics), OpenMP over envs ---- */
+typedef struct {
+    int n_maps;
+    const double *polys;  /* [n_maps][2][12][2] */
+    const double *goals;  /* [n_maps][n_goals][2] */
+} ora_bank;
+
+void ora_batch_reset(ora_world *ws, int n, const ora_config *cfg, const ora_bank *bank, const int32_t *map_ids,
+                     double *obs /* [n][H*F] */);
+void ora_batch_step(ora_world *ws, int n, const ora_bank *bank, const int32_t *actions, double *obs, double *reward,
+                    uint8_t *done, int auto_reset, int n_threads);
+/* counter-based action stream shared with the HIP side (Philox4x32-10) */
+int32_t ora_action(uint64_t seed, uint64_t step, uint64_t env_id);
+void ora_fill_actions(uint64_t seed, uint64_t step0, int K, int64_t env_base, int n, int32_t *out /* [K][n] */);
+/* timed random-action rollout for bench.py's cpu_baseline: returns env-steps done */
+int64_t ora_rollout(ora_world *ws, int n, const ora_bank *bank, uint64_t seed, int64_t env_base, int K, int n_threads,
+                    double *obs, double *reward, uint8_t *done);
+int ora_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
