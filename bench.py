@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched ShipEnv hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed / RCCL when N > 1, launched by torch.distributed.run); every rank steps
+its own shard of envs with NO data-path collective (envs are independent) after one RCCL broadcast
+of the map bank from rank 0.  A "step" is one ssg_step pass (one kernel launch) over the rank's whole env batch
+with a pre-generated random action vector already resident in HBM; obs / reward / done are written to HBM every
+step and done envs are auto-reset in-kernel.  Workload at N=1: BASELINE.json configs[2] — 65 536 parallel envs,
+1 ship, 8-beam lidar, default 600x600 map bank (64 maps), SPEED 10 — the configuration the ">= 10 M env-steps/s
+on one MI355X" target is quoted on.  Weak scaling: every rank owns 65 536 envs.
+
+Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
+  roofline     — algorithmic HBM bytes per launch (675 B/env-step at S=1, nb=8, H=2) divided by the
+                 kernel's average launch duration measured with HIP events on the launch stream, against 8 TB/s.
+  cpu_baseline — the CPU oracle ("port": our C restatement of the reference path, NOT pymunk) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 65536
+N_BEAMS = 8
+N_MAPS = 64
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(n_ships, nb, hist):
+    """SURVEY.md §8(d) per env-step figure (not to be redefined)."""
+    return 96 * n_ships + 8 + 8 + 2 + 80 + 4 + 4 + 16 * nb + 8 * (6 + nb) + 8 * hist * (6 + nb) + 9
+
+
+def cpu_baseline(vec, seconds_target=12.0):
+    """Time the CPU oracle on a bounded sample of the same workload: same bank, same Philox action stream."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_cfg
+    from oracle import oracle as O
+    threads = O.max_threads()
+    n = 4096
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    ob.reset()
+    t0 = time.perf_counter()
+    ob.rollout(12345, 0, 20, n_threads=threads)  # calibration
+    per_step = (time.perf_counter() - t0) / 20
+    K = max(20, min(4000, int(seconds_target / max(per_step, 1e-9))))
+    ob.reset()
+    t0 = time.perf_counter()
+    done_steps = ob.rollout(12345, 0, K, n_threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": done_steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d envs x %d steps, 8-beam lidar, same 64-map bank and Philox action stream, OpenMP over envs, "
+                      "%.1f s" % (n, K, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    from ship_sim_gym_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    n = args.envs_per_gpu
+    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=N_BEAMS,
+                     env_id_base=rank * n)
+    if world > 1:
+        sharding.broadcast_bank(vec, src=0)  # RCCL broadcast of the map bank over xGMI; the only collective on the path
+
+    K, W = args.steps, args.warmup
+    acts = vec.random_actions(12345, 0, K + W)  # [K+W, n] int32, generated on device before the timed region
+    vec.reset_tensor()
+    vec.rollout_tensor(acts[:W]) if W > 0 else None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    vec.rollout_tensor(acts[W:])  # K launches of the step kernel on torch's current stream
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    if rank == 0:
+        total_steps = float(n) * world * K
+        B = algorithmic_bytes(1, N_BEAMS, 2)
+        launch_s = ev_ms * 1e-3 / K
+        achieved = B * n / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec (batched ShipEnv)", "value": total_steps / wall, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 65536 parallel envs per GPU, 1 ship, 8-beam lidar, 64-map "
+                                   "bank (600x600, SPEED 10), random Philox actions, auto-reset in-kernel",
+                       "envs_per_gpu": n, "total_envs": n * world, "n_beams": N_BEAMS, "history": 2,
+                       "parallelism": "env-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "ssg::step_kernel<8,256,true>", "algorithmic_bytes_per_env_step": B,
+                         "avg_launch_us": launch_s * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vec)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

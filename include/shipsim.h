@@ -1,0 +1,202 @@
+/*
+ * shipsim.h — C ABI of libshipsim.so: the MI355X (gfx950) batched replacement for the pymunk-backed
+ * ShipEnv.step()/reset() hot path of CapAI/ship-sim-gym.
+ *
+ * The reference reaches its physics through pymunk 5.4.0's cffi binding of libchipmunk.so
+ * (notebooks/"Ship Sim Gym.ipynb":51, requirements.txt:78).  Each entry point below names the reference
+ * call site(s) it replaces; all pointers are plain host or device addresses, sizes are explicit, no C++ or
+ * torch types cross the boundary, nothing throws and nothing aborts.  Return value: 0 (SSG_OK) or a
+ * negative ssg_status; ssg_last_error() gives the text.  A handle is used by one host thread at a time;
+ * distinct handles (one per GPU / per env shard) are independent.  Device work is enqueued on the caller's
+ * hipStream_t (passed as void*) and is asynchronous unless stated.
+ *
+ * Device memory is owned by the caller (PyTorch-ROCm tensors as containers): the state blob, the map bank
+ * and every per-call buffer.  The library owns only the handle (host memory).
+ */
+#ifndef SHIPSIM_H
+#define SHIPSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSG_ABI_VERSION 1
+
+typedef enum ssg_status {
+    SSG_OK = 0,
+    SSG_ERR_BAD_ARG = -1,
+    SSG_ERR_HIP = -2,
+    SSG_ERR_NOT_BOUND = -3,
+    SSG_ERR_UNSUPPORTED = -4,
+    SSG_ERR_NO_DEVICE = -5
+} ssg_status;
+
+/* ---- limits ---- */
+#define SSG_MAX_BEAMS 16
+#define SSG_MAX_GOALS 8       /* bits 0..6 of the goal mask; bit 7 = "rudder has been moved" */
+#define SSG_MAX_HULL 12       /* game_map.gen_river_poly: 10 jittered points + 2 corners, game_map.py:22-73 */
+#define SSG_SHIP_VERTS 5      /* SHIP_TEMPLATE, models.py:6 */
+
+/* ---- flags ---- */
+#define SSG_FLAG_AUTO_RESET        0x1u /* VecEnv semantics: a done env is reset inside ssg_step and the returned
+                                           observation is the reset observation (SubprocVecEnv worker behaviour,
+                                           train/stable_baselines/ppo.py:123) */
+#define SSG_FLAG_FIX_COLLISION_REWARD 0x2u /* off by default: the reference's determine_reward overwrites the
+                                           collision reward (ship_env.py:66-77); set to make in-bounds collisions -1 */
+#define SSG_FLAG_BANK_IN_GLOBAL    0x4u /* never stage the map bank in LDS (per-lane gathers from L2/HBM); forced
+                                           when the bank does not fit LDS or when every env has its own slot */
+
+/*
+ * Map bank record: SSG_MAP_STRIDE doubles per map, built on the host by ssg_host_build_map().
+ *   [0] nL  [1] nR                      hull plane counts (as doubles)
+ *   [2..5]  left  hull AABB l,b,r,t     [6..9] right hull AABB
+ *   [10..26)  goal centres x0,y0,x1,y1,...  (SSG_MAX_GOALS pairs)
+ *   [26] [27] the goal nearest to the spawn point (the reset observation's goal, ship_env.py:102-108)
+ *   [28 + 8*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax 0     j < 12
+ *   [124 + 8*j ..) right plane j
+ *   [220] [221] spare
+ * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180); v0.n, dtMin =
+ * cross(n, v[j-1]) and dtMax = cross(n, v[j]) are the per-plane constants cpPolyShapeSegmentQuery derives.
+ * 222 doubles = 111 sixteen-byte slots: an odd slot stride, so consecutive maps start on different LDS banks.
+ */
+#define SSG_MAP_STRIDE 222
+#define SSG_MAP_OFF_COUNTS 0
+#define SSG_MAP_OFF_AABB 2
+#define SSG_MAP_OFF_GOALS 10
+#define SSG_MAP_OFF_SPAWN_GOAL 26
+#define SSG_MAP_OFF_PLANES 28
+#define SSG_PLANE_DOUBLES 8
+
+typedef struct ssg_config {
+    uint32_t struct_size;  /* sizeof(ssg_config), checked by ssg_create */
+    uint32_t flags;        /* SSG_FLAG_* */
+    int32_t device_id;     /* HIP device ordinal */
+    int32_t n_envs;        /* envs owned by this handle (this rank's shard) */
+    int64_t env_id_base;   /* global id of local env 0: keys the action stream and default map assignment */
+    /* EnvConfig / LiDAR (config.py:14-17, models.py:29) */
+    int32_t n_beams;       /* 1..SSG_MAX_BEAMS; reference LiDAR default 10 */
+    int32_t history;       /* EnvConfig.HISTORY_SIZE; 1 or 2 in ABI v1 */
+    int32_t max_steps;     /* EnvConfig.MAX_STEPS */
+    int32_t n_goals;       /* N_GOALS = 5, game.py:17; <= 7 */
+    double lidar_spread_deg; /* 90 */
+    double lidar_dist;       /* 100 */
+    double goal_radius;      /* 5, game.py:82 */
+    /* GameConfig (config.py:20-24) */
+    double width, height;  /* BOUNDS */
+    double dt;             /* SPEED * base_dt (game.py:27,194), computed by the host in double */
+    double damping_pow_dt; /* pow(space.damping = 0.4, dt) (game.py:270; cpSpaceStep) */
+    /* player ship (models.py:87-111, game.py:274-275) */
+    double spawn_x, spawn_y;
+    double ship_hull[2 * SSG_SHIP_VERTS];    /* CCW hull of SHIP_TEMPLATE*(w,h) in cpConvexHull order */
+    double ship_normals[2 * SSG_SHIP_VERTS]; /* local splitting-plane normals of that hull */
+    double ship_m_inv, ship_i_inv;           /* 1/mass, 1/cpMomentForPoly */
+    double force_y;                          /* force_vector = (0,100) */
+    double thrust_px0, thrust_py0;           /* point_of_thrust before the first rotate(), models.py:109 */
+    int32_t rudder_step, rudder_max;         /* 5, 10 */
+} ssg_config;
+
+typedef struct ssg_handle ssg_handle;
+
+/* State blob fields (struct-of-arrays, one column of n_envs_padded elements per field, lane-contiguous). */
+typedef enum ssg_field {
+    SSG_F_X = 0, SSG_F_Y, SSG_F_VX, SSG_F_VY, SSG_F_ANGLE, SSG_F_W, /* f64: body p, v, a, w            */
+    SSG_F_CUM_REWARD,                                              /* f64: ShipEnv.cumulative_reward    */
+    SSG_F_LIDAR,                                                   /* f64 x n_beams: LiDAR.vals (sticky) */
+    SSG_F_RUDDER,                                                  /* i32: Ship.rudder_angle            */
+    SSG_F_STEP_COUNT,                                              /* i32: ShipEnv.step_count           */
+    SSG_F_MAP_ID,                                                  /* i32: bank record of this env      */
+    SSG_F_GOAL_MASK,                                               /* u8 : bit g = goal g still listed  */
+    SSG_F_STATS,                                                   /* f64 x 4 per handle: sum_return,
+                                                                      sum_length, n_episodes, n_goals_hit */
+    SSG_F_COUNT
+} ssg_field;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Lifecycle
+ * ------------------------------------------------------------------------------------------------- */
+int ssg_abi_version(void);
+const char *ssg_strerror(int status);
+const char *ssg_last_error(const ssg_handle *h);
+
+/* Replaces: ShipEnv.__init__ + ShipGame.__init__ (ship_env.py:23-48, game.py:32-58) and the pm.Space()/Body/
+ * Poly construction inside them (game.py:269-270, models.py:87-111,153-196).  Host only: no GPU work. */
+int ssg_create(const ssg_config *cfg, ssg_handle **out);
+int ssg_destroy(ssg_handle *h);
+
+/* Fill *cfg with the reference defaults (config.py:8-24, models.py:6,29,87-110, game.py:17,82,274-275). */
+int ssg_default_config(ssg_config *cfg);
+/* Recompute ship_hull / ship_normals / ship_m_inv / ship_i_inv for SHIP_TEMPLATE*(width_scale,height_scale):
+ * Ship.__init__ (models.py:87-100): pm.moment_for_poly on the template order, pm.Poly hull order. */
+int ssg_config_set_ship(ssg_config *cfg, double width_scale, double height_scale, double mass);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Memory binding (caller-owned device memory)
+ * ------------------------------------------------------------------------------------------------- */
+int ssg_state_nbytes(const ssg_handle *h, size_t *nbytes);
+/* offset (bytes) of a field's first column in the blob, element size, columns per env-field. */
+int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_size, int *n_columns,
+                    size_t *column_stride_bytes);
+int ssg_bind_state(ssg_handle *h, void *dev_state);
+/* Replaces: gen_level + PolyEnv (game.py:60-71, models.py:153-196) and the goal list (game.py:77-95).
+ * dev_bank: n_maps records of SSG_MAP_STRIDE doubles in device memory. */
+int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The hot path
+ * ------------------------------------------------------------------------------------------------- */
+/* Replaces: ShipEnv.reset -> ShipGame.reset (ship_env.py:171-184, game.py:260-277).
+ * dev_mask: u8[n_envs], non-zero = reset this env; NULL = all.  dev_map_ids: i32[n_envs] record to install for
+ * each reset env; NULL = (env_id_base + e) mod n_maps.  dev_obs: f64[n_envs][history*(6+n_beams)], rows of reset
+ * envs are overwritten with the reset observation. */
+int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids, double *dev_obs, void *stream);
+
+/* Replaces: ShipEnv.step (ship_env.py:136-156) = handle_discrete_action (game.py:140-153) + update: LiDAR.query
+ * (models.py:39-76) + space.step = cpSpaceStep (game.py:194) with the collide_ship / collide_goal callbacks
+ * (game.py:232-257) + determine_reward / __add_states / is_done (ship_env.py:62-134).
+ * dev_actions i32[n_envs] in {0,1,2,3}; dev_obs f64[n_envs][D]; dev_reward f64[n_envs]; dev_done u8[n_envs] (0/1);
+ * dev_flags u8[n_envs] event bits SSG_EV_* or NULL. */
+int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
+             uint8_t *dev_flags /* nullable */, void *stream);
+
+/* Per-env event bits written to dev_flags (the reference's ShipGame.colliding / goal_reached attributes that
+ * tests reach through env.game.*, game.py:190-191,240,254, plus which is_done branch fired). */
+#define SSG_EV_COLLIDING 0x1u
+#define SSG_EV_GOAL_REACHED 0x2u
+#define SSG_EV_OUT_OF_BOUNDS 0x4u
+#define SSG_EV_MAX_STEPS 0x8u
+#define SSG_EV_NO_GOALS_LEFT 0x10u
+
+/* K consecutive ssg_step launches enqueued back to back on `stream`, step k reading dev_actions + k*n_envs
+ * (the random-action rollout loop of train/random.py:14-27, batched).  obs/reward/done/flags are overwritten by
+ * every step, exactly as K separate ssg_step calls would. */
+int ssg_rollout(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev_obs, double *dev_reward,
+                uint8_t *dev_done, uint8_t *dev_flags /* nullable */, void *stream);
+
+/* Random-action rollout driver (train/random.py:14-27 batched): fills i32[K][n_envs] with a counter-based
+ * Philox4x32-10 stream keyed by (seed, step0+k, env_id_base+e), uniform on Discrete(3) (ship_env.py:19). */
+int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_t *dev_actions, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Host-side geometry (what pymunk's cffi exposed at reset time); no GPU needed.
+ * ------------------------------------------------------------------------------------------------- */
+/* Replaces cpConvexHull as reached by pm.Poly(...) (models.py:96,180).  out_xy holds >= count pairs. */
+int ssg_host_convex_hull(int count, const double *verts_xy, double *out_xy, int *out_count);
+/* Replaces pm.moment_for_poly (models.py:89). */
+int ssg_host_moment_for_poly(double mass, int count, const double *verts_xy, double *out);
+/* Replaces Space.segment_query((W/2,y),(edge,y),10,filter)[0] over the two bank shapes (game.py:322-323):
+ * hulls are the records' planes.  hit=0 -> the reference's IndexError fallback applies. */
+int ssg_host_goal_x_range(const double *map_record, double width, double y, double *lo, double *hi, int *hit);
+/* Builds one bank record from the two raw 12-gons of gen_river_poly and the goal centres. */
+int ssg_host_build_map(const double *left_xy, int n_left, const double *right_xy, int n_right,
+                       const double *goals_xy, int n_goals, double spawn_x, double spawn_y, double *record_out);
+/* Generic fat/thin segment query against one hull of a record (side 0 = left, 1 = right); cpShapeSegmentQuery. */
+int ssg_host_segment_query(const double *map_record, int side, double ax, double ay, double bx, double by,
+                           double radius, int *hit, double *px, double *py, double *alpha);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHIPSIM_H */

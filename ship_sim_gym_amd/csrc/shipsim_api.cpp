@@ -1,0 +1,603 @@
+// shipsim_api.cpp — the extern "C" boundary of libshipsim.so (include/shipsim.h) and the host-side geometry
+// that pymunk's cffi layer provided to the reference at reset time (hulling, splitting planes, moments, the
+// fat segment queries of gen_goal_path).  No torch types, no exceptions across the boundary.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "shipsim.h"
+#include "shipsim_internal.h"
+
+struct ssg_handle {
+    ssg_config cfg;
+    ssg::DevCfg dev;
+    int n_pad = 0;
+    size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, nbytes = 0;
+    void *state = nullptr;
+    const double *bank = nullptr;
+    int n_maps = 0;
+    int block = 256;
+    bool lds = false;
+    size_t lds_bytes = 0;
+    bool prepared = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err; // errors raised before a handle exists
+
+int fail(ssg_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    else g_err = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host geometry
+// ---------------------------------------------------------------------------------------------------------
+struct P2 { double x, y; };
+inline double cross3(const P2 &o, const P2 &a, const P2 &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); }
+
+// Strict convex hull, counter-clockwise, first vertex = lexicographic (x, then y) minimum: the vertex order
+// cpConvexHull (QuickHull, tol 0) hands to cpPolyShape.  Implemented as Andrew's monotone chain.
+std::vector<P2> convex_hull(std::vector<P2> pts)
+{
+    std::sort(pts.begin(), pts.end(), [](const P2 &a, const P2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    pts.erase(std::unique(pts.begin(), pts.end(), [](const P2 &a, const P2 &b) { return a.x == b.x && a.y == b.y; }),
+              pts.end());
+    const int n = (int)pts.size();
+    if (n <= 2) return pts;
+    std::vector<P2> h(2 * n);
+    int k = 0;
+    for (int i = 0; i < n; ++i) { // lower chain
+        while (k >= 2 && cross3(h[k - 2], h[k - 1], pts[i]) <= 0.0) --k;
+        h[k++] = pts[i];
+    }
+    for (int i = n - 2, t = k + 1; i >= 0; --i) { // upper chain
+        while (k >= t && cross3(h[k - 2], h[k - 1], pts[i]) <= 0.0) --k;
+        h[k++] = pts[i];
+    }
+    h.resize(k - 1);
+    return h;
+}
+
+struct Plane { double v0x, v0y, nx, ny, v0n, dtmin, dtmax; };
+
+// cpPolyShape SetVerts: plane i = { v0 = v[i], n = normalize(rperp(v[i] - v[i-1])) }, rperp(x,y) = (y,-x),
+// normalize(v) = v * (1/(|v| + DBL_MIN)); plus the constants cpPolyShapeSegmentQuery derives per plane.
+std::vector<Plane> planes_of(const std::vector<P2> &v)
+{
+    const int n = (int)v.size();
+    std::vector<Plane> pl(n);
+    for (int i = 0; i < n; ++i) {
+        const P2 &a = v[(i - 1 + n) % n], &b = v[i];
+        const double ex = b.x - a.x, ey = b.y - a.y;
+        const double rx = ey, ry = -ex;
+        const double inv = 1.0 / (std::sqrt(rx * rx + ry * ry) + DBL_MIN);
+        Plane p;
+        p.v0x = b.x; p.v0y = b.y;
+        p.nx = rx * inv; p.ny = ry * inv;
+        pl[i] = p;
+    }
+    for (int i = 0; i < n; ++i) {
+        Plane &p = pl[i];
+        const P2 &prev = v[(i - 1 + n) % n];
+        p.v0n = p.v0x * p.nx + p.v0y * p.ny;          // cpvdot(v0, n)
+        p.dtmin = p.nx * prev.y - p.ny * prev.x;      // cpvcross(n, v[i-1])
+        p.dtmax = p.nx * p.v0y - p.ny * p.v0x;        // cpvcross(n, v[i])
+    }
+    return pl;
+}
+
+struct HullView {
+    int n;
+    const double *pl; // n planes of SSG_PLANE_DOUBLES doubles
+    double v0x(int i) const { return pl[8 * i + 0]; }
+    double v0y(int i) const { return pl[8 * i + 1]; }
+    double nx(int i) const { return pl[8 * i + 2]; }
+    double ny(int i) const { return pl[8 * i + 3]; }
+    double v0n(int i) const { return pl[8 * i + 4]; }
+    double dtmin(int i) const { return pl[8 * i + 5]; }
+    double dtmax(int i) const { return pl[8 * i + 6]; }
+};
+
+inline double clamp01(double f) { return std::max(0.0, std::min(f, 1.0)); }
+
+// cpPolyShapePointQuery (radius 0): signed distance of p to the hull and the closest boundary point.
+double point_query(const HullView &h, double px, double py, double *cx, double *cy)
+{
+    double v0x = h.v0x(h.n - 1), v0y = h.v0y(h.n - 1);
+    double best = INFINITY, bx = 0, by = 0;
+    bool outside = false;
+    for (int i = 0; i < h.n; ++i) {
+        const double v1x = h.v0x(i), v1y = h.v0y(i);
+        outside = outside || ((h.nx(i) * (px - v1x) + h.ny(i) * (py - v1y)) > 0.0);
+        const double dx = v0x - v1x, dy = v0y - v1y;
+        const double t = clamp01((dx * (px - v1x) + dy * (py - v1y)) / (dx * dx + dy * dy));
+        const double qx = v1x + dx * t, qy = v1y + dy * t;
+        const double ex = px - qx, ey = py - qy;
+        const double d = std::sqrt(ex * ex + ey * ey);
+        if (d < best) { best = d; bx = qx; by = qy; }
+        v0x = v1x; v0y = v1y;
+    }
+    if (cx) *cx = bx;
+    if (cy) *cy = by;
+    return outside ? best : -best;
+}
+
+struct SegHit { bool hit; double px, py, alpha; };
+
+// cpShapeSegmentQuery -> cpPolyShapeSegmentQuery + CircleSegmentQuery for the bevelled corners (poly radius 0,
+// query radius r2), as Space.segment_query / Shape.segment_query reach it.
+SegHit segment_query(const HullView &h, double ax, double ay, double bx, double by, double r2)
+{
+    SegHit out{false, bx, by, 1.0};
+    if (point_query(h, ax, ay, nullptr, nullptr) <= r2) {
+        out.hit = true;
+        out.alpha = 0.0;
+        return out; // reported point stays the far end b
+    }
+    for (int i = 0; i < h.n; ++i) {
+        const double nx = h.nx(i), ny = h.ny(i);
+        const double an = ax * nx + ay * ny;
+        const double d = an - h.v0n(i) - r2;
+        if (d < 0.0) continue;
+        const double bn = bx * nx + by * ny;
+        const double t = d / std::max(an - bn, DBL_MIN);
+        if (t < 0.0 || 1.0 < t) continue;
+        const double omt = 1.0 - t;
+        const double ptx = ax * omt + bx * t, pty = ay * omt + by * t;
+        const double dtv = nx * pty - ny * ptx;
+        if (h.dtmin(i) <= dtv && dtv <= h.dtmax(i)) {
+            out.hit = true;
+            out.px = ptx - nx * r2;
+            out.py = pty - ny * r2;
+            out.alpha = t;
+        }
+    }
+    if (r2 > 0.0) {
+        for (int i = 0; i < h.n; ++i) {
+            const double cx = h.v0x(i), cy = h.v0y(i);
+            const double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
+            const double daa = dax * dax + day * day, dab = dax * dbx + day * dby, dbb = dbx * dbx + dby * dby;
+            const double qa = daa - 2.0 * dab + dbb;
+            const double qb = dab - daa;
+            const double det = qb * qb - qa * (daa - r2 * r2);
+            if (det >= 0.0) {
+                const double t = (-qb - std::sqrt(det)) / qa;
+                if (0.0 <= t && t <= 1.0 && t < out.alpha) {
+                    const double omt = 1.0 - t;
+                    double nx = dax * omt + dbx * t, ny = day * omt + dby * t;
+                    const double inv = 1.0 / (std::sqrt(nx * nx + ny * ny) + DBL_MIN);
+                    nx *= inv; ny *= inv;
+                    out.hit = true;
+                    out.px = (ax * omt + bx * t) - nx * r2;
+                    out.py = (ay * omt + by * t) - ny * r2;
+                    out.alpha = t;
+                }
+            }
+        }
+    }
+    return out;
+}
+
+HullView hull_of_record(const double *rec, int side)
+{
+    return HullView{(int)rec[SSG_MAP_OFF_COUNTS + side],
+                    rec + SSG_MAP_OFF_PLANES + side * (SSG_MAX_HULL * SSG_PLANE_DOUBLES)};
+}
+
+const double kShipTemplate[SSG_SHIP_VERTS][2] = {{0, 0}, {0, 10}, {5, 15}, {10, 10}, {10, 0}}; // models.py:6
+
+double moment_for_poly(double m, int n, const double *v)
+{
+    // cpMomentForPoly, offset (0,0): about the local origin
+    double sum1 = 0.0, sum2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double x1 = v[2 * i], y1 = v[2 * i + 1];
+        const int j = (i + 1) % n;
+        const double x2 = v[2 * j], y2 = v[2 * j + 1];
+        const double a = x2 * y1 - y2 * x1;
+        const double b = (x1 * x1 + y1 * y1) + (x1 * x2 + y1 * y2) + (x2 * x2 + y2 * y2);
+        sum1 += a * b;
+        sum2 += a;
+    }
+    return (m * sum1) / (6.0 * sum2);
+}
+
+int set_ship(ssg_config *cfg, double ws, double hs, double mass)
+{
+    double pts[2 * SSG_SHIP_VERTS];
+    std::vector<P2> v(SSG_SHIP_VERTS);
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+        pts[2 * i] = kShipTemplate[i][0] * ws;
+        pts[2 * i + 1] = kShipTemplate[i][1] * hs;
+        v[i] = P2{pts[2 * i], pts[2 * i + 1]};
+    }
+    const double moment = moment_for_poly(mass, SSG_SHIP_VERTS, pts); // on the template order, as models.py:88-89
+    std::vector<P2> hull = convex_hull(v);
+    if ((int)hull.size() != SSG_SHIP_VERTS) return SSG_ERR_BAD_ARG;
+    std::vector<Plane> pl = planes_of(hull);
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+        cfg->ship_hull[2 * i] = hull[i].x;
+        cfg->ship_hull[2 * i + 1] = hull[i].y;
+        cfg->ship_normals[2 * i] = pl[i].nx;
+        cfg->ship_normals[2 * i + 1] = pl[i].ny;
+    }
+    cfg->ship_m_inv = 1.0 / mass;
+    cfg->ship_i_inv = 1.0 / moment;
+    return SSG_OK;
+}
+
+void refresh_dev(ssg_handle *h)
+{
+    const ssg_config &c = h->cfg;
+    ssg::DevCfg &d = h->dev;
+    d.n_envs = c.n_envs;
+    d.n_pad = h->n_pad;
+    d.env_id_base = c.env_id_base;
+    d.n_beams = c.n_beams;
+    d.history = c.history;
+    d.max_steps = c.max_steps;
+    d.n_goals = c.n_goals;
+    d.flags = c.flags;
+    d.n_maps = h->n_maps;
+    d.rudder_step = c.rudder_step;
+    d.rudder_max = c.rudder_max;
+    d.spread_deg = c.lidar_spread_deg;
+    d.lidar_dist = c.lidar_dist;
+    d.goal_r = c.goal_radius;
+    d.width = c.width;
+    d.height = c.height;
+    d.dt = c.dt;
+    d.damp = c.damping_pow_dt;
+    d.spawn_x = c.spawn_x;
+    d.spawn_y = c.spawn_y;
+    std::memcpy(d.hull, c.ship_hull, sizeof(d.hull));
+    std::memcpy(d.nrm, c.ship_normals, sizeof(d.nrm));
+    d.m_inv = c.ship_m_inv;
+    d.i_inv = c.ship_i_inv;
+    d.force_y = c.force_y;
+    d.px0 = c.thrust_px0;
+    d.py0 = c.thrust_py0;
+    char *base = static_cast<char *>(h->state);
+    d.stats = base ? reinterpret_cast<double *>(base + h->off_stats) : nullptr;
+    d.f64cols = base ? reinterpret_cast<double *>(base + h->off_f64) : nullptr;
+    d.i32cols = base ? reinterpret_cast<int32_t *>(base + h->off_i32) : nullptr;
+    d.mask = base ? reinterpret_cast<uint8_t *>(base + h->off_mask) : nullptr;
+    d.bank = h->bank;
+}
+
+int pick_block(int n_envs)
+{
+    if (const char *s = std::getenv("SSG_BLOCK")) {
+        const int b = std::atoi(s);
+        if (b == 64 || b == 128 || b == 256 || b == 512) return b;
+    }
+    // MI355X has 256 CUs: aim for >= 256 workgroups before growing the workgroup (one wave per SIMD first).
+    if (n_envs <= 64 * 256) return 64;
+    if (n_envs <= 128 * 256) return 128;
+    if (n_envs <= 256 * 256) return 256;
+    return 512;
+}
+
+int check_ready(ssg_handle *h, bool need_bank)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    if (!h->state) return fail(h, SSG_ERR_NOT_BOUND, "no state blob bound: call ssg_bind_state first");
+    if (need_bank && (!h->bank || h->n_maps <= 0))
+        return fail(h, SSG_ERR_NOT_BOUND, "no map bank set: call ssg_set_map_bank first");
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(h, SSG_ERR_NO_DEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    if (dev != h->cfg.device_id) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "current HIP device %d differs from the handle's device %d", dev,
+                      h->cfg.device_id);
+        return fail(h, SSG_ERR_BAD_ARG, buf);
+    }
+    return SSG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ssg_abi_version(void) { return SSG_ABI_VERSION; }
+
+const char *ssg_strerror(int status)
+{
+    switch (status) {
+    case SSG_OK: return "ok";
+    case SSG_ERR_BAD_ARG: return "bad argument";
+    case SSG_ERR_HIP: return "HIP runtime error";
+    case SSG_ERR_NOT_BOUND: return "state or map bank not bound";
+    case SSG_ERR_UNSUPPORTED: return "unsupported configuration";
+    case SSG_ERR_NO_DEVICE: return "no usable HIP device";
+    default: return "unknown status";
+    }
+}
+
+const char *ssg_last_error(const ssg_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int ssg_default_config(ssg_config *cfg)
+{
+    if (!cfg) return fail(nullptr, SSG_ERR_BAD_ARG, "cfg is NULL");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(ssg_config);
+    cfg->flags = SSG_FLAG_AUTO_RESET;
+    cfg->device_id = 0;
+    cfg->n_envs = 1;
+    cfg->env_id_base = 0;
+    cfg->n_beams = 10;          // models.py:29
+    cfg->history = 2;           // config.py:15
+    cfg->max_steps = 1000;      // config.py:16
+    cfg->n_goals = 5;           // game.py:17
+    cfg->lidar_spread_deg = 90; // models.py:29
+    cfg->lidar_dist = 100;
+    cfg->goal_radius = 5;       // game.py:82
+    cfg->width = 600;           // config.py:24
+    cfg->height = 600;
+    cfg->dt = 10 * 0.1;         // SPEED * base_dt, config.py:23, game.py:27
+    cfg->damping_pow_dt = std::pow(0.4, cfg->dt); // game.py:270
+    cfg->spawn_x = 600 / 2.0;   // game.py:274
+    cfg->spawn_y = 25;
+    cfg->force_y = 100;         // models.py:107
+    cfg->thrust_px0 = 0.0;      // models.py:109: shape.bb.center() of a shape not yet in a space
+    cfg->thrust_py0 = 0.0;
+    cfg->rudder_step = 5;       // game.py:149-151
+    cfg->rudder_max = 10;       // models.py:110
+    return set_ship(cfg, 2.0, 3.0, 5.0); // game.py:275, models.py:87
+}
+
+int ssg_config_set_ship(ssg_config *cfg, double width_scale, double height_scale, double mass)
+{
+    if (!cfg || !(mass > 0.0) || !(width_scale > 0.0) || !(height_scale > 0.0))
+        return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_config_set_ship: bad argument");
+    return set_ship(cfg, width_scale, height_scale, mass);
+}
+
+int ssg_create(const ssg_config *cfg, ssg_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: NULL argument");
+    if (cfg->struct_size != sizeof(ssg_config)) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: struct_size mismatch");
+    if (cfg->n_envs < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: n_envs must be >= 1");
+    if (cfg->n_beams < 1 || cfg->n_beams > SSG_MAX_BEAMS)
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_beams must be in 1..16");
+    // ship_env.py:46-47 raises ValueError("history_size must be greater than zero")
+    if (cfg->history < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "history_size must be greater than zero");
+    if (cfg->history > 2) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: history > 2 is not supported by ABI v1");
+    if (cfg->n_goals < 1 || cfg->n_goals > 7) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_goals must be in 1..7");
+    if (!(cfg->dt > 0.0)) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: dt must be > 0");
+    if (cfg->max_steps < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: max_steps must be >= 1");
+    ssg_handle *h = new (std::nothrow) ssg_handle();
+    if (!h) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: out of host memory");
+    h->cfg = *cfg;
+    h->n_pad = (cfg->n_envs + ssg::kPadEnvs - 1) / ssg::kPadEnvs * ssg::kPadEnvs;
+    const size_t np = (size_t)h->n_pad;
+    h->off_stats = 0;
+    h->off_f64 = ssg::kStatsDoubles * sizeof(double);
+    h->off_i32 = h->off_f64 + (size_t)(ssg::COL_LIDAR + cfg->n_beams) * np * sizeof(double);
+    h->off_mask = h->off_i32 + (size_t)ssg::ICOL_COUNT * np * sizeof(int32_t);
+    h->nbytes = h->off_mask + np;
+    h->block = pick_block(cfg->n_envs);
+    refresh_dev(h);
+    *out = h;
+    return SSG_OK;
+}
+
+int ssg_destroy(ssg_handle *h)
+{
+    delete h;
+    return SSG_OK;
+}
+
+int ssg_state_nbytes(const ssg_handle *h, size_t *nbytes)
+{
+    if (!h || !nbytes) return SSG_ERR_BAD_ARG;
+    *nbytes = h->nbytes;
+    return SSG_OK;
+}
+
+int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_size, int *n_columns,
+                    size_t *column_stride_bytes)
+{
+    if (!h || !offset || !elem_size || !n_columns || !column_stride_bytes) return SSG_ERR_BAD_ARG;
+    const size_t np = (size_t)h->n_pad;
+    size_t off;
+    int es, nc;
+    if (field >= SSG_F_X && field <= SSG_F_CUM_REWARD) {
+        off = h->off_f64 + (size_t)field * np * 8; es = 8; nc = 1;
+    } else if (field == SSG_F_LIDAR) {
+        off = h->off_f64 + (size_t)ssg::COL_LIDAR * np * 8; es = 8; nc = h->cfg.n_beams;
+    } else if (field == SSG_F_RUDDER || field == SSG_F_STEP_COUNT || field == SSG_F_MAP_ID) {
+        off = h->off_i32 + (size_t)(field - SSG_F_RUDDER) * np * 4; es = 4; nc = 1;
+    } else if (field == SSG_F_GOAL_MASK) {
+        off = h->off_mask; es = 1; nc = 1;
+    } else if (field == SSG_F_STATS) {
+        off = h->off_stats; es = 8; nc = 4;
+        *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = 8;
+        return SSG_OK;
+    } else {
+        return SSG_ERR_BAD_ARG;
+    }
+    *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = np * (size_t)es;
+    return SSG_OK;
+}
+
+int ssg_bind_state(ssg_handle *h, void *dev_state)
+{
+    if (!h || !dev_state) return fail(h, SSG_ERR_BAD_ARG, "ssg_bind_state: NULL argument");
+    if (reinterpret_cast<uintptr_t>(dev_state) % 256 != 0)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_bind_state: state blob must be 256-byte aligned");
+    h->state = dev_state;
+    refresh_dev(h);
+    return SSG_OK;
+}
+
+int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
+{
+    if (!h || !dev_bank || n_maps < 1) return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bad argument");
+    if (reinterpret_cast<uintptr_t>(dev_bank) % 16 != 0)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
+    h->bank = dev_bank;
+    h->n_maps = n_maps;
+    h->lds_bytes = (size_t)n_maps * SSG_MAP_STRIDE * sizeof(double);
+    h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) && h->lds_bytes <= 160u * 1024u; // 160 KiB LDS per CU on gfx950
+    h->prepared = false;
+    refresh_dev(h);
+    return SSG_OK;
+}
+
+int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids, double *dev_obs, void *stream)
+{
+    int rc = check_ready(h, true);
+    if (rc != SSG_OK) return rc;
+    hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("reset launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
+static int prepare(ssg_handle *h)
+{
+    if (h->prepared) return SSG_OK;
+    hipError_t e = ssg::prepare_step(h->dev, h->block, h->lds, h->lds_bytes);
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("prepare_step: ") + hipGetErrorString(e));
+    h->prepared = true;
+    return SSG_OK;
+}
+
+int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
+             uint8_t *dev_flags, void *stream)
+{
+    return ssg_rollout(h, dev_actions, 1, dev_obs, dev_reward, dev_done, dev_flags, stream);
+}
+
+int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_obs, double *dev_reward,
+                uint8_t *dev_done, uint8_t *dev_flags, void *stream)
+{
+    int rc = check_ready(h, true);
+    if (rc != SSG_OK) return rc;
+    if (!dev_actions || !dev_obs || !dev_reward || !dev_done || K < 1)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_step/ssg_rollout: NULL buffer or K < 1");
+    rc = prepare(h);
+    if (rc != SSG_OK) return rc;
+    for (int k = 0; k < K; ++k) {
+        hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs,
+                                        dev_obs, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+    }
+    return SSG_OK;
+}
+
+int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_t *dev_actions, void *stream)
+{
+    if (!h || !dev_actions || K < 1) return fail(h, SSG_ERR_BAD_ARG, "ssg_fill_actions: bad argument");
+    hipError_t e = ssg::launch_fill_actions(seed, step0, K, h->cfg.env_id_base, h->cfg.n_envs, dev_actions,
+                                            static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("fill_actions launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
+// ---- host geometry ----
+int ssg_host_convex_hull(int count, const double *verts_xy, double *out_xy, int *out_count)
+{
+    if (count < 1 || !verts_xy || !out_xy || !out_count) return SSG_ERR_BAD_ARG;
+    std::vector<P2> v(count);
+    for (int i = 0; i < count; ++i) v[i] = P2{verts_xy[2 * i], verts_xy[2 * i + 1]};
+    std::vector<P2> h = convex_hull(v);
+    for (size_t i = 0; i < h.size(); ++i) { out_xy[2 * i] = h[i].x; out_xy[2 * i + 1] = h[i].y; }
+    *out_count = (int)h.size();
+    return SSG_OK;
+}
+
+int ssg_host_moment_for_poly(double mass, int count, const double *verts_xy, double *out)
+{
+    if (count < 3 || !verts_xy || !out) return SSG_ERR_BAD_ARG;
+    *out = moment_for_poly(mass, count, verts_xy);
+    return SSG_OK;
+}
+
+int ssg_host_build_map(const double *left_xy, int n_left, const double *right_xy, int n_right, const double *goals_xy,
+                       int n_goals, double spawn_x, double spawn_y, double *rec)
+{
+    if (!left_xy || !right_xy || !rec || n_left < 3 || n_right < 3 || n_goals < 0 || n_goals > SSG_MAX_GOALS ||
+        (n_goals > 0 && !goals_xy))
+        return SSG_ERR_BAD_ARG;
+    std::fill(rec, rec + SSG_MAP_STRIDE, 0.0);
+    const double *src[2] = {left_xy, right_xy};
+    const int cnt[2] = {n_left, n_right};
+    for (int s = 0; s < 2; ++s) {
+        std::vector<P2> v(cnt[s]);
+        for (int i = 0; i < cnt[s]; ++i) v[i] = P2{src[s][2 * i], src[s][2 * i + 1]};
+        std::vector<P2> hull = convex_hull(v); // pm.Poly hulls its vertex list, models.py:180
+        if (hull.size() < 3 || hull.size() > SSG_MAX_HULL) return SSG_ERR_UNSUPPORTED;
+        std::vector<Plane> pl = planes_of(hull);
+        rec[SSG_MAP_OFF_COUNTS + s] = (double)hull.size();
+        double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY; // cpPolyShapeCacheData on a static body
+        for (const P2 &p : hull) {
+            l = std::min(l, p.x); r = std::max(r, p.x);
+            b = std::min(b, p.y); t = std::max(t, p.y);
+        }
+        double *bbp = rec + SSG_MAP_OFF_AABB + 4 * s;
+        bbp[0] = l; bbp[1] = b; bbp[2] = r; bbp[3] = t;
+        double *pp = rec + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
+        for (size_t i = 0; i < pl.size(); ++i) {
+            double *q = pp + SSG_PLANE_DOUBLES * i;
+            q[0] = pl[i].v0x; q[1] = pl[i].v0y; q[2] = pl[i].nx; q[3] = pl[i].ny;
+            q[4] = pl[i].v0n; q[5] = pl[i].dtmin; q[6] = pl[i].dtmax; q[7] = 0.0;
+        }
+    }
+    for (int g = 0; g < n_goals; ++g) {
+        rec[SSG_MAP_OFF_GOALS + 2 * g] = goals_xy[2 * g];
+        rec[SSG_MAP_OFF_GOALS + 2 * g + 1] = goals_xy[2 * g + 1];
+    }
+    // the reset observation's nearest goal (closest_goal, game.py:333-349: strict '<', first listed wins)
+    double gx = -1.0, gy = -1.0, best = 0.0;
+    for (int g = 0; g < n_goals; ++g) {
+        const double dx = goals_xy[2 * g] - spawn_x, dy = goals_xy[2 * g + 1] - spawn_y;
+        const double d = std::sqrt(dx * dx + dy * dy);
+        if (g == 0 || d < best) { best = d; gx = goals_xy[2 * g]; gy = goals_xy[2 * g + 1]; }
+    }
+    rec[SSG_MAP_OFF_SPAWN_GOAL] = gx;
+    rec[SSG_MAP_OFF_SPAWN_GOAL + 1] = gy;
+    return SSG_OK;
+}
+
+int ssg_host_segment_query(const double *rec, int side, double ax, double ay, double bx, double by, double radius,
+                           int *hit, double *px, double *py, double *alpha)
+{
+    if (!rec || side < 0 || side > 1 || !hit) return SSG_ERR_BAD_ARG;
+    SegHit r = segment_query(hull_of_record(rec, side), ax, ay, bx, by, radius);
+    *hit = r.hit ? 1 : 0;
+    if (px) *px = r.px;
+    if (py) *py = r.py;
+    if (alpha) *alpha = r.alpha;
+    return SSG_OK;
+}
+
+int ssg_host_goal_x_range(const double *rec, double width, double y, double *lo, double *hi, int *hit)
+{
+    if (!rec || !lo || !hi || !hit) return SSG_ERR_BAD_ARG;
+    // game.py:322-325: fat (radius 10) rays from the mid-line to x=0 and x=W; [0] of each hit list; tolerance 60.
+    const double tolerance = 60.0;
+    const double ax = width / 2, ay = y;
+    SegHit l{false, 0, 0, 1}, r{false, 0, 0, 1};
+    for (int s = 0; s < 2 && !l.hit; ++s) l = segment_query(hull_of_record(rec, s), ax, ay, 0.0, y, 10.0);
+    for (int s = 0; s < 2 && !r.hit; ++s) r = segment_query(hull_of_record(rec, s), ax, ay, width, y, 10.0);
+    *hit = (l.hit && r.hit) ? 1 : 0;
+    if (*hit) {
+        *lo = l.px + tolerance;
+        *hi = r.px - tolerance;
+    }
+    return SSG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,48 @@
+// shipsim_internal.h — shared between the kernels (.hip) and the C-ABI host layer (.cpp).  Not installed.
+#ifndef SHIPSIM_INTERNAL_H
+#define SHIPSIM_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "shipsim.h"
+
+namespace ssg {
+
+// f64 column indices inside the state blob (each column = n_pad doubles, lane-contiguous)
+enum { COL_X = 0, COL_Y, COL_VX, COL_VY, COL_A, COL_W, COL_CUM, COL_LIDAR /* + n_beams columns */ };
+// i32 column indices
+enum { ICOL_RUDDER = 0, ICOL_STEP, ICOL_MAP, ICOL_COUNT };
+
+constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
+constexpr int kStatsDoubles = 32; // 256-byte header: [0] sum_return [1] sum_length [2] episodes [3] goals hit
+
+// Kernel argument block (by value in kernarg memory; wave-uniform -> SGPRs).
+struct DevCfg {
+    int n_envs, n_pad;
+    long long env_id_base;
+    int n_beams, history, max_steps, n_goals;
+    unsigned flags;
+    int n_maps;
+    int rudder_step, rudder_max;
+    double spread_deg, lidar_dist, goal_r, width, height, dt, damp, spawn_x, spawn_y;
+    double hull[2 * SSG_SHIP_VERTS], nrm[2 * SSG_SHIP_VERTS];
+    double m_inv, i_inv, force_y, px0, py0;
+    double *f64cols;
+    int32_t *i32cols;
+    uint8_t *mask;
+    double *stats;
+    const double *bank;
+};
+
+hipError_t launch_step(const DevCfg &c, int block, bool lds, size_t lds_bytes, const int32_t *actions, double *obs,
+                       double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream);
+hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
+hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
+hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long env_base, int n, int32_t *out,
+                               hipStream_t stream);
+
+} // namespace ssg
+#endif

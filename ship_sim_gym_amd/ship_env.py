@@ -1,0 +1,150 @@
+"""Single-env view with the reference's ``ShipEnv`` surface (ship_gym/ship_env.py:16-184), backed by one lane of
+the HIP path in reference-exact ``fresh`` map mode: every ``reset()`` draws a brand-new river and goal path from
+the global ``random`` / ``np.random`` streams in the reference's call order, so identical seeds give identical
+worlds.  ``env.game`` offers the attribute reach-through the reference's tests use (tests/test_ship_env.py:22-36).
+
+Stepping after ``done`` without ``reset()`` is outside the contract: the reference would keep simulating contact
+response with Chipmunk's impulse solver, which this path does not carry.
+"""
+import numpy as np
+
+from . import _native as N
+from .vec_env import ShipVecEnv
+
+try:  # pragma: no cover
+    from gym import Env as _GymEnv  # type: ignore
+except Exception:
+    _GymEnv = object
+
+DEFAULT_STATE_VAL = -1
+STEP_PENALTY = -0.01
+
+
+class _Body(object):
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def angle(self):
+        return float(self._env._vec.field(N.F_ANGLE)[0].item())
+
+    @property
+    def position(self):
+        v = self._env._vec
+        return (float(v.field(N.F_X)[0].item()), float(v.field(N.F_Y)[0].item()))
+
+
+class _Goal(object):
+    def __init__(self, x, y):
+        self.x, self.y = float(x), float(y)
+
+    def __repr__(self):
+        return "Goal(%s, %s)" % (self.x, self.y)
+
+
+class _Player(object):
+    def __init__(self, env):
+        self._env = env
+        self.body = _Body(env)
+
+    @property
+    def x(self):
+        return self.body.position[0]
+
+    @property
+    def y(self):
+        return self.body.position[1]
+
+    @property
+    def rudder_angle(self):
+        return int(self._env._vec.field(N.F_RUDDER)[0].item())
+
+
+class _GameView(object):
+    """Read-only stand-in for ShipGame's attributes (game.py:21-58): player, goals, colliding, goal_reached, bounds."""
+
+    def __init__(self, env):
+        self._env = env
+        self.player = _Player(env)
+        self.bounds = env._vec.bounds
+
+    @property
+    def goals(self):
+        mask = int(self._env._vec.field(N.F_GOAL_MASK)[0].item())
+        g = self._env._vec.worlds[0][1]
+        return [_Goal(g[i, 0], g[i, 1]) for i in range(len(g)) if mask & (1 << i)]
+
+    @property
+    def colliding(self):
+        return bool(self._env._last_flags & N.EV_COLLIDING)
+
+    @property
+    def goal_reached(self):
+        return bool(self._env._last_flags & N.EV_GOAL_REACHED)
+
+    def closest_goal(self):
+        goals = self.goals
+        if not goals:
+            return None
+        px, py = self.player.body.position
+        best, bd = goals[0], np.hypot(goals[0].x - px, goals[0].y - py)
+        for g in goals[1:]:
+            d = np.hypot(g.x - px, g.y - py)
+            if d < bd:
+                best, bd = g, d
+        return best
+
+
+class ShipEnv(_GymEnv):
+    metadata = {'render.modes': ['human', 'rgb_array']}
+    reward_range = (-1, 1)
+
+    def __init__(self, game_config=None, env_config=None, device="cuda:0", **kw):
+        self._vec = ShipVecEnv(1, game_config, env_config, device=device, map_mode="fresh", auto_reset=False, **kw)
+        self.action_space = self._vec.action_space
+        self.observation_space = self._vec.observation_space
+        self.env_config = env_config
+        self.n_states = self._vec.n_states
+        self.states_history = self._vec.states_history
+        self.game = _GameView(self)
+        self.last_action = None
+        self.reward = 0
+        self.cumulative_reward = 0
+        self.step_count = 0
+        self.episodes_count = -1  # ship_env.py:33
+        self._last_flags = 0
+        self.states = None
+
+    def seed(self, seed=None):
+        np.random.seed(seed)  # ship_env.py:57-59
+        return [seed]
+
+    def reset(self):
+        obs = self._vec.reset()[0]
+        self.last_action = None
+        self.reward = 0
+        self.cumulative_reward = 0
+        self.step_count = 0
+        self.episodes_count += 1
+        self._last_flags = 0
+        self.states = obs
+        return obs
+
+    def step(self, action):
+        assert self.action_space.contains(action), "%r (%s) invalid" % (action, type(action))  # ship_env.py:143
+        obs, rew, done, _ = self._vec.step(np.asarray([action]))
+        self._last_flags = int(self._vec.flags[0].item())
+        self.last_action = action
+        self.reward = float(rew[0])
+        self.cumulative_reward += self.reward
+        self.step_count += 1
+        self.states = obs[0]
+        return obs[0], self.reward, bool(done[0]), {}
+
+    def render(self, mode='human', close=False):
+        import sys
+        if self.last_action is not None:  # ship_env.py:165-168
+            sys.stdout.write('action=%s, cumm_reward=%s' % (self.last_action, self.cumulative_reward))
+
+    def close(self):
+        self._vec.close()

@@ -1,0 +1,305 @@
+"""ShipVecEnv — the batched, MI355X-resident ShipEnv.
+
+Keeps the reference's gym surface (ship_gym/ship_env.py:16-184: ``action_space = Discrete(3)``,
+``observation_space = Box(0, max(bounds), (n_states*H,), uint8)``, ``reset()``, ``step()``) but for N envs at
+once, and speaks the two vector-env protocols the reference's trainers use:
+
+* stable-baselines 2.2.0 ``VecEnv`` (train/stable_baselines/ppo.py:122-123 builds a SubprocVecEnv): ``num_envs``,
+  ``reset() -> obs[N,D]``, ``step_async(actions)``, ``step_wait() -> (obs, rews, dones, infos)``, ``step``,
+  ``close``; a done env is reset inside the step and its returned observation is the reset observation.
+* RLlib 0.6.0 ``VectorEnv`` (train/rllib/ppo.py:21-24,43): ``vector_reset()``, ``reset_at(i)``,
+  ``vector_step(actions)``, ``get_unwrapped()``.
+
+State for all envs lives in one caller-owned torch-ROCm byte tensor (struct-of-arrays columns, see
+include/shipsim.h); PyTorch is only the device-buffer container and stream provider.  All compute goes through
+libshipsim.so; there is no CPU path.
+
+Two map modes:
+* ``"bank"`` (default): a fixed bank of ``n_maps`` pre-generated worlds lives in HBM (and is staged in LDS by
+  the kernel); env e starts on map ``(env_id_base+e) % n_maps`` and every in-kernel auto-reset moves it to the
+  next map.  No host involvement per step.
+* ``"fresh"``: reference-exact resets — every reset draws a brand-new world from the global ``random`` /
+  ``np.random`` streams on the host (game.py:260-277), one bank slot per env.  Needs a host round trip on done.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _native as N
+from . import config as cfgmod
+from . import spaces, worldgen
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class ShipVecEnv(object):
+    metadata = {'render.modes': ['human', 'rgb_array']}  # ship_env.py:18
+    reward_range = (-1, 1)                                # ship_env.py:20
+
+    def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
+                 map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
+                 fix_collision_reward=False, bank_in_global=False):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        game_config = game_config if game_config is not None else cfgmod.GameConfig
+        env_config = env_config if env_config is not None else cfgmod.EnvConfig
+        if env_config.HISTORY_SIZE < 1:  # ship_env.py:46-47
+            raise ValueError("history_size must be greater than zero")
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self.map_mode = map_mode
+        self.bounds = tuple(game_config.BOUNDS)
+        self.width_frac = float(width_frac)
+        self.auto_reset = bool(auto_reset)
+        self.env_id_base = int(env_id_base)
+
+        c = N.default_config()
+        c.device_id = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        c.n_envs = self.num_envs
+        c.env_id_base = self.env_id_base
+        if n_beams is None:
+            if getattr(env_config, "USE_LIDAR_CONFIG", False):
+                lc = env_config.LIDAR_CONFIG
+                c.n_beams, c.lidar_spread_deg, c.lidar_dist = lc.N_BEAMS, lc.ANGULAR_SPREAD, lc.DISTANCE
+            else:  # the reference ignores LidarConfig: LiDAR() defaults (models.py:29,150)
+                c.n_beams = cfgmod.LIDAR_DEFAULT_N_BEAMS
+        else:
+            c.n_beams = int(n_beams)
+        c.history = int(env_config.HISTORY_SIZE)
+        c.max_steps = int(env_config.MAX_STEPS)
+        c.n_goals = cfgmod.N_GOALS
+        c.width, c.height = float(self.bounds[0]), float(self.bounds[1])
+        c.dt = game_config.SPEED * cfgmod.BASE_DT                 # game.py:194: speed * base_dt
+        c.damping_pow_dt = math.pow(cfgmod.SPACE_DAMPING, c.dt)   # cpSpaceStep: pow(space.damping, dt)
+        c.spawn_x, c.spawn_y = self.bounds[0] / 2, 25.0           # game.py:274
+        flags = 0
+        if self.auto_reset and map_mode == "bank":
+            flags |= N.FLAG_AUTO_RESET
+        if fix_collision_reward:
+            flags |= N.FLAG_FIX_COLLISION_REWARD
+        if bank_in_global or map_mode == "fresh":
+            flags |= N.FLAG_BANK_IN_GLOBAL
+        c.flags = flags
+        self.cfg = c
+        self.n_states = 6 + c.n_beams                              # ship_env.py:43
+        self.states_history = self.n_states * c.history            # ship_env.py:44
+        self.action_space = spaces.Discrete(3)                     # ship_env.py:19
+        self.observation_space = spaces.Box(low=0, high=max(self.bounds), shape=(self.states_history,),
+                                            dtype=np.uint8)       # ship_env.py:48 (declared uint8; obs are float64)
+
+        L = N.lib()
+        self._h = C.c_void_p()
+        N.check(L.ssg_create(C.byref(c), C.byref(self._h)), None, "ssg_create")
+        nbytes = C.c_size_t()
+        N.check(L.ssg_state_nbytes(self._h, C.byref(nbytes)), self._h, "ssg_state_nbytes")
+        with torch.cuda.device(self.device):
+            self.state = torch.zeros(nbytes.value, dtype=torch.uint8, device=self.device)
+            self.obs = torch.empty((self.num_envs, self.states_history), dtype=torch.float64, device=self.device)
+            self.reward = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
+            self.done = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+            self.flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+            self._actions = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        N.check(L.ssg_bind_state(self._h, C.c_void_p(self.state.data_ptr())), self._h, "ssg_bind_state")
+
+        # ---- map bank ----
+        if map_mode == "bank":
+            if bank is None:
+                bank, self.bank_polys, self.bank_goals = worldgen.build_bank(
+                    n_maps, self.bounds, n_goals=c.n_goals, width_frac=self.width_frac, seed=map_seed)
+            else:
+                self.bank_polys = self.bank_goals = None
+            self.set_bank(bank)
+        elif map_mode == "fresh":
+            # reference-exact: ShipGame.__init__ ends with self.reset() (game.py:58), so constructing an env already
+            # consumes one world's worth of RNG; the user's reset() draws another (App. B-17).
+            self.bank_host = np.zeros((self.num_envs, N.MAP_STRIDE), dtype=np.float64)
+            self.worlds = [None] * self.num_envs
+            for e in range(self.num_envs):
+                self._fresh_world(e)
+            self.set_bank(self.bank_host)
+        else:
+            raise ValueError("map_mode must be 'bank' or 'fresh'")
+        self._pending = None
+        self._closed = False
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _fresh_world(self, e):
+        rec, polys, goals = worldgen.generate_world(self.bounds, n_goals=self.cfg.n_goals, width_frac=self.width_frac)
+        self.bank_host[e] = rec
+        self.worlds[e] = (polys, goals)
+
+    def set_bank(self, bank):
+        """Install a map bank (numpy [M, MAP_STRIDE] or a device tensor).  A curriculum lesson change calls this."""
+        torch = _torch()
+        if isinstance(bank, np.ndarray):
+            bank = torch.from_numpy(np.ascontiguousarray(bank, dtype=np.float64)).to(self.device)
+        assert bank.dtype == torch.float64 and bank.shape[1] == N.MAP_STRIDE and bank.is_contiguous()
+        self.bank = bank
+        self.n_maps = int(bank.shape[0])
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ssg_set_map_bank(self._h, C.c_void_p(bank.data_ptr()), self.n_maps), self._h,
+                    "ssg_set_map_bank")
+
+    def field(self, fid):
+        """Typed torch view [n_columns, num_envs] (or [num_envs]) into the state blob."""
+        torch = _torch()
+        off, es, nc, stride = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t()
+        N.check(N.lib().ssg_state_field(self._h, fid, C.byref(off), C.byref(es), C.byref(nc), C.byref(stride)), self._h,
+                "ssg_state_field")
+        dt = {8: torch.float64, 4: torch.int32, 1: torch.uint8}[es.value]
+        if fid == N.F_STATS:
+            return self.state[off.value: off.value + 8 * nc.value].view(torch.float64)
+        n_pad = stride.value // es.value
+        v = self.state[off.value: off.value + nc.value * stride.value].view(dt).view(nc.value, n_pad)[:, :self.num_envs]
+        return v[0] if nc.value == 1 else v
+
+    def stats(self):
+        """Per-handle episode counters accumulated in-kernel: sum_return, sum_length, episodes, goals_hit."""
+        s = self.field(N.F_STATS).cpu().numpy()
+        return {"sum_return": float(s[0]), "sum_length": float(s[1]), "episodes": float(s[2]), "goals_hit": float(s[3])}
+
+    # ------------------------------------------------------------------------------------------------
+    # tensor API (zero-copy; what a GPU-resident policy should use)
+    # ------------------------------------------------------------------------------------------------
+    def reset_tensor(self, mask=None, map_ids=None):
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
+            ip = C.c_void_p(map_ids.data_ptr()) if map_ids is not None else None
+            if self.map_mode == "fresh" and map_ids is None:
+                ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+                ip = C.c_void_p(ids.data_ptr())
+            N.check(N.lib().ssg_reset(self._h, mp, ip, C.c_void_p(self.obs.data_ptr()), self._stream()), self._h,
+                    "ssg_reset")
+            if self.map_mode == "fresh" and map_ids is None:
+                torch.cuda.current_stream(self.device).synchronize()  # keep `ids` alive until the kernel ran
+        return self.obs
+
+    def step_tensor(self, actions):
+        """actions: int32 device tensor [N].  Returns (obs, reward, done, flags) device tensors (reused buffers)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ssg_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                     C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                     C.c_void_p(self.flags.data_ptr()), self._stream()), self._h, "ssg_step")
+        return self.obs, self.reward, self.done, self.flags
+
+    def rollout_tensor(self, actions_kn):
+        """K back-to-back steps from a pre-generated int32 [K, N] action tensor (random-action throughput run)."""
+        torch = _torch()
+        K = int(actions_kn.shape[0])
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, C.c_void_p(self.obs.data_ptr()),
+                                        C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                        C.c_void_p(self.flags.data_ptr()), self._stream()), self._h, "ssg_rollout")
+        return self.obs, self.reward, self.done, self.flags
+
+    def random_actions(self, seed, step0, K):
+        """int32 [K, N] Philox action stream keyed by (seed, step, global env id), generated on the device."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            out = torch.empty((K, self.num_envs), dtype=torch.int32, device=self.device)
+            N.check(N.lib().ssg_fill_actions(self._h, int(seed), int(step0), int(K), C.c_void_p(out.data_ptr()),
+                                             self._stream()), self._h, "ssg_fill_actions")
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    # stable-baselines VecEnv protocol (numpy in / numpy out)
+    # ------------------------------------------------------------------------------------------------
+    def reset(self):
+        if self.map_mode == "fresh":
+            for e in range(self.num_envs):
+                self._fresh_world(e)
+            self.bank.copy_(_torch().from_numpy(self.bank_host))
+        return self.reset_tensor().cpu().numpy()
+
+    def step_async(self, actions):
+        a = np.asarray(actions)
+        for v in a.reshape(-1):
+            assert self.action_space.contains(int(v)), "%r (%s) invalid" % (v, type(v))  # ship_env.py:143
+        self._pending = a.astype(np.int32).reshape(self.num_envs)
+
+    def step_wait(self):
+        torch = _torch()
+        self._actions.copy_(torch.from_numpy(self._pending))
+        obs, rew, done, flags = self.step_tensor(self._actions)
+        done_h = done.cpu().numpy().astype(bool)
+        if self.map_mode == "fresh" and self.auto_reset and done_h.any():
+            # host-side auto-reset with brand-new worlds (reference-exact resets)
+            for e in np.nonzero(done_h)[0]:
+                self._fresh_world(int(e))
+            self.bank.copy_(torch.from_numpy(self.bank_host))
+            mask = torch.from_numpy(done_h.astype(np.uint8)).to(self.device)
+            ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+            self.reset_tensor(mask=mask, map_ids=ids)
+            torch.cuda.current_stream(self.device).synchronize()
+        infos = [{} for _ in range(self.num_envs)]
+        return obs.cpu().numpy(), rew.cpu().numpy(), done_h, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        if not self._closed and self._h:
+            N.lib().ssg_destroy(self._h)
+            self._h = None
+            self._closed = True
+
+    def seed(self, seed=None):
+        """ShipEnv.seed seeds numpy's global generator only (ship_env.py:52-60)."""
+        np.random.seed(seed)
+        return [seed]
+
+    def render(self, mode='human', close=False):
+        return None  # pygame rendering is out of scope
+
+    def get_attr(self, name, indices=None):
+        return [getattr(self, name)] * self.num_envs
+
+    def env_method(self, method_name, *args, **kwargs):
+        raise NotImplementedError(method_name)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------
+    # RLlib VectorEnv protocol
+    # ------------------------------------------------------------------------------------------------
+    def vector_reset(self):
+        return list(self.reset())
+
+    def reset_at(self, index):
+        torch = _torch()
+        mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        mask[index] = 1
+        if self.map_mode == "fresh":
+            self._fresh_world(int(index))
+            self.bank.copy_(torch.from_numpy(self.bank_host))
+            ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+            self.reset_tensor(mask=mask, map_ids=ids)
+        else:
+            ids = self.field(N.F_MAP_ID).clone()
+            ids[index] = (ids[index] + 1) % self.n_maps
+            self.reset_tensor(mask=mask, map_ids=ids.contiguous())
+        torch.cuda.current_stream(self.device).synchronize()
+        return self.obs[index].cpu().numpy()
+
+    def vector_step(self, actions):
+        obs, rew, done, infos = self.step(np.asarray(actions))
+        return list(obs), list(rew), list(done), infos
+
+    def get_unwrapped(self):
+        return []
