@@ -58,6 +58,11 @@ def lib():
         raise ShipSimError(
             "libshipsim.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ship_sim_gym_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # libshipsim.so needs libamdhip64.so.7.  PyTorch-ROCm bundles its own copy of that runtime (same SONAME) and
+    # is the owner of the device memory and streams we are handed, so torch must be imported FIRST: the dynamic
+    # loader then binds our HIP calls to the runtime already in the process instead of mapping a second one from
+    # /opt/rocm (two HIP runtimes in one process cannot share streams and fail at the first hipGetDevice).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, dp, i32p, u8p, szp, ip = (C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
                                  C.POINTER(C.c_size_t), C.POINTER(C.c_int))
