@@ -89,7 +89,15 @@ def main():
 
     n = args.envs_per_gpu
     vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=N_BEAMS,
-                     env_id_base=rank * n)
+                     env_id_base=rank * n, exact_lidar=bool(int(os.environ.get("SSG_EXACT_LIDAR", "0"))))
+    if os.environ.get("SSG_ABLATE"):  # timing-only development aid (needs a -DSSG_ABLATION build)
+        import ctypes as C
+        vec.cfg.flags |= int(os.environ["SSG_ABLATE"], 0) << 16
+        from ship_sim_gym_amd import _native as N
+        N.lib().ssg_destroy(vec._h)
+        N.check(N.lib().ssg_create(C.byref(vec.cfg), C.byref(vec._h)), None, "ssg_create")
+        N.check(N.lib().ssg_bind_state(vec._h, C.c_void_p(vec.state.data_ptr())), vec._h, "bind")
+        vec.set_bank(vec.bank)
     if world > 1:
         sharding.broadcast_bank(vec, src=0)  # RCCL broadcast of the map bank over xGMI; the only collective on the path
 

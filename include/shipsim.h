@@ -49,6 +49,11 @@ typedef enum ssg_status {
 #define SSG_FLAG_BANK_IN_GLOBAL    0x4u /* never stage the map bank in LDS (per-lane gathers from L2/HBM); forced
                                            when the bank does not fit LDS or when every env has its own slot */
 
+#define SSG_FLAG_EXACT_LIDAR       0x8u /* lidar: intersect every hull plane with every beam exactly as
+                                           cpPolyShapeSegmentQuery does (one division per plane and beam) instead of
+                                           the default one-division-per-beam evaluation of the same predicate; the two
+                                           differ only for rays within rounding of a hull vertex.  Validation aid. */
+
 /*
  * Map bank record: SSG_MAP_STRIDE doubles per map, built on the host by ssg_host_build_map().
  *   [0] nL  [1] nR                      hull plane counts (as doubles)
@@ -109,8 +114,9 @@ typedef enum ssg_field {
     SSG_F_STEP_COUNT,                                              /* i32: ShipEnv.step_count           */
     SSG_F_MAP_ID,                                                  /* i32: bank record of this env      */
     SSG_F_GOAL_MASK,                                               /* u8 : bit g = goal g still listed  */
-    SSG_F_STATS,                                                   /* f64 x 4 per handle: sum_return,
-                                                                      sum_length, n_episodes, n_goals_hit */
+    SSG_F_STATS,                                                   /* i64 [256 slots][4] per handle, to be summed
+                                                                      over slots: 100*sum_return, sum_length,
+                                                                      n_episodes, n_goals_hit */
     SSG_F_COUNT
 } ssg_field;
 

@@ -279,11 +279,10 @@ int pick_block(int n_envs)
 {
     if (const char *s = std::getenv("SSG_BLOCK")) {
         const int b = std::atoi(s);
-        if (b == 64 || b == 128 || b == 256 || b == 512) return b;
+        if (b == 64 || b == 256 || b == 512) return b;
     }
     // MI355X has 256 CUs: aim for >= 256 workgroups before growing the workgroup (one wave per SIMD first).
     if (n_envs <= 64 * 256) return 64;
-    if (n_envs <= 128 * 256) return 128;
     if (n_envs <= 256 * 256) return 256;
     return 512;
 }
@@ -422,7 +421,8 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
     } else if (field == SSG_F_GOAL_MASK) {
         off = h->off_mask; es = 1; nc = 1;
     } else if (field == SSG_F_STATS) {
-        off = h->off_stats; es = 8; nc = 4;
+        // kStatsSlots rows of 4 int64 counters; sum over rows: [0] sum_return*100 [1] sum_length [2] episodes [3] goals
+        off = h->off_stats; es = 8; nc = 4 * ssg::kStatsSlots;
         *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = 8;
         return SSG_OK;
     } else {

@@ -17,7 +17,8 @@ enum { COL_X = 0, COL_Y, COL_VX, COL_VY, COL_A, COL_W, COL_CUM, COL_LIDAR /* + n
 enum { ICOL_RUDDER = 0, ICOL_STEP, ICOL_MAP, ICOL_COUNT };
 
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
-constexpr int kStatsDoubles = 32; // 256-byte header: [0] sum_return [1] sum_length [2] episodes [3] goals hit
+constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
+constexpr int kStatsDoubles = 4 * kStatsSlots;
 
 // Kernel argument block (by value in kernarg memory; wave-uniform -> SGPRs).
 struct DevCfg {

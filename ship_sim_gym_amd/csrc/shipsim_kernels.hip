@@ -46,6 +46,25 @@ struct GlbRec {
 __device__ __forceinline__ double dmin(double a, double b) { return (a < b) ? a : b; } // cpfmin
 __device__ __forceinline__ double dmax(double a, double b) { return (a > b) ? a : b; } // cpfmax
 
+// Stage `bytes` (multiple of 16) from global memory into LDS at offset 0 with LDS-DMA (global_load_lds_dwordx4:
+// 1 KiB per wave-instruction, no VGPR round trip, all requests in flight at once), tail < 1 KiB through registers.
+template <int BLOCK>
+__device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, int bytes)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NW = BLOCK / 64;
+    const int nchunk = bytes >> 10;
+    const char *g = reinterpret_cast<const char *>(bank);
+    char *l = reinterpret_cast<char *>(lds_bank());
+    for (int c = wave; c < nchunk; c += NW) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (size_t)c * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(l + c * 1024), 16, 0, 0);
+    }
+    const int tail0 = nchunk << 10;
+    const int o = tail0 + (int)threadIdx.x * 16;
+    if (o < bytes) *reinterpret_cast<double2 *>(l + o) = *reinterpret_cast<const double2 *>(g + o);
+}
+
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
 template <class Rec>
 __device__ __forceinline__ void nearest_goal(const Rec &rec, unsigned gm, int n_goals, double x, double y, double &gx,
@@ -53,27 +72,116 @@ __device__ __forceinline__ void nearest_goal(const Rec &rec, unsigned gm, int n_
 {
     gx = -1.0;
     gy = -1.0;
-    double best = 0.0;
-    bool have = false;
+    double best = INFINITY;
     for (int g = 0; g < n_goals; ++g) {
-        if (gm & (1u << g)) {
-            double px = rec[SSG_MAP_OFF_GOALS + 2 * g], py = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
-            double dx = px - x, dy = py - y;
-            double d = sqrt(dx * dx + dy * dy);
-            if (!have || d < best) {
-                best = d;
-                gx = px;
-                gy = py;
-                have = true;
+        const double px = rec[SSG_MAP_OFF_GOALS + 2 * g], py = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
+        const double dx = px - x, dy = py - y;
+        const double d = sqrt(dx * dx + dy * dy);
+        const bool take = (gm & (1u << g)) && (d < best); // first alive goal always beats +inf
+        best = take ? d : best;
+        gx = take ? px : gx;
+        gy = take ? py : gy;
+    }
+}
+
+// One bank hull against the NB lidar beams of this lane: cpShapeSegmentQuery(shape, a=(cx,cy), b=(ex,ey), r=0).
+//   EXACT = true : cpPolyShapeSegmentQuery literally — every plane is intersected (one division per plane and
+//                  beam), accepted when the crossing lies inside the edge's extent, later planes overwrite.
+//   EXACT = false: the same predicate evaluated with one division per beam: among the planes the beam crosses
+//                  front-to-back within its length (d >= 0 and d <= den, i.e. 0 <= t <= 1) only the one with the
+//                  largest t can be the entry edge of a convex polygon, so only that plane gets the exact
+//                  t = d/den, lerp and edge-extent test of the reference.  Identical results except when a ray
+//                  passes within rounding of a hull vertex (then: adjacent edge, same point to ~1e-13).
+// Branch-free over lanes; the trip count is the wave-wide maximum plane count.
+template <int NB, bool EXACT, class Rec>
+__device__ __forceinline__ void lidar_hull(const Rec &rec, int s, double cx, double cy, const double (&ex)[NB],
+                                           const double (&ey)[NB], unsigned &hit, double (&hx)[NB], double (&hy)[NB])
+{
+    const int cnt = (int)rec[SSG_MAP_OFF_COUNTS + s];
+    const int pbase = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
+    bool outside = false; // cpPolyShapePointQuery(a): any plane with a strictly in front
+    hit = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { hx[i] = ex[i]; hy[i] = ey[i]; }
+    double bd[NB], bden[NB];
+    int bj[NB];
+    if (!EXACT) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { bd[i] = -1.0; bden[i] = 1.0; bj[i] = 0; }
+    }
+    for (int j = 0; __any(j < cnt); ++j) {
+        const bool valid = j < cnt;
+        const int jj = valid ? j : 0;
+        const double v0x = rec[pbase + 8 * jj + 0], v0y = rec[pbase + 8 * jj + 1];
+        const double nx = rec[pbase + 8 * jj + 2], ny = rec[pbase + 8 * jj + 3];
+        const double v0n = rec[pbase + 8 * jj + 4];
+        outside = outside || (valid && ((nx * (cx - v0x) + ny * (cy - v0y)) > 0.0));
+        const double an = cx * nx + cy * ny;
+        const double d = an - v0n;
+        const bool front = valid && !(d < 0.0);
+        if (EXACT) {
+            const double dtmin = rec[pbase + 8 * jj + 5], dtmax = rec[pbase + 8 * jj + 6];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double bn = ex[i] * nx + ey[i] * ny;
+                const double t = d / dmax(an - bn, DBL_MIN);
+                const double omt = 1.0 - t;
+                const double ptx = cx * omt + ex[i] * t, pty = cy * omt + ey[i] * t; // cpvlerp(a,b,t)
+                const double dtv = nx * pty - ny * ptx;                               // cpvcross(n, point)
+                const bool ok = front && !(t < 0.0 || 1.0 < t) && (dtmin <= dtv) && (dtv <= dtmax);
+                hit |= ok ? (1u << i) : 0u;
+                hx[i] = ok ? ptx : hx[i];
+                hy[i] = ok ? pty : hy[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double bn = ex[i] * nx + ey[i] * ny;
+                const double den = dmax(an - bn, DBL_MIN);
+                // candidate: 0 <= d/den <= 1; better: d/den >= best (cross-multiplied, dens > 0; ties -> later plane)
+                const bool better = front && (d <= den) && (d * bden[i] >= bd[i] * den);
+                bd[i] = better ? d : bd[i];
+                bden[i] = better ? den : bden[i];
+                bj[i] = better ? j : bj[i];
             }
         }
     }
+    if (!EXACT) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int q = pbase + 8 * bj[i];
+            const double nx = rec[q + 2], ny = rec[q + 3], dtmin = rec[q + 5], dtmax = rec[q + 6];
+            const double t = bd[i] / bden[i];
+            const double omt = 1.0 - t;
+            const double ptx = cx * omt + ex[i] * t, pty = cy * omt + ey[i] * t;
+            const double dtv = nx * pty - ny * ptx;
+            const bool ok = (bd[i] >= 0.0) && (dtmin <= dtv) && (dtv <= dtmax);
+            hit |= ok ? (1u << i) : 0u;
+            hx[i] = ptx;
+            hy[i] = pty;
+        }
+    }
+    // start point inside (or on) the polygon: hit at alpha 0 whose reported point is the FAR end b (App. A.7)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        hx[i] = outside ? hx[i] : ex[i];
+        hy[i] = outside ? hy[i] : ey[i];
+    }
+    hit = outside ? hit : ((1u << NB) - 1u);
 }
+
+// Timing-only ablation switches (development builds with -DSSG_ABLATION; never in the product library): bits
+// 16.. of DevCfg.flags skip a section so its share of the kernel time can be measured.  Outputs are wrong.
+#ifdef SSG_ABLATION
+#define SSG_ABL(bit) (c.flags & (1u << (16 + (bit))))
+#else
+#define SSG_ABL(bit) false
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // The step kernel
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, int BLOCK, bool LDS_BANK>
+template <int NB, int BLOCK, bool LDS_BANK, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions,
                                                      double *__restrict__ obs, double *__restrict__ reward_out,
                                                      uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out)
@@ -94,7 +202,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     int32_t *__restrict__ colStep = c.i32cols + ICOL_STEP * np;
     int32_t *__restrict__ colMap = c.i32cols + ICOL_MAP * np;
 
-    // ---- issue every state load first (coalesced; latency overlaps the LDS staging below) ----
+    // ---- the bank DMA and every state load are issued back to back; one wait covers them all ----
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<BLOCK>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
     const int el = live ? e : 0;
     double x = colX[el], y = colY[el], vx = colVX[el], vy = colVY[el], ang = colA[el], w = colW[el];
     double cum = colCum[el];
@@ -104,13 +213,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     int rudder = colRud[el], steps = colStep[el], map_id = colMap[el];
     unsigned gm = c.mask[el];
     const int act = actions[el];
-
     if (LDS_BANK) {
-        // Stage the whole bank: n_maps * SSG_MAP_STRIDE doubles, 16 bytes per lane per pass.
-        const int n16 = c.n_maps * (SSG_MAP_STRIDE / 2);
-        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(c.bank);
-        double2 *dst = reinterpret_cast<double2 *>(lds_bank());
-        for (int i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
         __syncthreads();
     }
     if (!live) return;
@@ -125,8 +229,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     const bool hist2 = c.history >= 2;
 
     // ---- previous frame (oldest slot of the 2-frame history) is a pure function of the pre-step state ----
-    double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang, pf_gx, pf_gy;
-    nearest_goal(rec, gm, c.n_goals, x, y, pf_gx, pf_gy);
+    const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang;
+    double pf_gx = 0, pf_gy = 0;
+    if (!SSG_ABL(0)) nearest_goal(rec, gm, c.n_goals, x, y, pf_gx, pf_gy);
     double pf_lid[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) pf_lid[i] = lid[i];
@@ -134,27 +239,28 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     // ---- handle_discrete_action (game.py:140-153) ----
     double sa, ca;
     sincos(ang, &sa, &ca); // cpvforangle(a) = (cos a, sin a): body->transform rotation
-    double fx = 0.0, fy = 0.0, tq = 0.0;
-    if (act == 0) {
+    double fx, fy, tq;
+    {
         // Ship.move_forward -> cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust)
         const double px = (gm & 0x80u) ? (0.0 - (double)rudder) : c.px0; // models.py:109,146
         const double py = c.py0;
         const double fwx = (-sa) * c.force_y, fwy = ca * c.force_y;      // cpTransformVect(transform, (0,F))
         const double pwx = ca * px + (-sa) * py + x, pwy = sa * px + ca * py + y; // cpTransformPoint
         const double rx = pwx - x, ry = pwy - y;                         // minus transform * cog, cog = (0,0)
-        fx = fwx;
-        fy = fwy;
-        tq = rx * fwy - ry * fwx;
-    } else if (act == 1 || act == 2) {
+        const bool thrust = act == 0;
+        fx = thrust ? fwx : 0.0;
+        fy = thrust ? fwy : 0.0;
+        tq = thrust ? (rx * fwy - ry * fwx) : 0.0;
+    }
+    if (act == 1 || act == 2) {
         // Ship.rotate(-5 / +5) + clamp_rudder (models.py:136-146)
         rudder += (act == 1) ? -c.rudder_step : c.rudder_step;
-        if (rudder < -c.rudder_max) rudder = -c.rudder_max;
-        else if (rudder > c.rudder_max) rudder = c.rudder_max;
+        rudder = max(-c.rudder_max, min(c.rudder_max, rudder));
         gm |= 0x80u;
     }
 
     // ---- LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step) ----
-    {
+    if (!SSG_ABL(1)) {
         double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
 #pragma unroll
         for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
@@ -169,65 +275,31 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
         const double angle_start = ang + (90.0 - c.spread_deg / 2) * deg2rad;
 
         double ex[NB], ey[NB];
-        unsigned decided = 0; // bit i: beam i already took a value from an earlier shape (first hit shape wins)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const double rotation = angle_start + (angle_delta * (double)i);
-            double sr, cr;
-            sincos(rotation, &sr, &cr);
+            double sr = rotation, cr = 1.0 - rotation;
+            if (!SSG_ABL(2)) sincos(rotation, &sr, &cr);
             ex[i] = cx + c.lidar_dist * cr;
             ey[i] = cy + c.lidar_dist * sr;
         }
-        for (int s = 0; s < 2; ++s) {
-            const int cnt = (int)rec[SSG_MAP_OFF_COUNTS + s];
-            const int pbase = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
-            // cpShapeSegmentQuery first asks cpShapePointQuery(a): a start point inside (or on) the polygon is a
-            // hit at alpha 0 whose reported point is the FAR end b.
-            bool outside = false;
-            for (int j = 0; j < cnt; ++j) {
-                const double v0x = rec[pbase + 8 * j + 0], v0y = rec[pbase + 8 * j + 1];
-                const double nx = rec[pbase + 8 * j + 2], ny = rec[pbase + 8 * j + 3];
-                outside = outside || ((nx * (cx - v0x) + ny * (cy - v0y)) > 0.0);
-            }
-            double hitx[NB], hity[NB];
-            unsigned hit = 0;
-            if (!outside) {
+        unsigned hit0 = 0, hit1 = 0;
+        double h0x[NB], h0y[NB], h1x[NB], h1y[NB];
+        if (!SSG_ABL(3)) {
+            lidar_hull<NB, EXACT>(rec, 0, cx, cy, ex, ey, hit0, h0x, h0y);
+            lidar_hull<NB, EXACT>(rec, 1, cx, cy, ex, ey, hit1, h1x, h1y);
+        } else {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) { hitx[i] = ex[i]; hity[i] = ey[i]; }
-                hit = (1u << NB) - 1u;
-            } else {
-                // cpPolyShapeSegmentQuery, r2 = 0: every plane is tested; a later accepted plane overwrites.
-                for (int j = 0; j < cnt; ++j) {
-                    const double nx = rec[pbase + 8 * j + 2], ny = rec[pbase + 8 * j + 3];
-                    const double v0n = rec[pbase + 8 * j + 4];
-                    const double dtmin = rec[pbase + 8 * j + 5], dtmax = rec[pbase + 8 * j + 6];
-                    const double an = cx * nx + cy * ny;
-                    const double d = an - v0n;
-                    if (d < 0.0) continue;
+            for (int i = 0; i < NB; ++i) { h0x[i] = ex[i]; h0y[i] = ey[i]; h1x[i] = ey[i]; h1y[i] = ex[i]; }
+        }
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        const double bn = ex[i] * nx + ey[i] * ny;
-                        const double t = d / dmax(an - bn, DBL_MIN);
-                        if (t < 0.0 || 1.0 < t) continue;
-                        const double omt = 1.0 - t;
-                        const double ptx = cx * omt + ex[i] * t, pty = cy * omt + ey[i] * t; // cpvlerp(a,b,t)
-                        const double dtv = nx * pty - ny * ptx;                               // cpvcross(n, point)
-                        if (dtmin <= dtv && dtv <= dtmax) {
-                            hit |= 1u << i;
-                            hitx[i] = ptx;
-                            hity[i] = pty;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if ((hit & (1u << i)) && !(decided & (1u << i))) {
-                    const double dx = hitx[i] - cx, dy = hity[i] - cy;
-                    lid[i] = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
-                    decided |= 1u << i;
-                }
-            }
+        for (int i = 0; i < NB; ++i) {
+            // first shape in list order that reports a hit wins (models.py:61-72); a miss keeps the old value
+            const bool a0 = hit0 & (1u << i), a1 = hit1 & (1u << i);
+            const double px = a0 ? h0x[i] : h1x[i], py = a0 ? h0y[i] : h1y[i];
+            const double dx = px - cx, dy = py - cy;
+            const double dist = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
+            lid[i] = (a0 || a1) ? dist : lid[i];
         }
     }
 
@@ -253,46 +325,51 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     }
 
     // player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed convex sets
-    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals.
+    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals.  A hull is skipped only
+    // when no lane of the wave passes the AABB test.
     bool colliding = false;
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < (SSG_ABL(4) ? 0 : 2); ++s) {
         const double al = rec[SSG_MAP_OFF_AABB + 4 * s + 0], ab = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
         const double ar = rec[SSG_MAP_OFF_AABB + 4 * s + 2], at = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
-        if (!(sbl <= ar && al <= sbr && sbb <= at && ab <= sbt)) continue;
+        const bool near = (sbl <= ar) && (al <= sbr) && (sbb <= at) && (ab <= sbt);
+        if (!__any(near)) continue;
         const int cnt = (int)rec[SSG_MAP_OFF_COUNTS + s];
         const int pbase = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
         bool separated = false;
         double mn_ship_axis[SSG_SHIP_VERTS]; // min over bank verts of dot(ship normal i, v)
 #pragma unroll
         for (int i = 0; i < SSG_SHIP_VERTS; ++i) mn_ship_axis[i] = INFINITY;
-        for (int j = 0; j < cnt; ++j) {
-            const double v0x = rec[pbase + 8 * j + 0], v0y = rec[pbase + 8 * j + 1];
-            const double nx = rec[pbase + 8 * j + 2], ny = rec[pbase + 8 * j + 3];
-            const double v0n = rec[pbase + 8 * j + 4];
+        for (int j = 0; __any(j < cnt); ++j) {
+            const bool valid = j < cnt;
+            const int jj = valid ? j : 0;
+            const double v0x = rec[pbase + 8 * jj + 0], v0y = rec[pbase + 8 * jj + 1];
+            const double nx = rec[pbase + 8 * jj + 2], ny = rec[pbase + 8 * jj + 3];
+            const double v0n = rec[pbase + 8 * jj + 4];
             double mn = INFINITY;
 #pragma unroll
             for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
                 mn = dmin(mn, nx * swx[i] + ny * swy[i]);
-                mn_ship_axis[i] = dmin(mn_ship_axis[i], snx[i] * v0x + sny[i] * v0y);
+                mn_ship_axis[i] = dmin(mn_ship_axis[i], snx[i] * v0x + sny[i] * v0y); // jj=0 repeats a real vertex
             }
-            if (mn > v0n) separated = true;
+            separated = separated || (valid && (mn > v0n));
         }
 #pragma unroll
         for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
             const double off = snx[i] * swx[i] + sny[i] * swy[i];
-            if (mn_ship_axis[i] > off) separated = true;
+            separated = separated || (mn_ship_axis[i] > off);
         }
-        if (!separated) colliding = true;
+        colliding = colliding || (near && !separated);
     }
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
     bool goal_reached = false;
-    for (int g = 0; g < c.n_goals; ++g) {
-        if (!(gm & (1u << g))) continue;
+    for (int g = 0; g < (SSG_ABL(5) ? 0 : c.n_goals); ++g) {
         const double gx = rec[SSG_MAP_OFF_GOALS + 2 * g], gy = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
         const double r = c.goal_r;
-        if (!((gx - r) <= sbr && sbl <= (gx + r) && (gy - r) <= sbt && sbb <= (gy + r))) continue;
+        const bool near = (gm & (1u << g)) && ((gx - r) <= sbr) && (sbl <= (gx + r)) && ((gy - r) <= sbt) &&
+                          (sbb <= (gy + r));
+        if (!__any(near)) continue;
         bool outside = false;
         double min_dist = INFINITY;
         double v0x = swx[SSG_SHIP_VERTS - 1], v0y = swy[SSG_SHIP_VERTS - 1];
@@ -306,15 +383,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
             const double qx = v1x + dx * tt, qy = v1y + dy * tt;
             const double ex_ = gx - qx, ey_ = gy - qy;
             const double dist = sqrt(ex_ * ex_ + ey_ * ey_);
-            if (dist < min_dist) min_dist = dist;
+            min_dist = (dist < min_dist) ? dist : min_dist;
             v0x = v1x;
             v0y = v1y;
         }
         const double sd = outside ? min_dist : -min_dist;
-        if (sd <= r) {
-            goal_reached = true;
-            gm &= ~(1u << g);
-        }
+        const bool got = near && (sd <= r);
+        goal_reached = goal_reached || got;
+        gm = got ? (gm & ~(1u << g)) : gm;
     }
 
     // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0); forces are cleared afterwards ----
@@ -326,17 +402,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     // ---- determine_reward (ship_env.py:62-77) ----
     const bool oob_x = (x < 0.0) || (x > c.width);
     const bool oob_y = (y < 0.0) || (y > c.height);
-    double rew;
-    if (goal_reached) rew = 1.0;
-    else if (oob_x) rew = -1.0;
-    else if (oob_y) rew = -1.0;
-    else rew = -0.01;
+    double rew = goal_reached ? 1.0 : ((oob_x || oob_y) ? -1.0 : -0.01);
     if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && colliding && !goal_reached) rew = -1.0;
     cum += rew;
 
     // ---- __add_states (ship_env.py:79-113) ----
-    double nf_gx, nf_gy;
-    nearest_goal(rec, gm, c.n_goals, x, y, nf_gx, nf_gy);
+    double nf_gx = 0, nf_gy = 0;
+    if (!SSG_ABL(0)) nearest_goal(rec, gm, c.n_goals, x, y, nf_gx, nf_gy);
 
     // ---- step_count += 1; is_done (ship_env.py:115-134,152-154) ----
     steps += 1;
@@ -347,26 +419,27 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     double *__restrict__ orow = obs + (size_t)e * (size_t)(F * c.history);
     const bool do_reset = done && (c.flags & SSG_FLAG_AUTO_RESET);
 
-    if (done) {
-        // episode statistics (per handle): sum of returns, sum of lengths, episodes
-        atomicAdd(&c.stats[0], cum);
-        atomicAdd(&c.stats[1], (double)steps);
-        atomicAdd(&c.stats[2], 1.0);
-    }
-    if (goal_reached) atomicAdd(&c.stats[3], 1.0);
-
-    if (!do_reset) {
-        if (hist2) {
-            orow[0] = pf_x; orow[1] = pf_y; orow[2] = pf_rud; orow[3] = pf_a; orow[4] = pf_gx; orow[5] = pf_gy;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) orow[6 + i] = pf_lid[i];
-            orow += F;
+    if (!SSG_ABL(6)) {
+        // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
+        // single hot address, and integer adds commute, so the totals are bitwise reproducible run to run.
+        // cum is a sum of {1, -1, -0.01} terms, so round(100*cum) is the exact return in hundredths.
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(c.stats) + 4 * (blockIdx.x % kStatsSlots);
+        if (done) {
+            atomicAdd(slot + 0, (unsigned long long)(long long)llrint(cum * 100.0));
+            atomicAdd(slot + 1, (unsigned long long)steps);
+            atomicAdd(slot + 2, 1ull);
         }
-        orow[0] = x; orow[1] = y; orow[2] = (double)rudder; orow[3] = ang; orow[4] = nf_gx; orow[5] = nf_gy;
+        if (goal_reached) atomicAdd(slot + 3, 1ull);
+    }
+
+    // observation values: the stepped frames, or (VecEnv auto-reset) ShipGame.reset + ShipEnv.reset onto the next
+    // bank record: history of -1 then the spawn frame.
+    double o_old[6 + NB], o_new[6 + NB];
+    o_old[0] = pf_x; o_old[1] = pf_y; o_old[2] = pf_rud; o_old[3] = pf_a; o_old[4] = pf_gx; o_old[5] = pf_gy;
+    o_new[0] = x; o_new[1] = y; o_new[2] = (double)rudder; o_new[3] = ang; o_new[4] = nf_gx; o_new[5] = nf_gy;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) orow[6 + i] = lid[i];
-    } else {
-        // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record.
+    for (int i = 0; i < NB; ++i) { o_old[6 + i] = pf_lid[i]; o_new[6 + i] = lid[i]; }
+    if (do_reset) {
         map_id = map_id + 1;
         if (map_id >= c.n_maps) map_id = 0;
         const auto nrec = make_rec(map_id);
@@ -375,15 +448,20 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
         gm = (1u << c.n_goals) - 1u;
 #pragma unroll
         for (int i = 0; i < NB; ++i) lid[i] = -1.0;
-        if (hist2) {
-            for (int i = 0; i < F; ++i) orow[i] = -1.0;
-            orow += F;
-        }
-        orow[0] = x; orow[1] = y; orow[2] = 0.0; orow[3] = 0.0;
-        orow[4] = nrec[SSG_MAP_OFF_SPAWN_GOAL]; orow[5] = nrec[SSG_MAP_OFF_SPAWN_GOAL + 1];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) orow[6 + i] = -1.0;
+        for (int i = 0; i < 6 + NB; ++i) { o_old[i] = -1.0; o_new[i] = -1.0; }
+        o_new[0] = x; o_new[1] = y; o_new[2] = 0.0; o_new[3] = 0.0;
+        o_new[4] = nrec[SSG_MAP_OFF_SPAWN_GOAL]; o_new[5] = nrec[SSG_MAP_OFF_SPAWN_GOAL + 1];
     }
+    if (!SSG_ABL(7)) {
+    if (hist2) {
+#pragma unroll
+        for (int i = 0; i < 6 + NB; ++i) orow[i] = o_old[i];
+        orow += F;
+    }
+#pragma unroll
+    for (int i = 0; i < 6 + NB; ++i) orow[i] = o_new[i];
+    } else { double acc = 0; for (int i = 0; i < 6 + NB; ++i) acc += o_old[i] + o_new[i]; orow[0] = acc; }
 
     reward_out[e] = rew;
     done_out[e] = done ? 1 : 0;
@@ -479,31 +557,35 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
 using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *);
 
 template <int NB, int BLOCK>
-static step_fn_t step_fn_nb(bool lds)
+static step_fn_t step_fn_nb(bool lds, bool exact)
 {
-    return lds ? step_kernel<NB, BLOCK, true> : step_kernel<NB, BLOCK, false>;
+    if (exact) return lds ? step_kernel<NB, BLOCK, true, true> : step_kernel<NB, BLOCK, false, true>;
+    return lds ? step_kernel<NB, BLOCK, true, false> : step_kernel<NB, BLOCK, false, false>;
 }
 
 template <int BLOCK>
-static step_fn_t step_fn_block(int nb, bool lds)
+static step_fn_t step_fn_block(int nb, bool lds, bool exact)
 {
     switch (nb) {
 #define SSG_CASE(NB_) \
-    case NB_: return step_fn_nb<NB_, BLOCK>(lds);
+    case NB_: return step_fn_nb<NB_, BLOCK>(lds, exact);
+#ifdef SSG_DEV_BUILD /* development builds instantiate the two BASELINE beam counts only */
+        SSG_CASE(8) SSG_CASE(10)
+#else
         SSG_CASE(1) SSG_CASE(2) SSG_CASE(3) SSG_CASE(4) SSG_CASE(5) SSG_CASE(6) SSG_CASE(7) SSG_CASE(8)
         SSG_CASE(9) SSG_CASE(10) SSG_CASE(11) SSG_CASE(12) SSG_CASE(13) SSG_CASE(14) SSG_CASE(15) SSG_CASE(16)
+#endif
 #undef SSG_CASE
     default: return nullptr;
     }
 }
 
-static step_fn_t step_fn(int nb, int block, bool lds)
+static step_fn_t step_fn(int nb, int block, bool lds, bool exact)
 {
     switch (block) {
-    case 64: return step_fn_block<64>(nb, lds);
-    case 128: return step_fn_block<128>(nb, lds);
-    case 256: return step_fn_block<256>(nb, lds);
-    case 512: return step_fn_block<512>(nb, lds);
+    case 64: return step_fn_block<64>(nb, lds, exact);
+    case 256: return step_fn_block<256>(nb, lds, exact);
+    case 512: return step_fn_block<512>(nb, lds, exact);
     default: return nullptr;
     }
 }
@@ -511,7 +593,7 @@ static step_fn_t step_fn(int nb, int block, bool lds)
 // Raise the dynamic-LDS cap of the selected instantiation once (whenever the bank size changes).
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes)
 {
-    step_fn_t k = step_fn(c.n_beams, block, lds);
+    step_fn_t k = step_fn(c.n_beams, block, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
     if (!lds) return hipSuccess;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -521,7 +603,7 @@ hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes)
 hipError_t launch_step(const DevCfg &c, int block, bool lds, size_t lds_bytes, const int32_t *actions, double *obs,
                        double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream)
 {
-    step_fn_t k = step_fn(c.n_beams, block, lds);
+    step_fn_t k = step_fn(c.n_beams, block, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
     const int grid = (c.n_envs + block - 1) / block;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds ? lds_bytes : 0, stream, c, actions, obs, reward, done, flags);

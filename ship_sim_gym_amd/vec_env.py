@@ -42,7 +42,7 @@ class ShipVecEnv(object):
 
     def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
                  map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
-                 fix_collision_reward=False, bank_in_global=False):
+                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -85,6 +85,8 @@ class ShipVecEnv(object):
             flags |= N.FLAG_FIX_COLLISION_REWARD
         if bank_in_global or map_mode == "fresh":
             flags |= N.FLAG_BANK_IN_GLOBAL
+        if exact_lidar:
+            flags |= N.FLAG_EXACT_LIDAR
         c.flags = flags
         self.cfg = c
         self.n_states = 6 + c.n_beams                              # ship_env.py:43
@@ -157,15 +159,15 @@ class ShipVecEnv(object):
                 "ssg_state_field")
         dt = {8: torch.float64, 4: torch.int32, 1: torch.uint8}[es.value]
         if fid == N.F_STATS:
-            return self.state[off.value: off.value + 8 * nc.value].view(torch.float64)
+            return self.state[off.value: off.value + 8 * nc.value].view(torch.int64).view(-1, 4)
         n_pad = stride.value // es.value
         v = self.state[off.value: off.value + nc.value * stride.value].view(dt).view(nc.value, n_pad)[:, :self.num_envs]
         return v[0] if nc.value == 1 else v
 
     def stats(self):
         """Per-handle episode counters accumulated in-kernel: sum_return, sum_length, episodes, goals_hit."""
-        s = self.field(N.F_STATS).cpu().numpy()
-        return {"sum_return": float(s[0]), "sum_length": float(s[1]), "episodes": float(s[2]), "goals_hit": float(s[3])}
+        s = self.field(N.F_STATS).sum(dim=0).cpu().numpy()
+        return {"sum_return": float(s[0]) / 100.0, "sum_length": int(s[1]), "episodes": int(s[2]), "goals_hit": int(s[3])}
 
     # ------------------------------------------------------------------------------------------------
     # tensor API (zero-copy; what a GPU-resident policy should use)

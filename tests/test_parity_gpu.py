@@ -70,6 +70,25 @@ def test_ragged_sizes_and_bank_in_global(torch_cuda, oracle, native):
         assert err <= ATOL
 
 
+def test_exact_and_one_division_lidar_agree(torch_cuda, oracle, native):
+    """SSG_FLAG_EXACT_LIDAR (cpPolyShapeSegmentQuery plane by plane) vs the default one-division-per-beam evaluation:
+    same hit/miss decisions and hit points, so identical observations; both against the oracle."""
+    torch = torch_cuda
+    a = _vec(8192, n_maps=64, n_beams=10)
+    b = _vec(8192, n_maps=64, n_beams=10, exact_lidar=True)
+    a.reset_tensor(); b.reset_tensor()
+    acts = a.random_actions(11, 0, 300)
+    worst = 0.0
+    for k in range(300):
+        oa, ra, da, fa = a.step_tensor(acts[k])
+        ob, rb, db, fb = b.step_tensor(acts[k])
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(fa, fb)
+        worst = max(worst, float((oa - ob).abs().max()))
+    assert worst <= 1e-9, worst  # equal up to the vertex-grazing case (none expected in 2.4e7 rays)
+    err, _ = run_pair(oracle, native, _vec(1024, n_maps=64, exact_lidar=True), K=200)
+    assert err <= ATOL
+
+
 def test_event_flags_bit_exact(torch_cuda, oracle, native):
     """colliding / goal_reached (ShipGame attributes, game.py:190-191,240,254) against the oracle's."""
     vec = _vec(512, n_maps=32)
