@@ -267,6 +267,17 @@ void refresh_dev(ssg_handle *h)
     d.force_y = c.force_y;
     d.px0 = c.thrust_px0;
     d.py0 = c.thrust_py0;
+    {
+        // LiDAR.query (models.py:48-49,62): rotation_i = angle + rad(90 - spread/2) + rad(spread/n_beams) * i
+        const double deg2rad = 0.017453292519943295; // CPython math.radians: pi/180
+        const double delta = (c.lidar_spread_deg / (double)c.n_beams) * deg2rad;
+        const double phi0 = (90.0 - c.lidar_spread_deg / 2) * deg2rad;
+        for (int i = 0; i < SSG_MAX_BEAMS; ++i) {
+            const double phi = phi0 + delta * (double)i;
+            d.beam_cos[i] = std::cos(phi);
+            d.beam_sin[i] = std::sin(phi);
+        }
+    }
     char *base = static_cast<char *>(h->state);
     d.stats = base ? reinterpret_cast<double *>(base + h->off_stats) : nullptr;
     d.f64cols = base ? reinterpret_cast<double *>(base + h->off_f64) : nullptr;
@@ -449,8 +460,10 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
     h->bank = dev_bank;
     h->n_maps = n_maps;
-    h->lds_bytes = (size_t)n_maps * SSG_MAP_STRIDE * sizeof(double);
-    h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) && h->lds_bytes <= 160u * 1024u; // 160 KiB LDS per CU on gfx950
+    // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch
+    h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
+             ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) <= 160u * 1024u;
+    h->lds_bytes = ssg::step_lds_bytes(h->cfg.n_beams, h->block, h->lds, n_maps);
     h->prepared = false;
     refresh_dev(h);
     return SSG_OK;

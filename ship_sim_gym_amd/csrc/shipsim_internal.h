@@ -31,6 +31,7 @@ struct DevCfg {
     double spread_deg, lidar_dist, goal_r, width, height, dt, damp, spawn_x, spawn_y;
     double hull[2 * SSG_SHIP_VERTS], nrm[2 * SSG_SHIP_VERTS];
     double m_inv, i_inv, force_y, px0, py0;
+    double beam_cos[SSG_MAX_BEAMS], beam_sin[SSG_MAX_BEAMS]; // cos/sin of the beam offsets phi_i from the heading
     double *f64cols;
     int32_t *i32cols;
     uint8_t *mask;
@@ -40,6 +41,7 @@ struct DevCfg {
 
 hipError_t launch_step(const DevCfg &c, int block, bool lds, size_t lds_bytes, const int32_t *actions, double *obs,
                        double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream);
+size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long env_base, int n, int32_t *out,

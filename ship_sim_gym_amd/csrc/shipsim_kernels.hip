@@ -65,6 +65,24 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
     if (o < bytes) *reinterpret_cast<double2 *>(l + o) = *reinterpret_cast<const double2 *>(g + o);
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) // src_lane must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// pick element k (0..4, per lane) of a 5-entry table held in wave-uniform registers
+__device__ __forceinline__ double pick5(const double *t, int stride, int k)
+{
+    double r = t[0];
+    r = (k == 1) ? t[stride] : r;
+    r = (k == 2) ? t[2 * stride] : r;
+    r = (k == 3) ? t[3 * stride] : r;
+    r = (k == 4) ? t[4 * stride] : r;
+    return r;
+}
+
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
 template <class Rec>
 __device__ __forceinline__ void nearest_goal(const Rec &rec, unsigned gm, int n_goals, double x, double y, double &gx,
@@ -84,90 +102,102 @@ __device__ __forceinline__ void nearest_goal(const Rec &rec, unsigned gm, int n_
     }
 }
 
-// One bank hull against the NB lidar beams of this lane: cpShapeSegmentQuery(shape, a=(cx,cy), b=(ex,ey), r=0).
-//   EXACT = true : cpPolyShapeSegmentQuery literally — every plane is intersected (one division per plane and
-//                  beam), accepted when the crossing lies inside the edge's extent, later planes overwrite.
-//   EXACT = false: the same predicate evaluated with one division per beam: among the planes the beam crosses
-//                  front-to-back within its length (d >= 0 and d <= den, i.e. 0 <= t <= 1) only the one with the
-//                  largest t can be the entry edge of a convex polygon, so only that plane gets the exact
-//                  t = d/den, lerp and edge-extent test of the reference.  Identical results except when a ray
-//                  passes within rounding of a hull vertex (then: adjacent edge, same point to ~1e-13).
-// Branch-free over lanes; the trip count is the wave-wide maximum plane count.
-template <int NB, bool EXACT, class Rec>
-__device__ __forceinline__ void lidar_hull(const Rec &rec, int s, double cx, double cy, const double (&ex)[NB],
-                                           const double (&ey)[NB], unsigned &hit, double (&hx)[NB], double (&hy)[NB])
+// ---------------------------------------------------------------------------------------------------------
+// LiDAR (models.py:39-76), wave-compacted.
+//
+// A beam can only touch a bank hull if the beam's bounding box meets the hull's (most beams of most ships do
+// not: the river is wider than the 100-unit range).  Each lane therefore only CULLS its NB x 2 (beam, hull)
+// pairs; the surviving pairs of the whole wave are compacted into a per-wave LDS queue (ballot + mbcnt) and
+// processed 64 at a time, one pair per lane, so the plane loops run on dense wavefronts.  A worker lane pulls
+// the pose of the env it serves with ds_bpermute, rebuilds the beam (same expressions as the owner lane) and runs
+// cpShapeSegmentQuery(shape, a=(cx,cy), b=(ex,ey), r=0) against one hull:
+//   EXACT = true : cpPolyShapeSegmentQuery literally — every plane is intersected (one division per plane),
+//                  accepted when the crossing lies inside the edge's extent, later planes overwrite.
+//   EXACT = false: the same predicate with one division per beam: among the planes the beam crosses front-to-back
+//                  within its length (d >= 0 and d <= den, i.e. 0 <= t <= 1) only the one with the largest t can
+//                  be the entry edge of a convex polygon, so only that plane gets the exact t = d/den, lerp and
+//                  edge-extent test.  Identical results except when a ray passes within rounding of a hull vertex.
+// Hull 0 (left bank) pairs are processed before hull 1 pairs: the first shape in list order that reports a hit
+// wins (models.py:61-72).  Results travel back through a per-wave LDS array res[beam][lane] (-1 = no hit).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_scratch_wave_bytes(int nb) { return nb * (64 * 8 + 2 * 64 * 2); }
+
+template <int NB, bool LDS_BANK, bool EXACT>
+__device__ __forceinline__ void lidar_pass(const DevCfg &c, const int s, const int n_items,
+                                           const unsigned short *queue, double *res,
+                                           const double *beamtab, const double cx, const double cy,
+                                           const double ca, const double sa, const int rec_off, const int lane)
 {
-    const int cnt = (int)rec[SSG_MAP_OFF_COUNTS + s];
-    const int pbase = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
-    bool outside = false; // cpPolyShapePointQuery(a): any plane with a strictly in front
-    hit = 0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) { hx[i] = ex[i]; hy[i] = ey[i]; }
-    double bd[NB], bden[NB];
-    int bj[NB];
-    if (!EXACT) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) { bd[i] = -1.0; bden[i] = 1.0; bj[i] = 0; }
-    }
-    for (int j = 0; __any(j < cnt); ++j) {
-        const bool valid = j < cnt;
-        const int jj = valid ? j : 0;
-        const double v0x = rec[pbase + 8 * jj + 0], v0y = rec[pbase + 8 * jj + 1];
-        const double nx = rec[pbase + 8 * jj + 2], ny = rec[pbase + 8 * jj + 3];
-        const double v0n = rec[pbase + 8 * jj + 4];
-        outside = outside || (valid && ((nx * (cx - v0x) + ny * (cy - v0y)) > 0.0));
-        const double an = cx * nx + cy * ny;
-        const double d = an - v0n;
-        const bool front = valid && !(d < 0.0);
-        if (EXACT) {
-            const double dtmin = rec[pbase + 8 * jj + 5], dtmax = rec[pbase + 8 * jj + 6];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const double bn = ex[i] * nx + ey[i] * ny;
-                const double t = d / dmax(an - bn, DBL_MIN);
+    const auto bk = [&](int i) {
+        if constexpr (LDS_BANK) return lds_bank()[i];
+        else return c.bank[i];
+    };
+    for (int base = 0; base < n_items; base += 64) {
+        const int idx = base + lane;
+        const bool act = idx < n_items;
+        const unsigned code = queue[act ? idx : 0];
+        const int src = code & 63, bi = code >> 6;
+        const double wcx = __shfl(cx, src), wcy = __shfl(cy, src), wca = __shfl(ca, src), wsa = __shfl(sa, src);
+        const int woff = __shfl(rec_off, src);
+        const double cphi = beamtab[bi], sphi = beamtab[SSG_MAX_BEAMS + bi];
+        const double ux = wca * cphi - wsa * sphi, uy = wsa * cphi + wca * sphi;
+        const double ex = wcx + c.lidar_dist * ux, ey = wcy + c.lidar_dist * uy;
+        const int cnt = (int)bk(woff + SSG_MAP_OFF_COUNTS + s);
+        const int pb = woff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
+        bool outside = false; // cpPolyShapePointQuery(a): some plane has a strictly in front
+        bool ok = false;
+        double ptx = ex, pty = ey;
+        double bd = -1.0, bden = 1.0;
+        int bj = 0;
+        for (int j = 0; __any(act && (j < cnt)); ++j) {
+            const bool valid = act && (j < cnt);
+            const int q = pb + 8 * (valid ? j : 0);
+            const double v0x = bk(q + 0), v0y = bk(q + 1), nx = bk(q + 2), ny = bk(q + 3), v0n = bk(q + 4);
+            outside = outside || (valid && ((nx * (wcx - v0x) + ny * (wcy - v0y)) > 0.0));
+            const double an = wcx * nx + wcy * ny;
+            const double d = an - v0n;
+            const bool front = valid && !(d < 0.0);
+            const double bn = ex * nx + ey * ny;
+            const double den = dmax(an - bn, DBL_MIN);
+            if (EXACT) {
+                const double dtmin = bk(q + 5), dtmax = bk(q + 6);
+                const double t = d / den;
                 const double omt = 1.0 - t;
-                const double ptx = cx * omt + ex[i] * t, pty = cy * omt + ey[i] * t; // cpvlerp(a,b,t)
-                const double dtv = nx * pty - ny * ptx;                               // cpvcross(n, point)
-                const bool ok = front && !(t < 0.0 || 1.0 < t) && (dtmin <= dtv) && (dtv <= dtmax);
-                hit |= ok ? (1u << i) : 0u;
-                hx[i] = ok ? ptx : hx[i];
-                hy[i] = ok ? pty : hy[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const double bn = ex[i] * nx + ey[i] * ny;
-                const double den = dmax(an - bn, DBL_MIN);
+                const double qx = wcx * omt + ex * t, qy = wcy * omt + ey * t; // cpvlerp(a,b,t)
+                const double dtv = nx * qy - ny * qx;                           // cpvcross(n, point)
+                const bool acc = front && !(t < 0.0 || 1.0 < t) && (dtmin <= dtv) && (dtv <= dtmax);
+                ok = ok || acc;
+                ptx = acc ? qx : ptx;
+                pty = acc ? qy : pty;
+            } else {
                 // candidate: 0 <= d/den <= 1; better: d/den >= best (cross-multiplied, dens > 0; ties -> later plane)
-                const bool better = front && (d <= den) && (d * bden[i] >= bd[i] * den);
-                bd[i] = better ? d : bd[i];
-                bden[i] = better ? den : bden[i];
-                bj[i] = better ? j : bj[i];
+                const bool better = front && (d <= den) && (d * bden >= bd * den);
+                bd = better ? d : bd;
+                bden = better ? den : bden;
+                bj = better ? j : bj;
             }
         }
-    }
-    if (!EXACT) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int q = pbase + 8 * bj[i];
-            const double nx = rec[q + 2], ny = rec[q + 3], dtmin = rec[q + 5], dtmax = rec[q + 6];
-            const double t = bd[i] / bden[i];
+        if (!EXACT) {
+            const int q = pb + 8 * bj;
+            const double nx = bk(q + 2), ny = bk(q + 3), dtmin = bk(q + 5), dtmax = bk(q + 6);
+            const double t = bd / bden;
             const double omt = 1.0 - t;
-            const double ptx = cx * omt + ex[i] * t, pty = cy * omt + ey[i] * t;
+            ptx = wcx * omt + ex * t;
+            pty = wcy * omt + ey * t;
             const double dtv = nx * pty - ny * ptx;
-            const bool ok = (bd[i] >= 0.0) && (dtmin <= dtv) && (dtv <= dtmax);
-            hit |= ok ? (1u << i) : 0u;
-            hx[i] = ptx;
-            hy[i] = pty;
+            ok = (bd >= 0.0) && (dtmin <= dtv) && (dtv <= dtmax);
+        }
+        // start point inside (or on) the polygon: hit at alpha 0 whose reported point is the FAR end b (App. A.7)
+        const bool hit = act && (outside ? ok : true);
+        const double px = outside ? ptx : ex, py = outside ? pty : ey;
+        const double dx = px - wcx, dy = py - wcy;
+        const double dist = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
+        const int slot = bi * 64 + src;
+        if (hit) {
+            if (s == 0) res[slot] = dist;
+            else if (res[slot] < 0.0) res[slot] = dist; // the left bank (listed first) already answered this beam
         }
     }
-    // start point inside (or on) the polygon: hit at alpha 0 whose reported point is the FAR end b (App. A.7)
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        hx[i] = outside ? hx[i] : ex[i];
-        hy[i] = outside ? hy[i] : ey[i];
-    }
-    hit = outside ? hit : ((1u << NB) - 1u);
 }
 
 // Timing-only ablation switches (development builds with -DSSG_ABLATION; never in the product library): bits
@@ -213,11 +243,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     int rudder = colRud[el], steps = colStep[el], map_id = colMap[el];
     unsigned gm = c.mask[el];
     const int act = actions[el];
-    if (LDS_BANK) {
-        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-        __syncthreads();
-    }
-    if (!live) return;
+    // LDS layout: [bank records (LDS_BANK only)] [beam cos/sin table 2 x 16 doubles] [per-wave lidar scratch]
+    char *lds_scratch = reinterpret_cast<char *>(lds_bank()) + (LDS_BANK ? ((c.n_maps * (SSG_MAP_STRIDE * 8) + 15) & ~15) : 0);
+    if (threadIdx.x < 2 * SSG_MAX_BEAMS)
+        reinterpret_cast<double *>(lds_scratch)[threadIdx.x] =
+            (threadIdx.x < SSG_MAX_BEAMS) ? c.beam_cos[threadIdx.x & (SSG_MAX_BEAMS - 1)] : c.beam_sin[threadIdx.x & (SSG_MAX_BEAMS - 1)];
+    if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int rec_off = (int)map_id * SSG_MAP_STRIDE;
+    // No early exit: lanes past n_envs stay active as workers of the wave-cooperative sections below; they carry
+    // env 0's state, never count as "near" anything and store nothing.
 
     auto make_rec = [&](int m) {
         if constexpr (LDS_BANK) return LdsRec{m * SSG_MAP_STRIDE};
@@ -270,36 +306,55 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
             bb = dmin(bb, wy); bt = dmax(bt, wy);
         }
         const double cx = x + (br - bl) / 2, cy = y + (bt - bb) / 2; // models.py:51-53: pos + half AABB extents
-        const double deg2rad = 0.017453292519943295;                  // CPython math.radians: pi/180
-        const double angle_delta = (c.spread_deg / (double)NB) * deg2rad;
-        const double angle_start = ang + (90.0 - c.spread_deg / 2) * deg2rad;
-
-        double ex[NB], ey[NB];
+        // Beam i points along heading + phi_i, phi_i = rad(90 - spread/2) + i*rad(spread/n_beams) (models.py:48-49,
+        // 62-64).  cos/sin(heading + phi_i) come from the body rotation (ca, sa) and host-computed cos/sin(phi_i) by
+        // the angle-addition identity instead of one sincos per beam: endpoints agree with the reference's to
+        // ~1e-13 (they only feed lidar readings, never the dynamics).
+        unsigned need0 = 0, need1 = 0;
+        {
+            const double a0l = rec[SSG_MAP_OFF_AABB + 0], a0b = rec[SSG_MAP_OFF_AABB + 1];
+            const double a0r = rec[SSG_MAP_OFF_AABB + 2], a0t = rec[SSG_MAP_OFF_AABB + 3];
+            const double a1l = rec[SSG_MAP_OFF_AABB + 4], a1b = rec[SSG_MAP_OFF_AABB + 5];
+            const double a1r = rec[SSG_MAP_OFF_AABB + 6], a1t = rec[SSG_MAP_OFF_AABB + 7];
+            const double eps = 1e-6; // conservative margin: culling must never drop a pair the reference would hit
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double ux = ca * c.beam_cos[i] - sa * c.beam_sin[i], uy = sa * c.beam_cos[i] + ca * c.beam_sin[i];
+                const double ex = cx + c.lidar_dist * ux, ey = cy + c.lidar_dist * uy;
+                const double lox = dmin(cx, ex) - eps, hix = dmax(cx, ex) + eps;
+                const double loy = dmin(cy, ey) - eps, hiy = dmax(cy, ey) + eps;
+                const bool n0 = live && (lox <= a0r) && (a0l <= hix) && (loy <= a0t) && (a0b <= hiy);
+                const bool n1 = live && (lox <= a1r) && (a1l <= hix) && (loy <= a1t) && (a1b <= hiy);
+                need0 |= n0 ? (1u << i) : 0u;
+                need1 |= n1 ? (1u << i) : 0u;
+            }
+        }
+        // per-wave LDS scratch: res[NB][64] doubles, queue0[NB*64] u16, queue1[NB*64] u16
+        char *wscr = lds_scratch + 2 * SSG_MAX_BEAMS * 8 + (threadIdx.x >> 6) * lds_scratch_wave_bytes(NB);
+        double *res = reinterpret_cast<double *>(wscr);
+        unsigned short *q0 = reinterpret_cast<unsigned short *>(wscr + NB * 64 * 8);
+        unsigned short *q1 = q0 + NB * 64;
+        int n0 = 0, n1 = 0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const double rotation = angle_start + (angle_delta * (double)i);
-            double sr = rotation, cr = 1.0 - rotation;
-            if (!SSG_ABL(2)) sincos(rotation, &sr, &cr);
-            ex[i] = cx + c.lidar_dist * cr;
-            ey[i] = cy + c.lidar_dist * sr;
+            res[i * 64 + lane] = -1.0;
+            const unsigned long long m0 = __ballot((need0 >> i) & 1u), m1 = __ballot((need1 >> i) & 1u);
+            const int p0 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+            const int p1 = n1 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+            if ((need0 >> i) & 1u) q0[p0] = (unsigned short)(lane | (i << 6));
+            if ((need1 >> i) & 1u) q1[p1] = (unsigned short)(lane | (i << 6));
+            n0 += __popcll(m0);
+            n1 += __popcll(m1);
         }
-        unsigned hit0 = 0, hit1 = 0;
-        double h0x[NB], h0y[NB], h1x[NB], h1y[NB];
         if (!SSG_ABL(3)) {
-            lidar_hull<NB, EXACT>(rec, 0, cx, cy, ex, ey, hit0, h0x, h0y);
-            lidar_hull<NB, EXACT>(rec, 1, cx, cy, ex, ey, hit1, h1x, h1y);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) { h0x[i] = ex[i]; h0y[i] = ey[i]; h1x[i] = ey[i]; h1y[i] = ex[i]; }
+            const double *beamtab = reinterpret_cast<const double *>(lds_scratch);
+            lidar_pass<NB, LDS_BANK, EXACT>(c, 0, n0, q0, res, beamtab, cx, cy, ca, sa, rec_off, lane);
+            lidar_pass<NB, LDS_BANK, EXACT>(c, 1, n1, q1, res, beamtab, cx, cy, ca, sa, rec_off, lane);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            // first shape in list order that reports a hit wins (models.py:61-72); a miss keeps the old value
-            const bool a0 = hit0 & (1u << i), a1 = hit1 & (1u << i);
-            const double px = a0 ? h0x[i] : h1x[i], py = a0 ? h0y[i] : h1y[i];
-            const double dx = px - cx, dy = py - cy;
-            const double dist = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
-            lid[i] = (a0 || a1) ? dist : lid[i];
+            const double r = res[i * 64 + lane];
+            lid[i] = (r >= 0.0) ? r : lid[i]; // a miss keeps the previous reading (sticky, App. B-3)
         }
     }
 
@@ -324,73 +379,129 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
         sbb = dmin(sbb, swy[i]); sbt = dmax(sbt, swy[i]);
     }
 
+    // ---- narrowphase, wave-cooperative ----------------------------------------------------------------------
+    // Per lane only the cheap cpBBIntersects rejects run.  The few lanes that pass are then served one at a time
+    // by the WHOLE wave: lane L = 5*q + i works on (bank plane q or goal q, ship vertex/edge i) of the served
+    // env, whose pose is broadcast with v_readlane.  The arithmetic of every product and sum is exactly the
+    // per-env formulation's (cpPolyShapeCacheData, SAT dot products, cpPolyShapePointQuery); only the min/any
+    // reductions over vertices and planes are done with ballots instead of sequential loops.
+    const int wq = lane / 5, wi = lane - 5 * wq;                    // worker coordinates
+    const double w_hx = pick5(c.hull, 2, wi), w_hy = pick5(c.hull + 1, 2, wi);       // ship vertex i (local)
+    const double w_nx = pick5(c.nrm, 2, wi), w_ny = pick5(c.nrm + 1, 2, wi);         // ship normal i (local)
+    const int wip = (wi == 0) ? (SSG_SHIP_VERTS - 1) : (wi - 1);
+    const double w_px = pick5(c.hull, 2, wip), w_py = pick5(c.hull + 1, 2, wip);     // previous vertex (edge start)
+
     // player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed convex sets
-    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals.  A hull is skipped only
-    // when no lane of the wave passes the AABB test.
+    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
+    // has every vertex of the other polygon strictly in front.
     bool colliding = false;
-    for (int s = 0; s < (SSG_ABL(4) ? 0 : 2); ++s) {
-        const double al = rec[SSG_MAP_OFF_AABB + 4 * s + 0], ab = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
-        const double ar = rec[SSG_MAP_OFF_AABB + 4 * s + 2], at = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
-        const bool near = (sbl <= ar) && (al <= sbr) && (sbb <= at) && (ab <= sbt);
-        if (!__any(near)) continue;
-        const int cnt = (int)rec[SSG_MAP_OFF_COUNTS + s];
-        const int pbase = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
-        bool separated = false;
-        double mn_ship_axis[SSG_SHIP_VERTS]; // min over bank verts of dot(ship normal i, v)
+    {
+        unsigned nearbits = 0;
+        for (int s = 0; s < (SSG_ABL(4) ? 0 : 2); ++s) {
+            const double al = rec[SSG_MAP_OFF_AABB + 4 * s + 0], ab = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
+            const double ar = rec[SSG_MAP_OFF_AABB + 4 * s + 2], at = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
+            const bool near = live && (sbl <= ar) && (al <= sbr) && (sbb <= at) && (ab <= sbt);
+            nearbits |= near ? (1u << s) : 0u;
+        }
+        unsigned long long todo = __ballot(nearbits != 0u);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
+            const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
+            const int boff = __builtin_amdgcn_readlane(rec_off, src);
+            const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
+            const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
+            const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
+            const double off_i = snx_ * svx + sny_ * svy;
+            bool col = false;
+            for (int s = 0; s < 2; ++s) {
+                if (!(bnear & (1u << s))) continue; // wave-uniform
+                const auto brec = [&](int i) {
+                    if constexpr (LDS_BANK) return lds_bank()[boff + i];
+                    else return c.bank[(size_t)boff + i];
+                };
+                const int cnt = (int)brec(SSG_MAP_OFF_COUNTS + s);
+                const bool valid = (lane < 60) && (wq < cnt);
+                const int q = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + 8 * (valid ? wq : 0);
+                const double v0x = brec(q + 0), v0y = brec(q + 1), nx = brec(q + 2), ny = brec(q + 3), v0n = brec(q + 4);
+                const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
+                const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
+                const unsigned long long mV = __ballot(valid);
+                const unsigned long long mA = __ballot(valid && frontA);
+                const unsigned long long missB = mV & ~__ballot(valid && frontB);
+                const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
+                // axis = bank plane q: all five (q,i) bits set
+                const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
+                // axis = ship plane i: no valid (q,i) bit missing
+                bool sepB = false;
 #pragma unroll
-        for (int i = 0; i < SSG_SHIP_VERTS; ++i) mn_ship_axis[i] = INFINITY;
-        for (int j = 0; __any(j < cnt); ++j) {
-            const bool valid = j < cnt;
-            const int jj = valid ? j : 0;
-            const double v0x = rec[pbase + 8 * jj + 0], v0y = rec[pbase + 8 * jj + 1];
-            const double nx = rec[pbase + 8 * jj + 2], ny = rec[pbase + 8 * jj + 3];
-            const double v0n = rec[pbase + 8 * jj + 4];
-            double mn = INFINITY;
-#pragma unroll
-            for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-                mn = dmin(mn, nx * swx[i] + ny * swy[i]);
-                mn_ship_axis[i] = dmin(mn_ship_axis[i], snx[i] * v0x + sny[i] * v0y); // jj=0 repeats a real vertex
+                for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB || (((missB >> i) & P) == 0ull);
+                const bool separated = (allA != 0ull) || sepB;
+                col = col || !separated;
             }
-            separated = separated || (valid && (mn > v0n));
+            colliding = (lane == src) ? col : colliding;
         }
-#pragma unroll
-        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-            const double off = snx[i] * swx[i] + sny[i] * swy[i];
-            separated = separated || (mn_ship_axis[i] > off);
-        }
-        colliding = colliding || (near && !separated);
     }
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
     bool goal_reached = false;
-    for (int g = 0; g < (SSG_ABL(5) ? 0 : c.n_goals); ++g) {
-        const double gx = rec[SSG_MAP_OFF_GOALS + 2 * g], gy = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
-        const double r = c.goal_r;
-        const bool near = (gm & (1u << g)) && ((gx - r) <= sbr) && (sbl <= (gx + r)) && ((gy - r) <= sbt) &&
-                          (sbb <= (gy + r));
-        if (!__any(near)) continue;
-        bool outside = false;
-        double min_dist = INFINITY;
-        double v0x = swx[SSG_SHIP_VERTS - 1], v0y = swy[SSG_SHIP_VERTS - 1];
-#pragma unroll
-        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-            const double v1x = swx[i], v1y = swy[i];
-            outside = outside || ((snx[i] * (gx - v1x) + sny[i] * (gy - v1y)) > 0.0);
+    {
+        unsigned nearmask = 0;
+        for (int g = 0; g < (SSG_ABL(5) ? 0 : c.n_goals); ++g) {
+            const double gx = rec[SSG_MAP_OFF_GOALS + 2 * g], gy = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
+            const double r = c.goal_r;
+            const bool near = live && (gm & (1u << g)) && ((gx - r) <= sbr) && (sbl <= (gx + r)) && ((gy - r) <= sbt) &&
+                              (sbb <= (gy + r));
+            nearmask |= near ? (1u << g) : 0u;
+        }
+        unsigned long long todo = __ballot(nearmask != 0u);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
+            const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
+            const int boff = __builtin_amdgcn_readlane(rec_off, src);
+            const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearmask, src);
+            const auto brec = [&](int i) {
+                if constexpr (LDS_BANK) return lds_bank()[boff + i];
+                else return c.bank[(size_t)boff + i];
+            };
+            // lane (q = goal, i = ship edge from vertex i-1 to vertex i)
+            const bool valid = (wq < SSG_MAX_GOALS - 1) && (bnear & (1u << wq));
+            const int gq = valid ? wq : 0;
+            const double gx = brec(SSG_MAP_OFF_GOALS + 2 * gq), gy = brec(SSG_MAP_OFF_GOALS + 2 * gq + 1);
+            const double v1x = bca * w_hx + (-bsa) * w_hy + bx, v1y = bsa * w_hx + bca * w_hy + by;
+            const double v0x = bca * w_px + (-bsa) * w_py + bx, v0y = bsa * w_px + bca * w_py + by;
+            const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
+            const bool out_i = (snx_ * (gx - v1x) + sny_ * (gy - v1y)) > 0.0;
             // cpClosetPointOnSegment(p, v0, v1)
             const double dx = v0x - v1x, dy = v0y - v1y;
             const double tt = dmax(0.0, dmin((dx * (gx - v1x) + dy * (gy - v1y)) / (dx * dx + dy * dy), 1.0));
             const double qx = v1x + dx * tt, qy = v1y + dy * tt;
             const double ex_ = gx - qx, ey_ = gy - qy;
             const double dist = sqrt(ex_ * ex_ + ey_ * ey_);
-            min_dist = (dist < min_dist) ? dist : min_dist;
-            v0x = v1x;
-            v0y = v1y;
+            // min over the five edges of this goal (lanes 5q .. 5q+4), any(outside) over the same five lanes
+            double md = dist;
+#pragma unroll
+            for (int k = 1; k < SSG_SHIP_VERTS; ++k) {
+                int o = wi + k;
+                o = (o >= SSG_SHIP_VERTS) ? o - SSG_SHIP_VERTS : o;
+                md = dmin(md, __shfl(dist, 5 * wq + o));
+            }
+            const unsigned long long mo = __ballot(valid && out_i);
+            const bool outside = ((mo >> (5 * wq)) & 31ull) != 0ull;
+            const double sd = outside ? md : -md;
+            const unsigned long long got = __ballot(valid && (wi == 0) && (sd <= c.goal_r)); // bit 5q = goal q consumed
+            unsigned gotmask = 0;
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS - 1; ++g) gotmask |= ((got >> (5 * g)) & 1ull) ? (1u << g) : 0u;
+            if (lane == src) {
+                goal_reached = gotmask != 0u;
+                gm &= ~gotmask;
+            }
         }
-        const double sd = outside ? min_dist : -min_dist;
-        const bool got = near && (sd <= r);
-        goal_reached = goal_reached || got;
-        gm = got ? (gm & ~(1u << g)) : gm;
     }
 
     // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0); forces are cleared afterwards ----
@@ -416,10 +527,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done = colliding || (alive == 0u) || oob_x || oob_y || (steps >= c.max_steps);
 
-    double *__restrict__ orow = obs + (size_t)e * (size_t)(F * c.history);
+    double *__restrict__ orow = obs + (size_t)el * (size_t)(F * c.history);
     const bool do_reset = done && (c.flags & SSG_FLAG_AUTO_RESET);
 
-    if (!SSG_ABL(6)) {
+    if (live && !SSG_ABL(6)) {
         // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
         // single hot address, and integer adds commute, so the totals are bitwise reproducible run to run.
         // cum is a sum of {1, -1, -0.01} terms, so round(100*cum) is the exact return in hundredths.
@@ -453,6 +564,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
         o_new[0] = x; o_new[1] = y; o_new[2] = 0.0; o_new[3] = 0.0;
         o_new[4] = nrec[SSG_MAP_OFF_SPAWN_GOAL]; o_new[5] = nrec[SSG_MAP_OFF_SPAWN_GOAL + 1];
     }
+    if (!live) return; // every cooperative section is behind us: lanes past n_envs store nothing
     if (!SSG_ABL(7)) {
     if (hist2) {
 #pragma unroll
@@ -590,12 +702,20 @@ static step_fn_t step_fn(int nb, int block, bool lds, bool exact)
     }
 }
 
+// dynamic LDS: [bank (if staged)] [beam table] [per-wave lidar scratch]
+size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps)
+{
+    size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
+    b += 2 * SSG_MAX_BEAMS * 8;
+    b += (size_t)(block / 64) * (size_t)(n_beams * (64 * 8 + 2 * 64 * 2));
+    return b;
+}
+
 // Raise the dynamic-LDS cap of the selected instantiation once (whenever the bank size changes).
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes)
 {
     step_fn_t k = step_fn(c.n_beams, block, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
-    if (!lds) return hipSuccess;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds_bytes);
 }
@@ -606,7 +726,7 @@ hipError_t launch_step(const DevCfg &c, int block, bool lds, size_t lds_bytes, c
     step_fn_t k = step_fn(c.n_beams, block, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
     const int grid = (c.n_envs + block - 1) / block;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds ? lds_bytes : 0, stream, c, actions, obs, reward, done, flags);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, stream, c, actions, obs, reward, done, flags);
     return hipGetLastError();
 }
 
