@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 65536
 N_BEAMS = 8
-N_MAPS = 64
+N_MAPS = int(os.environ.get("SSG_BENCH_MAPS", "64"))  # BASELINE workload: 64; override only for experiments
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 

@@ -60,20 +60,21 @@ typedef enum ssg_status {
  *   [2..5]  left  hull AABB l,b,r,t     [6..9] right hull AABB
  *   [10..26)  goal centres x0,y0,x1,y1,...  (SSG_MAX_GOALS pairs)
  *   [26] [27] the goal nearest to the spawn point (the reset observation's goal, ship_env.py:102-108)
- *   [28 + 8*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax 0     j < 12
- *   [124 + 8*j ..) right plane j
- *   [220] [221] spare
+ *   [28 + 7*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax       j < 12
+ *   [112 + 7*j ..) right plane j
+ *   [196] [197] spare
  * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180); v0.n, dtMin =
  * cross(n, v[j-1]) and dtMax = cross(n, v[j]) are the per-plane constants cpPolyShapeSegmentQuery derives.
- * 222 doubles = 111 sixteen-byte slots: an odd slot stride, so consecutive maps start on different LDS banks.
+ * 198 doubles = 99 sixteen-byte slots: an odd slot stride, so consecutive maps start on different LDS banks; a
+ * 64-map bank is 101 376 bytes and fits the CU's 160 KiB of LDS beside the per-wave lidar scratch.
  */
-#define SSG_MAP_STRIDE 222
+#define SSG_MAP_STRIDE 198
 #define SSG_MAP_OFF_COUNTS 0
 #define SSG_MAP_OFF_AABB 2
 #define SSG_MAP_OFF_GOALS 10
 #define SSG_MAP_OFF_SPAWN_GOAL 26
 #define SSG_MAP_OFF_PLANES 28
-#define SSG_PLANE_DOUBLES 8
+#define SSG_PLANE_DOUBLES 7
 
 typedef struct ssg_config {
     uint32_t struct_size;  /* sizeof(ssg_config), checked by ssg_create */

@@ -15,7 +15,7 @@
 
 struct ssg_handle {
     ssg_config cfg;
-    ssg::DevCfg dev;
+    ssg::DevCfg dev{};
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, nbytes = 0;
     void *state = nullptr;
@@ -99,13 +99,13 @@ std::vector<Plane> planes_of(const std::vector<P2> &v)
 struct HullView {
     int n;
     const double *pl; // n planes of SSG_PLANE_DOUBLES doubles
-    double v0x(int i) const { return pl[8 * i + 0]; }
-    double v0y(int i) const { return pl[8 * i + 1]; }
-    double nx(int i) const { return pl[8 * i + 2]; }
-    double ny(int i) const { return pl[8 * i + 3]; }
-    double v0n(int i) const { return pl[8 * i + 4]; }
-    double dtmin(int i) const { return pl[8 * i + 5]; }
-    double dtmax(int i) const { return pl[8 * i + 6]; }
+    double v0x(int i) const { return pl[SSG_PLANE_DOUBLES * i + 0]; }
+    double v0y(int i) const { return pl[SSG_PLANE_DOUBLES * i + 1]; }
+    double nx(int i) const { return pl[SSG_PLANE_DOUBLES * i + 2]; }
+    double ny(int i) const { return pl[SSG_PLANE_DOUBLES * i + 3]; }
+    double v0n(int i) const { return pl[SSG_PLANE_DOUBLES * i + 4]; }
+    double dtmin(int i) const { return pl[SSG_PLANE_DOUBLES * i + 5]; }
+    double dtmax(int i) const { return pl[SSG_PLANE_DOUBLES * i + 6]; }
 };
 
 inline double clamp01(double f) { return std::max(0.0, std::min(f, 1.0)); }
@@ -285,6 +285,7 @@ void refresh_dev(ssg_handle *h)
     d.mask = base ? reinterpret_cast<uint8_t *>(base + h->off_mask) : nullptr;
     d.bank = h->bank;
 }
+
 
 int pick_block(int n_envs)
 {
@@ -519,6 +520,16 @@ int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_
     return SSG_OK;
 }
 
+#ifdef SSG_STAMPS
+// diagnostic builds only: where per-wave s_memtime stamps go (16 u64 per wave)
+int ssg_debug_set_stamp_buffer(ssg_handle *h, void *dev_buf)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    h->dev.dbg = static_cast<unsigned long long *>(dev_buf);
+    return SSG_OK;
+}
+#endif
+
 // ---- host geometry ----
 int ssg_host_convex_hull(int count, const double *verts_xy, double *out_xy, int *out_count)
 {
@@ -565,7 +576,7 @@ int ssg_host_build_map(const double *left_xy, int n_left, const double *right_xy
         for (size_t i = 0; i < pl.size(); ++i) {
             double *q = pp + SSG_PLANE_DOUBLES * i;
             q[0] = pl[i].v0x; q[1] = pl[i].v0y; q[2] = pl[i].nx; q[3] = pl[i].ny;
-            q[4] = pl[i].v0n; q[5] = pl[i].dtmin; q[6] = pl[i].dtmax; q[7] = 0.0;
+            q[4] = pl[i].v0n; q[5] = pl[i].dtmin; q[6] = pl[i].dtmax;
         }
     }
     for (int g = 0; g < n_goals; ++g) {

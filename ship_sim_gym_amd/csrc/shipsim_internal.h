@@ -37,6 +37,7 @@ struct DevCfg {
     uint8_t *mask;
     double *stats;
     const double *bank;
+    unsigned long long *dbg; // diagnostic builds only (-DSSG_STAMPS): per-wave s_memtime stamps
 };
 
 hipError_t launch_step(const DevCfg &c, int block, bool lds, size_t lds_bytes, const int32_t *actions, double *obs,

@@ -94,7 +94,7 @@ __device__ __forceinline__ void nearest_goal(const Rec &rec, unsigned gm, int n_
     for (int g = 0; g < n_goals; ++g) {
         const double px = rec[SSG_MAP_OFF_GOALS + 2 * g], py = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
         const double dx = px - x, dy = py - y;
-        const double d = sqrt(dx * dx + dy * dy);
+        const double d = dx * dx + dy * dy; // squared distance orders exactly like Vec2d.get_distance's sqrt
         const bool take = (gm & (1u << g)) && (d < best); // first alive goal always beats +inf
         best = take ? d : best;
         gx = take ? px : gx;
@@ -117,15 +117,20 @@ __device__ __forceinline__ void nearest_goal(const Rec &rec, unsigned gm, int n_
 //                  within its length (d >= 0 and d <= den, i.e. 0 <= t <= 1) only the one with the largest t can
 //                  be the entry edge of a convex polygon, so only that plane gets the exact t = d/den, lerp and
 //                  edge-extent test.  Identical results except when a ray passes within rounding of a hull vertex.
-// Hull 0 (left bank) pairs are processed before hull 1 pairs: the first shape in list order that reports a hit
-// wins (models.py:61-72).  Results travel back through a per-wave LDS array res[beam][lane] (-1 = no hit).
+// Results travel back through two per-wave LDS arrays res0/res1[beam][lane] (-1 = no hit), one per hull; the owner
+// lane then applies "the first shape in list order that reports a hit wins" (models.py:61-72): left bank first.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_scratch_wave_bytes(int nb) { return nb * (64 * 8 + 2 * 64 * 2); }
+// per-wave LDS scratch: res0[NB][64] + res1[NB][64] doubles, queue[2*NB*64 + 64 trash] u16, item counter (16 B)
+__host__ __device__ __forceinline__ constexpr int lds_scratch_wave_bytes(int nb)
+{
+    return 2 * nb * 64 * 8 + (2 * nb * 64 + 64) * 2 + 16;
+}
+
+constexpr int kPlaneChunk = 4; // hull planes fetched from LDS ahead of their arithmetic, per loop trip
 
 template <int NB, bool LDS_BANK, bool EXACT>
-__device__ __forceinline__ void lidar_pass(const DevCfg &c, const int s, const int n_items,
-                                           const unsigned short *queue, double *res,
-                                           const double *beamtab, const double cx, const double cy,
+__device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue, double *res0,
+                                           double *res1, const double *beamtab, const double cx, const double cy,
                                            const double ca, const double sa, const int rec_off, const int lane)
 {
     const auto bk = [&](int i) {
@@ -136,7 +141,7 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int s, const i
         const int idx = base + lane;
         const bool act = idx < n_items;
         const unsigned code = queue[act ? idx : 0];
-        const int src = code & 63, bi = code >> 6;
+        const int src = code & 63, bi = (code >> 6) & (SSG_MAX_BEAMS - 1), s = (code >> 10) & 1;
         const double wcx = __shfl(cx, src), wcy = __shfl(cy, src), wca = __shfl(ca, src), wsa = __shfl(sa, src);
         const int woff = __shfl(rec_off, src);
         const double cphi = beamtab[bi], sphi = beamtab[SSG_MAX_BEAMS + bi];
@@ -149,36 +154,47 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int s, const i
         double ptx = ex, pty = ey;
         double bd = -1.0, bden = 1.0;
         int bj = 0;
-        for (int j = 0; __any(act && (j < cnt)); ++j) {
-            const bool valid = act && (j < cnt);
-            const int q = pb + 8 * (valid ? j : 0);
-            const double v0x = bk(q + 0), v0y = bk(q + 1), nx = bk(q + 2), ny = bk(q + 3), v0n = bk(q + 4);
-            outside = outside || (valid && ((nx * (wcx - v0x) + ny * (wcy - v0y)) > 0.0));
-            const double an = wcx * nx + wcy * ny;
-            const double d = an - v0n;
-            const bool front = valid && !(d < 0.0);
-            const double bn = ex * nx + ey * ny;
-            const double den = dmax(an - bn, DBL_MIN);
-            if (EXACT) {
-                const double dtmin = bk(q + 5), dtmax = bk(q + 6);
-                const double t = d / den;
-                const double omt = 1.0 - t;
-                const double qx = wcx * omt + ex * t, qy = wcy * omt + ey * t; // cpvlerp(a,b,t)
-                const double dtv = nx * qy - ny * qx;                           // cpvcross(n, point)
-                const bool acc = front && !(t < 0.0 || 1.0 < t) && (dtmin <= dtv) && (dtv <= dtmax);
-                ok = ok || acc;
-                ptx = acc ? qx : ptx;
-                pty = acc ? qy : pty;
-            } else {
-                // candidate: 0 <= d/den <= 1; better: d/den >= best (cross-multiplied, dens > 0; ties -> later plane)
-                const bool better = front && (d <= den) && (d * bden >= bd * den);
-                bd = better ? d : bd;
-                bden = better ? den : bden;
-                bj = better ? j : bj;
+        for (int j0 = 0; __any(act && (j0 < cnt)); j0 += kPlaneChunk) {
+            double pv0x[kPlaneChunk], pv0y[kPlaneChunk], pnx[kPlaneChunk], pny[kPlaneChunk], pv0n[kPlaneChunk];
+            double pdtmin[kPlaneChunk], pdtmax[kPlaneChunk];
+#pragma unroll
+            for (int u = 0; u < kPlaneChunk; ++u) { // all LDS reads of the chunk first: one latency per chunk
+                const int j = j0 + u;
+                const int q = pb + SSG_PLANE_DOUBLES * ((act && (j < cnt)) ? j : 0);
+                pv0x[u] = bk(q + 0); pv0y[u] = bk(q + 1); pnx[u] = bk(q + 2); pny[u] = bk(q + 3); pv0n[u] = bk(q + 4);
+                if (EXACT) { pdtmin[u] = bk(q + 5); pdtmax[u] = bk(q + 6); }
+            }
+#pragma unroll
+            for (int u = 0; u < kPlaneChunk; ++u) {
+                const int j = j0 + u;
+                const bool valid = act && (j < cnt);
+                const double v0x = pv0x[u], v0y = pv0y[u], nx = pnx[u], ny = pny[u], v0n = pv0n[u];
+                outside = outside || (valid && ((nx * (wcx - v0x) + ny * (wcy - v0y)) > 0.0));
+                const double an = wcx * nx + wcy * ny;
+                const double d = an - v0n;
+                const bool front = valid && !(d < 0.0);
+                const double bn = ex * nx + ey * ny;
+                const double den = dmax(an - bn, DBL_MIN);
+                if (EXACT) {
+                    const double t = d / den;
+                    const double omt = 1.0 - t;
+                    const double qx = wcx * omt + ex * t, qy = wcy * omt + ey * t; // cpvlerp(a,b,t)
+                    const double dtv = nx * qy - ny * qx;                           // cpvcross(n, point)
+                    const bool acc = front && !(t < 0.0 || 1.0 < t) && (pdtmin[u] <= dtv) && (dtv <= pdtmax[u]);
+                    ok = ok || acc;
+                    ptx = acc ? qx : ptx;
+                    pty = acc ? qy : pty;
+                } else {
+                    // candidate: 0 <= d/den <= 1; better: d/den >= best (cross-multiplied, dens > 0; ties -> later)
+                    const bool better = front && (d <= den) && (d * bden >= bd * den);
+                    bd = better ? d : bd;
+                    bden = better ? den : bden;
+                    bj = better ? j : bj;
+                }
             }
         }
         if (!EXACT) {
-            const int q = pb + 8 * bj;
+            const int q = pb + SSG_PLANE_DOUBLES * bj;
             const double nx = bk(q + 2), ny = bk(q + 3), dtmin = bk(q + 5), dtmax = bk(q + 6);
             const double t = bd / bden;
             const double omt = 1.0 - t;
@@ -192,16 +208,25 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int s, const i
         const double px = outside ? ptx : ex, py = outside ? pty : ey;
         const double dx = px - wcx, dy = py - wcy;
         const double dist = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
-        const int slot = bi * 64 + src;
-        if (hit) {
-            if (s == 0) res[slot] = dist;
-            else if (res[slot] < 0.0) res[slot] = dist; // the left bank (listed first) already answered this beam
-        }
+        if (hit) (s ? res1 : res0)[bi * 64 + src] = dist;
     }
 }
 
-// Timing-only ablation switches (development builds with -DSSG_ABLATION; never in the product library): bits
-// 16.. of DevCfg.flags skip a section so its share of the kernel time can be measured.  Outputs are wrong.
+// Diagnostic stamps (-DSSG_STAMPS builds only; the product kernel executes none): s_memtime at section boundaries,
+// written by lane 0 of every wave to a buffer nothing else reads.
+#ifdef SSG_STAMPS
+#define SSG_STAMP(k)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        stamp_[k] = t_;                                                                           \
+    } while (0)
+#else
+#define SSG_STAMP(k) do { } while (0)
+#endif
+
 #ifdef SSG_ABLATION
 #define SSG_ABL(bit) (c.flags & (1u << (16 + (bit))))
 #else
@@ -219,6 +244,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     const bool live = e < c.n_envs;
     const size_t np = (size_t)c.n_pad;
+    const int lane = threadIdx.x & 63;
 
     double *__restrict__ colX = c.f64cols + COL_X * np;
     double *__restrict__ colY = c.f64cols + COL_Y * np;
@@ -232,8 +258,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     int32_t *__restrict__ colStep = c.i32cols + ICOL_STEP * np;
     int32_t *__restrict__ colMap = c.i32cols + ICOL_MAP * np;
 
-    // ---- the bank DMA and every state load are issued back to back; one wait covers them all ----
-    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<BLOCK>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+#ifdef SSG_STAMPS
+    unsigned long long stamp_[16] = {};
+#endif
+    SSG_STAMP(0);
+    // ---- state loads first, then the bank DMA: everything below that does not need the bank (trigonometry, the
+    //      action, the integrator, the ship's world transform) runs while the 100 KB of records stream into LDS.
+    //      No early exit: lanes past n_envs stay active as workers of the wave-cooperative sections; they carry
+    //      env 0's state, never count as "near" anything and store nothing. ----
     const int el = live ? e : 0;
     double x = colX[el], y = colY[el], vx = colVX[el], vy = colVY[el], ang = colA[el], w = colW[el];
     double cum = colCum[el];
@@ -243,45 +275,30 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     int rudder = colRud[el], steps = colStep[el], map_id = colMap[el];
     unsigned gm = c.mask[el];
     const int act = actions[el];
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<BLOCK>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
     // LDS layout: [bank records (LDS_BANK only)] [beam cos/sin table 2 x 16 doubles] [per-wave lidar scratch]
     char *lds_scratch = reinterpret_cast<char *>(lds_bank()) + (LDS_BANK ? ((c.n_maps * (SSG_MAP_STRIDE * 8) + 15) & ~15) : 0);
     if (threadIdx.x < 2 * SSG_MAX_BEAMS)
         reinterpret_cast<double *>(lds_scratch)[threadIdx.x] =
             (threadIdx.x < SSG_MAX_BEAMS) ? c.beam_cos[threadIdx.x & (SSG_MAX_BEAMS - 1)] : c.beam_sin[threadIdx.x & (SSG_MAX_BEAMS - 1)];
-    if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int rec_off = (int)map_id * SSG_MAP_STRIDE;
-    // No early exit: lanes past n_envs stay active as workers of the wave-cooperative sections below; they carry
-    // env 0's state, never count as "near" anything and store nothing.
-
-    auto make_rec = [&](int m) {
-        if constexpr (LDS_BANK) return LdsRec{m * SSG_MAP_STRIDE};
-        else return GlbRec{c.bank + (size_t)m * SSG_MAP_STRIDE};
-    };
-    const auto rec = make_rec(map_id);
 
     const int F = 6 + NB;
     const bool hist2 = c.history >= 2;
+    const int rec_off = (int)map_id * SSG_MAP_STRIDE;
 
-    // ---- previous frame (oldest slot of the 2-frame history) is a pure function of the pre-step state ----
+    // previous frame (oldest slot of the 2-frame history): a pure function of the pre-step state
     const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang;
-    double pf_gx = 0, pf_gy = 0;
-    if (!SSG_ABL(0)) nearest_goal(rec, gm, c.n_goals, x, y, pf_gx, pf_gy);
-    double pf_lid[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) pf_lid[i] = lid[i];
 
     // ---- handle_discrete_action (game.py:140-153) ----
-    double sa, ca;
-    sincos(ang, &sa, &ca); // cpvforangle(a) = (cos a, sin a): body->transform rotation
+    double sa0, ca0;
+    sincos(ang, &sa0, &ca0); // cpvforangle(a) = (cos a, sin a): body->transform rotation
     double fx, fy, tq;
     {
         // Ship.move_forward -> cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust)
         const double px = (gm & 0x80u) ? (0.0 - (double)rudder) : c.px0; // models.py:109,146
         const double py = c.py0;
-        const double fwx = (-sa) * c.force_y, fwy = ca * c.force_y;      // cpTransformVect(transform, (0,F))
-        const double pwx = ca * px + (-sa) * py + x, pwy = sa * px + ca * py + y; // cpTransformPoint
+        const double fwx = (-sa0) * c.force_y, fwy = ca0 * c.force_y;    // cpTransformVect(transform, (0,F))
+        const double pwx = ca0 * px + (-sa0) * py + x, pwy = sa0 * px + ca0 * py + y; // cpTransformPoint
         const double rx = pwx - x, ry = pwy - y;                         // minus transform * cog, cog = (0,0)
         const bool thrust = act == 0;
         fx = thrust ? fwx : 0.0;
@@ -295,21 +312,78 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
         gm |= 0x80u;
     }
 
-    // ---- LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step) ----
-    if (!SSG_ABL(1)) {
+    // lidar origin on the PRE-step pose: pos + half the world AABB extents (models.py:51-53)
+    double cx, cy;
+    {
         double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
 #pragma unroll
         for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
             const double hx = c.hull[2 * i], hy = c.hull[2 * i + 1];
-            const double wx = ca * hx + (-sa) * hy + x, wy = sa * hx + ca * hy + y;
+            const double wx = ca0 * hx + (-sa0) * hy + x, wy = sa0 * hx + ca0 * hy + y;
             bl = dmin(bl, wx); br = dmax(br, wx);
             bb = dmin(bb, wy); bt = dmax(bt, wy);
         }
-        const double cx = x + (br - bl) / 2, cy = y + (bt - bb) / 2; // models.py:51-53: pos + half AABB extents
+        cx = x + (br - bl) / 2;
+        cy = y + (bt - bb) / 2;
+    }
+    const double x0 = x, y0 = y;
+
+    // ---- cpSpaceStep (1): cpBodyUpdatePosition ----
+    x = x + vx * c.dt;
+    y = y + vy * c.dt;
+    ang = ang + w * c.dt;
+    double sa, ca;
+    sincos(ang, &sa, &ca);
+
+    // ---- cpSpaceStep (2): cpPolyShapeCacheData for the ship: world AABB (the planes are rebuilt by the workers) ----
+    double sbl = INFINITY, sbr = -INFINITY, sbb = INFINITY, sbt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+        const double hx = c.hull[2 * i], hy = c.hull[2 * i + 1];
+        const double wx = ca * hx + (-sa) * hy + x, wy = sa * hx + ca * hy + y;
+        sbl = dmin(sbl, wx); sbr = dmax(sbr, wx);
+        sbb = dmin(sbb, wy); sbt = dmax(sbt, wy);
+    }
+
+    // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0); forces are cleared afterwards.  (The narrowphase sits
+    //      between (1) and (3) in Chipmunk but reads positions only, so the order here is immaterial.) ----
+    vx = vx * c.damp + (fx * c.m_inv) * c.dt;
+    vy = vy * c.damp + (fy * c.m_inv) * c.dt;
+    w = w * c.damp + tq * c.i_inv * c.dt;
+    // (4) impulse solver: its output cannot reach an observation before the env is reset (DESIGN.md §2).
+    const bool oob_x = (x < 0.0) || (x > c.width);
+    const bool oob_y = (y < 0.0) || (y > c.height);
+
+    // worker coordinates of the wave-cooperative sections: lane L = 5*q + i
+    const int wq = lane / 5, wi = lane - 5 * wq;
+    const double w_hx = pick5(c.hull, 2, wi), w_hy = pick5(c.hull + 1, 2, wi);       // ship vertex i (local)
+    const double w_nx = pick5(c.nrm, 2, wi), w_ny = pick5(c.nrm + 1, 2, wi);         // ship normal i (local)
+    const int wip = (wi == 0) ? (SSG_SHIP_VERTS - 1) : (wi - 1);
+    const double w_px = pick5(c.hull, 2, wip), w_py = pick5(c.hull + 1, 2, wip);     // previous vertex (edge start)
+
+    SSG_STAMP(1);
+    if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+    __syncthreads();
+    SSG_STAMP(2);
+
+    auto make_rec = [&](int m) {
+        if constexpr (LDS_BANK) return LdsRec{m * SSG_MAP_STRIDE};
+        else return GlbRec{c.bank + (size_t)m * SSG_MAP_STRIDE};
+    };
+    const auto rec = make_rec(map_id);
+
+    double pf_gx = 0, pf_gy = 0;
+    if (!SSG_ABL(0)) nearest_goal(rec, gm, c.n_goals, x0, y0, pf_gx, pf_gy);
+
+    // ---- LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step) ----
+    double nl[NB]; // this step's new readings (-1 where nothing was hit)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) nl[i] = -1.0;
+    if (!SSG_ABL(1)) {
         // Beam i points along heading + phi_i, phi_i = rad(90 - spread/2) + i*rad(spread/n_beams) (models.py:48-49,
-        // 62-64).  cos/sin(heading + phi_i) come from the body rotation (ca, sa) and host-computed cos/sin(phi_i) by
-        // the angle-addition identity instead of one sincos per beam: endpoints agree with the reference's to
-        // ~1e-13 (they only feed lidar readings, never the dynamics).
+        // 62-64).  cos/sin(heading + phi_i) come from the body rotation and host-computed cos/sin(phi_i) by the
+        // angle-addition identity instead of one sincos per beam: endpoints agree with the reference's to ~1e-13
+        // (they only feed lidar readings, never the dynamics).
         unsigned need0 = 0, need1 = 0;
         {
             const double a0l = rec[SSG_MAP_OFF_AABB + 0], a0b = rec[SSG_MAP_OFF_AABB + 1];
@@ -319,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
             const double eps = 1e-6; // conservative margin: culling must never drop a pair the reference would hit
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const double ux = ca * c.beam_cos[i] - sa * c.beam_sin[i], uy = sa * c.beam_cos[i] + ca * c.beam_sin[i];
+                const double ux = ca0 * c.beam_cos[i] - sa0 * c.beam_sin[i], uy = sa0 * c.beam_cos[i] + ca0 * c.beam_sin[i];
                 const double ex = cx + c.lidar_dist * ux, ey = cy + c.lidar_dist * uy;
                 const double lox = dmin(cx, ex) - eps, hix = dmax(cx, ex) + eps;
                 const double loy = dmin(cy, ey) - eps, hiy = dmax(cy, ey) + eps;
@@ -329,55 +403,41 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
                 need1 |= n1 ? (1u << i) : 0u;
             }
         }
-        // per-wave LDS scratch: res[NB][64] doubles, queue0[NB*64] u16, queue1[NB*64] u16
+        // per-wave LDS scratch
         char *wscr = lds_scratch + 2 * SSG_MAX_BEAMS * 8 + (threadIdx.x >> 6) * lds_scratch_wave_bytes(NB);
-        double *res = reinterpret_cast<double *>(wscr);
-        unsigned short *q0 = reinterpret_cast<unsigned short *>(wscr + NB * 64 * 8);
-        unsigned short *q1 = q0 + NB * 64;
-        int n0 = 0, n1 = 0;
+        double *res0 = reinterpret_cast<double *>(wscr);
+        double *res1 = res0 + NB * 64;
+        unsigned short *queue = reinterpret_cast<unsigned short *>(res1 + NB * 64);
+        constexpr int kTrash = 2 * NB * 64; // 64 u16 past the queue swallow the writes of pairs that were culled
+        int *counter = reinterpret_cast<int *>(queue + kTrash + 64);
+        if (lane == 0) *counter = 0;
+        const int mine = __popc(need0) + __popc(need1);
+        int pos = (mine > 0) ? atomicAdd(counter, mine) : 0; // LDS atomic: compaction offset of this lane's pairs
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            res[i * 64 + lane] = -1.0;
-            const unsigned long long m0 = __ballot((need0 >> i) & 1u), m1 = __ballot((need1 >> i) & 1u);
-            const int p0 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
-            const int p1 = n1 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-            if ((need0 >> i) & 1u) q0[p0] = (unsigned short)(lane | (i << 6));
-            if ((need1 >> i) & 1u) q1[p1] = (unsigned short)(lane | (i << 6));
-            n0 += __popcll(m0);
-            n1 += __popcll(m1);
+            res0[i * 64 + lane] = -1.0;
+            res1[i * 64 + lane] = -1.0;
+            const bool k0 = (need0 >> i) & 1u, k1 = (need1 >> i) & 1u;
+            queue[k0 ? pos : (kTrash + lane)] = (unsigned short)(lane | (i << 6));
+            pos += k0 ? 1 : 0;
+            queue[k1 ? pos : (kTrash + lane)] = (unsigned short)(lane | (i << 6) | (1 << 10));
+            pos += k1 ? 1 : 0;
         }
+        const int n_items = __builtin_amdgcn_readfirstlane(*counter);
+        SSG_STAMP(3);
         if (!SSG_ABL(3)) {
             const double *beamtab = reinterpret_cast<const double *>(lds_scratch);
-            lidar_pass<NB, LDS_BANK, EXACT>(c, 0, n0, q0, res, beamtab, cx, cy, ca, sa, rec_off, lane);
-            lidar_pass<NB, LDS_BANK, EXACT>(c, 1, n1, q1, res, beamtab, cx, cy, ca, sa, rec_off, lane);
+            lidar_pass<NB, LDS_BANK, EXACT>(c, n_items, queue, res0, res1, beamtab, cx, cy, ca0, sa0, rec_off, lane);
         }
+        SSG_STAMP(4);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const double r = res[i * 64 + lane];
-            lid[i] = (r >= 0.0) ? r : lid[i]; // a miss keeps the previous reading (sticky, App. B-3)
+            // first shape in list order that reports a hit wins (models.py:61-72): the left bank before the right
+            const double r0 = res0[i * 64 + lane], r1 = res1[i * 64 + lane];
+            nl[i] = (r0 >= 0.0) ? r0 : r1;
         }
     }
-
-    // ---- cpSpaceStep (1): cpBodyUpdatePosition ----
-    x = x + vx * c.dt;
-    y = y + vy * c.dt;
-    ang = ang + w * c.dt;
-    sincos(ang, &sa, &ca);
-
-    // ---- cpSpaceStep (2): cpPolyShapeCacheData for the ship, then the narrowphase ----
-    double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], snx[SSG_SHIP_VERTS], sny[SSG_SHIP_VERTS];
-    double sbl = INFINITY, sbr = -INFINITY, sbb = INFINITY, sbt = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-        const double hx = c.hull[2 * i], hy = c.hull[2 * i + 1];
-        const double lnx = c.nrm[2 * i], lny = c.nrm[2 * i + 1];
-        swx[i] = ca * hx + (-sa) * hy + x;
-        swy[i] = sa * hx + ca * hy + y;
-        snx[i] = ca * lnx + (-sa) * lny;
-        sny[i] = sa * lnx + ca * lny;
-        sbl = dmin(sbl, swx[i]); sbr = dmax(sbr, swx[i]);
-        sbb = dmin(sbb, swy[i]); sbt = dmax(sbt, swy[i]);
-    }
+    SSG_STAMP(5);
 
     // ---- narrowphase, wave-cooperative ----------------------------------------------------------------------
     // Per lane only the cheap cpBBIntersects rejects run.  The few lanes that pass are then served one at a time
@@ -385,11 +445,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     // env, whose pose is broadcast with v_readlane.  The arithmetic of every product and sum is exactly the
     // per-env formulation's (cpPolyShapeCacheData, SAT dot products, cpPolyShapePointQuery); only the min/any
     // reductions over vertices and planes are done with ballots instead of sequential loops.
-    const int wq = lane / 5, wi = lane - 5 * wq;                    // worker coordinates
-    const double w_hx = pick5(c.hull, 2, wi), w_hy = pick5(c.hull + 1, 2, wi);       // ship vertex i (local)
-    const double w_nx = pick5(c.nrm, 2, wi), w_ny = pick5(c.nrm + 1, 2, wi);         // ship normal i (local)
-    const int wip = (wi == 0) ? (SSG_SHIP_VERTS - 1) : (wi - 1);
-    const double w_px = pick5(c.hull, 2, wip), w_py = pick5(c.hull + 1, 2, wip);     // previous vertex (edge start)
 
     // player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed convex sets
     // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
@@ -423,7 +478,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
                 };
                 const int cnt = (int)brec(SSG_MAP_OFF_COUNTS + s);
                 const bool valid = (lane < 60) && (wq < cnt);
-                const int q = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + 8 * (valid ? wq : 0);
+                const int q = SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * (valid ? wq : 0);
                 const double v0x = brec(q + 0), v0y = brec(q + 1), nx = brec(q + 2), ny = brec(q + 3), v0n = brec(q + 4);
                 const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
                 const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
@@ -443,6 +498,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
             colliding = (lane == src) ? col : colliding;
         }
     }
+    SSG_STAMP(6);
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -503,16 +559,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
             }
         }
     }
-
-    // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0); forces are cleared afterwards ----
-    vx = vx * c.damp + (fx * c.m_inv) * c.dt;
-    vy = vy * c.damp + (fy * c.m_inv) * c.dt;
-    w = w * c.damp + tq * c.i_inv * c.dt;
-    // (4) impulse solver: its output cannot reach an observation before the env is reset (DESIGN.md §2).
+    SSG_STAMP(7);
 
     // ---- determine_reward (ship_env.py:62-77) ----
-    const bool oob_x = (x < 0.0) || (x > c.width);
-    const bool oob_y = (y < 0.0) || (y > c.height);
     double rew = goal_reached ? 1.0 : ((oob_x || oob_y) ? -1.0 : -0.01);
     if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && colliding && !goal_reached) rew = -1.0;
     cum += rew;
@@ -526,8 +575,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     const int steps_after = steps;
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done = colliding || (alive == 0u) || oob_x || oob_y || (steps >= c.max_steps);
-
-    double *__restrict__ orow = obs + (size_t)el * (size_t)(F * c.history);
     const bool do_reset = done && (c.flags & SSG_FLAG_AUTO_RESET);
 
     if (live && !SSG_ABL(6)) {
@@ -549,7 +596,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
     o_old[0] = pf_x; o_old[1] = pf_y; o_old[2] = pf_rud; o_old[3] = pf_a; o_old[4] = pf_gx; o_old[5] = pf_gy;
     o_new[0] = x; o_new[1] = y; o_new[2] = (double)rudder; o_new[3] = ang; o_new[4] = nf_gx; o_new[5] = nf_gy;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) { o_old[6 + i] = pf_lid[i]; o_new[6 + i] = lid[i]; }
+    for (int i = 0; i < NB; ++i) {
+        o_old[6 + i] = lid[i];                            // readings before this step's query
+        lid[i] = (nl[i] >= 0.0) ? nl[i] : lid[i];         // a miss keeps the previous reading (sticky, App. B-3)
+        o_new[6 + i] = lid[i];
+    }
     if (do_reset) {
         map_id = map_id + 1;
         if (map_id >= c.n_maps) map_id = 0;
@@ -564,16 +615,28 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevCfg c, const int32
         o_new[0] = x; o_new[1] = y; o_new[2] = 0.0; o_new[3] = 0.0;
         o_new[4] = nrec[SSG_MAP_OFF_SPAWN_GOAL]; o_new[5] = nrec[SSG_MAP_OFF_SPAWN_GOAL + 1];
     }
-    if (!live) return; // every cooperative section is behind us: lanes past n_envs store nothing
-    if (!SSG_ABL(7)) {
-    if (hist2) {
-#pragma unroll
-        for (int i = 0; i < 6 + NB; ++i) orow[i] = o_old[i];
-        orow += F;
+    SSG_STAMP(8);
+#ifdef SSG_STAMPS
+    if (c.dbg && lane == 0) {
+        unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+        for (int k = 0; k < 9; ++k) d_[k] = stamp_[k];
     }
+#endif
+    if (!live) return; // every cooperative section is behind us: lanes past n_envs store nothing
+    double *__restrict__ orow = obs + (size_t)e * (size_t)(F * c.history);
+    if (!SSG_ABL(7)) {
+        if (hist2) {
 #pragma unroll
-    for (int i = 0; i < 6 + NB; ++i) orow[i] = o_new[i];
-    } else { double acc = 0; for (int i = 0; i < 6 + NB; ++i) acc += o_old[i] + o_new[i]; orow[0] = acc; }
+            for (int i = 0; i < 6 + NB; ++i) orow[i] = o_old[i];
+            orow += F;
+        }
+#pragma unroll
+        for (int i = 0; i < 6 + NB; ++i) orow[i] = o_new[i];
+    } else {
+        double acc = 0;
+        for (int i = 0; i < 6 + NB; ++i) acc += o_old[i] + o_new[i];
+        orow[0] = acc;
+    }
 
     reward_out[e] = rew;
     done_out[e] = done ? 1 : 0;
@@ -707,7 +770,7 @@ size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps)
 {
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
     b += 2 * SSG_MAX_BEAMS * 8;
-    b += (size_t)(block / 64) * (size_t)(n_beams * (64 * 8 + 2 * 64 * 2));
+    b += (size_t)(block / 64) * (size_t)lds_scratch_wave_bytes(n_beams);
     return b;
 }
 
