@@ -62,13 +62,12 @@ typedef enum ssg_status {
  *   [26] [27] the goal nearest to the spawn point (the reset observation's goal, ship_env.py:102-108)
  *   [28 + 7*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax       j < 12
  *   [112 + 7*j ..) right plane j
- *   [196] [197] spare
  * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180); v0.n, dtMin =
  * cross(n, v[j-1]) and dtMax = cross(n, v[j]) are the per-plane constants cpPolyShapeSegmentQuery derives.
- * 198 doubles = 99 sixteen-byte slots: an odd slot stride, so consecutive maps start on different LDS banks; a
- * 64-map bank is 101 376 bytes and fits the CU's 160 KiB of LDS beside the per-wave lidar scratch.
+ * 196 doubles (1568 bytes, a multiple of the 16-byte LDS-DMA granule): a 64-map bank is 100 352 bytes and fits the
+ * CU's 160 KiB of LDS beside the role-A waves' lidar scratch for up to 10 beams at 256 envs per workgroup.
  */
-#define SSG_MAP_STRIDE 198
+#define SSG_MAP_STRIDE 196
 #define SSG_MAP_OFF_COUNTS 0
 #define SSG_MAP_OFF_AABB 2
 #define SSG_MAP_OFF_GOALS 10

@@ -291,12 +291,13 @@ int pick_block(int n_envs)
 {
     if (const char *s = std::getenv("SSG_BLOCK")) {
         const int b = std::atoi(s);
-        if (b == 64 || b == 256 || b == 512) return b;
+        if (b == 64 || b == 128 || b == 256) return b;
     }
-    // MI355X has 256 CUs: aim for >= 256 workgroups before growing the workgroup (one wave per SIMD first).
+    // Envs per workgroup (the workgroup has twice as many threads: role-split waves).  MI355X has 256 CUs and a
+    // workgroup that stages the bank owns its CU's LDS: aim for >= 256 workgroups before growing them.
     if (n_envs <= 64 * 256) return 64;
-    if (n_envs <= 256 * 256) return 256;
-    return 512;
+    if (n_envs <= 128 * 256) return 128;
+    return 256;
 }
 
 int check_ready(ssg_handle *h, bool need_bank)
