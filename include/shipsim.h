@@ -64,10 +64,12 @@ typedef enum ssg_status {
  *   [112 + 7*j ..) right plane j
  * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180); v0.n, dtMin =
  * cross(n, v[j-1]) and dtMax = cross(n, v[j]) are the per-plane constants cpPolyShapeSegmentQuery derives.
- * 196 doubles (1568 bytes, a multiple of the 16-byte LDS-DMA granule): a 64-map bank is 100 352 bytes and fits the
- * CU's 160 KiB of LDS beside the role-A waves' lidar scratch for up to 10 beams at 256 envs per workgroup.
+ *   [196] spare
+ * 197 doubles: an ODD stride in 8-byte units, so the same field of different maps falls on different LDS banks
+ * (lanes of a wave sit on different maps; an even stride made such reads 8-way bank conflicts).  A 64-map bank is
+ * 100 864 bytes and fits the CU's 160 KiB of LDS beside the lidar waves' scratch.
  */
-#define SSG_MAP_STRIDE 196
+#define SSG_MAP_STRIDE 197
 #define SSG_MAP_OFF_COUNTS 0
 #define SSG_MAP_OFF_AABB 2
 #define SSG_MAP_OFF_GOALS 10

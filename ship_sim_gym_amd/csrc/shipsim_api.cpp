@@ -460,6 +460,11 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     if (!h || !dev_bank || n_maps < 1) return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bad argument");
     if (reinterpret_cast<uintptr_t>(dev_bank) % 16 != 0)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
+    // Envs per workgroup: start from the size preferred for this env count and halve it until the staged bank fits
+    // the CU's LDS beside the lidar scratch; if even 64 does not fit, gather records from L2/HBM instead.
+    h->block = pick_block(h->cfg.n_envs);
+    if (!(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL))
+        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) > 160u * 1024u) h->block /= 2;
     h->bank = dev_bank;
     h->n_maps = n_maps;
     // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch

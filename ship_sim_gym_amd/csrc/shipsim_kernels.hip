@@ -62,7 +62,7 @@ __device__ __forceinline__ double bank_at(const DevCfg &c, int i)
     else return c.bank[i];
 }
 
-// Stage `bytes` (multiple of 16) from global memory into LDS at offset 0 with LDS-DMA (global_load_lds_dwordx4:
+// Stage `bytes` (multiple of 8) from global memory into LDS at offset 0 with LDS-DMA (global_load_lds_dwordx4:
 // 1 KiB per wave-instruction, no VGPR round trip, all requests in flight at once), tail < 1 KiB through registers.
 template <int THREADS>
 __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, int bytes)
@@ -77,8 +77,9 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
                                          (__attribute__((address_space(3))) void *)(l + ch * 1024), 16, 0, 0);
     }
     const int tail0 = nchunk << 10;
-    const int o = tail0 + (int)threadIdx.x * 16;
-    if (o < bytes) *reinterpret_cast<double2 *>(l + o) = *reinterpret_cast<const double2 *>(g + o);
+    const int o = tail0 + (int)threadIdx.x * 8;
+    if (o < bytes) *reinterpret_cast<double *>(l + o) = *reinterpret_cast<const double *>(g + o);
+    static_assert(THREADS * 8 >= 1024, "tail copy needs one thread per 8 bytes of a 1 KiB chunk");
 }
 
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
@@ -116,8 +117,9 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 // LDS layout of the step kernel (doubles unless noted), after the optional bank copy:
 //   beamtab  [2][16]      cos/sin(phi_i)
 //   shiptab  [6][8]       per ship vertex i: local vertex, local plane normal, previous vertex
-//   xchg     [5][EPW]     A -> B: force x, force y, torque, previous-frame nearest goal x, y
-//   scratch  per A wave:  res0[NB][64], res1[NB][64], queue[2*NB*64 + 64 trash] u16
+//   xchg     [5][EPW]     -> role 3: force x, force y, torque (role 0); new-frame nearest goal x, y (role 2)
+//   gres     [EPW] u32    -> role 3: goal mask after collide_goal | goal_reached << 31 (role 2)
+//   scratch  per lidar wave (roles 0,1): res0[NBH][64], res1[NBH][64], queue[2*NBH*64 + 64 trash] u16, NBH = ceil(NB/2)
 // ---------------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ constexpr int lds_wave_scratch_bytes(int nb)
 {
@@ -125,7 +127,7 @@ __host__ __device__ __forceinline__ constexpr int lds_wave_scratch_bytes(int nb)
 }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-__host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw) { return kBeamTabBytes + kShipTabBytes + 5 * epw * 8; }
+__host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw) { return kBeamTabBytes + kShipTabBytes + 5 * epw * 8 + epw * 4; }
 
 // ---------------------------------------------------------------------------------------------------------
 // LiDAR (models.py:39-76), wave-compacted.
@@ -147,7 +149,7 @@ __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw) { ret
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kPlaneChunk = 6; // hull planes fetched from LDS ahead of their arithmetic, per loop trip
 
-template <int NB, bool LDS_BANK, bool EXACT>
+template <bool LDS_BANK, bool EXACT>
 __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue, double *res0,
                                            double *res1, const double *beamtab, const double cx, const double cy,
                                            const double ca, const double sa, const int rec_off, const int lane)
@@ -243,7 +245,7 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
 #define SSG_STAMP_FLUSH(n)                                                                        \
     do {                                                                                          \
         if (c.dbg && lane == 0) {                                                                 \
-            unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (2 * EPW / 64) + (threadIdx.x >> 6)); \
+            unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (4 * EPW / 64) + (threadIdx.x >> 6)); \
             for (int k_ = 0; k_ < (n); ++k_) d_[k_] = stamp_[k_];                                 \
         }                                                                                         \
     } while (0)
@@ -261,15 +263,31 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
-// The step kernel: workgroup of 2*EPW threads = EPW envs; waves [0, EPW/64) role A, waves [EPW/64, 2*EPW/64) role B.
+// The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
+//   role 0  LIDAR-lo : body rotation on the pre-step pose, handle_discrete_action's force/torque, beams [0, NB0)
+//   role 1  LIDAR-hi : body rotation on the pre-step pose, beams [NB0, NB)
+//   role 2  GOALS    : integrator + ship transform, goal-circle narrowphase, nearest remaining goal
+//   role 3  BODY     : integrator + ship transform, bank narrowphase, then (after the workgroup barrier) velocity
+//                      update, reward/done, statistics, sticky-lidar merge, observation and state write-back
+// Roles 0-2 hand their results to role 3 through LDS.  A lone wave on a SIMD issues FP64 at half rate and runs
+// latency-bound; 65 536 envs are only one wave per SIMD, so each env's step is cut into four shorter instruction
+// streams that run as four co-resident waves per SIMD.
 // ---------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
+
+// post-step pose shared by roles 2 and 3 (bitwise identical in both: same loads, same operations)
+struct PostPose {
+    double x, y, ang, ca, sa, sbl, sbr, sbb, sbt;
+};
+
 template <int NB, int EPW, bool LDS_BANK, bool EXACT>
-__global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
                                                        uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out)
 {
-    const bool role_b = threadIdx.x >= EPW;                    // wave-uniform
-    const int tl = threadIdx.x - (role_b ? EPW : 0);           // env slot inside the workgroup
+    constexpr int NB0 = nb_lo(NB);
+    const int role = threadIdx.x / EPW;                        // wave-uniform (EPW is a multiple of 64)
+    const int tl = threadIdx.x - role * EPW;                   // env slot inside the workgroup
     const int e = blockIdx.x * EPW + tl;
     const bool live = e < c.n_envs;
     const int el = live ? e : 0; // lanes past n_envs stay active as workers; they carry env 0 and store nothing
@@ -288,11 +306,12 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
     int32_t *__restrict__ colStep = c.i32cols + ICOL_STEP * np;
     int32_t *__restrict__ colMap = c.i32cols + ICOL_MAP * np;
 
-    const int bank_bytes = LDS_BANK ? ((c.n_maps * (SSG_MAP_STRIDE * 8) + 15) & ~15) : 0;
+    const int bank_bytes = LDS_BANK ? ((c.n_maps * (SSG_MAP_STRIDE * 8) + 15) & ~15) : 0; // 16-byte aligned tables follow
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *xchg = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes);
+    double *xchg = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [5][EPW]
+    unsigned *gres = reinterpret_cast<unsigned *>(xchg + 5 * EPW);                         // [EPW]
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
 
 #ifdef SSG_STAMPS
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
 #endif
     SSG_STAMP(0);
 
-    // small constant tables (written once per workgroup, read with per-lane indices later)
+    // small constant tables (written once per workgroup, read after the first barrier)
     if (threadIdx.x < 2 * SSG_MAX_BEAMS)
         beamtab[threadIdx.x] = (threadIdx.x < SSG_MAX_BEAMS) ? c.beam_cos[threadIdx.x & (SSG_MAX_BEAMS - 1)]
                                                              : c.beam_sin[threadIdx.x & (SSG_MAX_BEAMS - 1)];
@@ -311,22 +330,24 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[4 * 8 + i] = c.hull[2 * ip];    shiptab[5 * 8 + i] = c.hull[2 * ip + 1];  // vertex i-1 (edge start)
     }
 
-    if (!role_b) {
+    if (role < 2) {
         // =====================================================================================================
-        // ROLE A: pre-step half — body rotation, handle_discrete_action, the whole LiDAR.query
+        // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step);
+        //              role 0 also evaluates handle_discrete_action's force and torque.
         // =====================================================================================================
         const double x = colX[el], y = colY[el], ang = colA[el];
-        const int rudder = colRud[el], map_id = colMap[el];
-        const unsigned gm = c.mask[el];
-        const int act = actions[el];
-        if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<2 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+        const int map_id = colMap[el];
+        int rudder = 0, act = 3;
+        unsigned gm = 0;
+        if (role == 0) { rudder = colRud[el]; gm = c.mask[el]; act = actions[el]; }
+        if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
         const int rec_off = map_id * SSG_MAP_STRIDE;
 
         double sa0, ca0;
         sincos(ang, &sa0, &ca0); // cpvforangle(a) = (cos a, sin a): body->transform rotation
-        // ---- handle_discrete_action (game.py:140-153): Ship.move_forward ->
-        //      cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust); the rudder update itself is B's ----
-        {
+        if (role == 0) {
+            // handle_discrete_action (game.py:140-153): Ship.move_forward ->
+            // cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust); the rudder update itself is role 3's
             const double px = (gm & 0x80u) ? (0.0 - (double)rudder) : c.px0; // models.py:109,146
             const double py = c.py0;
             const double fwx = (-sa0) * c.force_y, fwy = ca0 * c.force_y;    // cpTransformVect(transform, (0,F))
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
         __syncthreads();                             // barrier 1: bank + tables visible
         SSG_STAMP(2);
 
-        // lidar origin on the PRE-step pose: pos + half the world AABB extents (models.py:51-53)
+        // lidar origin: pos + half the world AABB extents (models.py:51-53)
         double cx, cy;
         {
             double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
@@ -356,36 +377,31 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
             cx = x + (br - bl) / 2;
             cy = y + (bt - bb) / 2;
         }
-        // previous frame's nearest goal (oldest slot of the 2-frame history): a function of the pre-step state
-        {
-            double pgx = 0, pgy = 0;
-            if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm, x, y, pgx, pgy);
-            xchg[3 * EPW + tl] = pgx;
-            xchg[4 * EPW + tl] = pgy;
-        }
 
-        // ---- LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step) ----
-        char *wscr = scratch0 + (threadIdx.x >> 6) * lds_wave_scratch_bytes(NB);
+        const int lw = role * (EPW / 64) + (tl >> 6); // lidar-wave index inside the workgroup
+        char *wscr = scratch0 + lw * lds_wave_scratch_bytes(NB0);
         double *res0 = reinterpret_cast<double *>(wscr);
-        double *res1 = res0 + NB * 64;
-        unsigned short *queue = reinterpret_cast<unsigned short *>(res1 + NB * 64);
-        constexpr int kTrash = 2 * NB * 64; // 64 u16 past the queue swallow the writes of culled pairs
+        double *res1 = res0 + NB0 * 64;
+        unsigned short *queue = reinterpret_cast<unsigned short *>(res1 + NB0 * 64);
+        constexpr int kTrash = 2 * NB0 * 64; // 64 u16 past the queue swallow the writes of culled pairs
+        const int b_first = role ? NB0 : 0, b_count = role ? (NB - NB0) : NB0;
         int n_items = 0;
-        if (!SSG_ABL(1)) {
-            // hull AABBs widened by eps: culling must never drop a pair the reference would hit
-            const double eps = 1e-6;
-            double al[2], ab[2], ar[2], at[2];
+        // hull AABBs widened by eps: culling must never drop a pair the reference would hit
+        const double eps = 1e-6;
+        double al[2], ab[2], ar[2], at[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                al[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0) - eps;
-                ab[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1) - eps;
-                ar[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2) + eps;
-                at[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3) + eps;
-            }
+        for (int s = 0; s < 2; ++s) {
+            al[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0) - eps;
+            ab[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1) - eps;
+            ar[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2) + eps;
+            at[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3) + eps;
+        }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                res0[i * 64 + lane] = -1.0;
-                res1[i * 64 + lane] = -1.0;
+        for (int k = 0; k < NB0; ++k) {
+            res0[k * 64 + lane] = -1.0;
+            res1[k * 64 + lane] = -1.0;
+            if (k < b_count && !SSG_ABL(1)) { // wave-uniform
+                const int i = b_first + k;
                 // Beam i points along heading + phi_i, phi_i = rad(90 - spread/2) + i*rad(spread/n_beams)
                 // (models.py:48-49,62-64); endpoint via the angle-addition identity (beam_end): agrees with the
                 // reference's per-beam cos/sin to ~1e-13 and only feeds lidar readings, never the dynamics.
@@ -399,50 +415,44 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
                     const unsigned long long m = __ballot(need);
                     const int pos = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                                               __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (i << 6) | (s << 10));
+                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (k << 6) | (s << 10));
                     n_items += __popcll(m);
                 }
             }
-            SSG_STAMP(3);
-            if (!SSG_ABL(3))
-                lidar_pass<NB, LDS_BANK, EXACT>(c, n_items, queue, res0, res1, beamtab, cx, cy, ca0, sa0, rec_off, lane);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) { res0[i * 64 + lane] = -1.0; res1[i * 64 + lane] = -1.0; }
         }
+        SSG_STAMP(3);
+        if (!SSG_ABL(3))
+            lidar_pass<LDS_BANK, EXACT>(c, n_items, queue, res0, res1, beamtab + b_first, cx, cy, ca0, sa0, rec_off, lane);
         SSG_STAMP(4);
-        __syncthreads(); // barrier 2: lidar results and the exchange block are complete
+        __syncthreads(); // barrier 2: results complete
         SSG_STAMP(5);
         SSG_STAMP_FLUSH(6);
         return;
     }
 
     // =========================================================================================================
-    // ROLE B: post-step half — integrator, ship transform, narrowphase, reward/done, observation, write-back
+    // ROLES 2 / 3 share the post-step pose: cpSpaceStep (1) cpBodyUpdatePosition, (2) cpPolyShapeCacheData
     // =========================================================================================================
     double x = colX[el], y = colY[el], vx = colVX[el], vy = colVY[el], ang = colA[el], w = colW[el];
-    double cum = colCum[el];
-    double lid[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) lid[i] = colLid[(size_t)i * np + el];
-    int rudder = colRud[el], steps = colStep[el], map_id = colMap[el];
     unsigned gm = c.mask[el];
-    const int act = actions[el];
-    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<2 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
-
-    const int F = 6 + NB;
-    const bool hist2 = c.history >= 2;
+    int map_id = colMap[el];
+    // role 3 only
+    double cum = 0.0;
+    double lid[NB];
+    int rudder = 0, steps = 0, act = 3;
+    if (role == 3) {
+        cum = colCum[el];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) lid[i] = colLid[(size_t)i * np + el];
+        rudder = colRud[el];
+        steps = colStep[el];
+        act = actions[el];
+    }
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
     const int rec_off = map_id * SSG_MAP_STRIDE;
     const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang; // previous frame = pre-step state
+    const unsigned gm0 = gm;
 
-    if (act == 1 || act == 2) {
-        // Ship.rotate(-5 / +5) + clamp_rudder (models.py:136-146)
-        rudder += (act == 1) ? -c.rudder_step : c.rudder_step;
-        rudder = max(-c.rudder_max, min(c.rudder_max, rudder));
-        gm |= 0x80u;
-    }
-
-    // ---- cpSpaceStep (1): cpBodyUpdatePosition ----
     x = x + vx * c.dt;
     y = y + vy * c.dt;
     ang = ang + w * c.dt;
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
     __syncthreads();                             // barrier 1: bank + tables visible
     SSG_STAMP(2);
 
-    // ---- cpSpaceStep (2): cpPolyShapeCacheData for the ship: world AABB (the planes are rebuilt by the workers) ----
+    // world AABB of the ship (the planes are rebuilt by the cooperative workers)
     double sbl = INFINITY, sbr = -INFINITY, sbb = INFINITY, sbt = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
@@ -463,8 +473,6 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
         sbl = dmin(sbl, wx); sbr = dmax(sbr, wx);
         sbb = dmin(sbb, wy); sbt = dmax(sbt, wy);
     }
-    const bool oob_x = (x < 0.0) | (x > c.width);
-    const bool oob_y = (y < 0.0) | (y > c.height);
 
     // ---- narrowphase, wave-cooperative ----------------------------------------------------------------------
     // Per lane only the cheap cpBBIntersects rejects run.  The few lanes that pass are then served one at a time
@@ -475,72 +483,15 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
-    const double w_px = shiptab[4 * 8 + wi], w_py = shiptab[5 * 8 + wi]; // vertex i-1 (edge start)
 
-    // player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed convex sets
-    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
-    // has every vertex of the other polygon strictly in front.
-    bool colliding = false;
-    {
-        unsigned nearbits = 0;
-        int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
-            const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
-            const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
-            const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
-            const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
-            nearbits |= near ? (1u << s) : 0u;
-            cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
-        }
-        unsigned long long todo = __ballot(nearbits != 0u);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
-            const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
-            const int boff = __builtin_amdgcn_readlane(rec_off, src);
-            const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
-            const int bcnts = __builtin_amdgcn_readlane(cnts, src);
-            const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
-            const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
-            const double off_i = snx_ * svx + sny_ * svy;
-            bool col = false;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (!(bnear & (1u << s))) continue; // wave-uniform
-                const int cnt = (bcnts >> (8 * s)) & 0xFF;
-                const bool valid = (lane < 60) & (wq < cnt);
-                const int q = boff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) +
-                              SSG_PLANE_DOUBLES * (valid ? wq : 0);
-                const double v0x = bank_at<LDS_BANK>(c, q + 0), v0y = bank_at<LDS_BANK>(c, q + 1);
-                const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
-                const double v0n = bank_at<LDS_BANK>(c, q + 4);
-                const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
-                const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
-                const unsigned long long mV = __ballot(valid);
-                const unsigned long long mA = __ballot(valid & frontA);
-                const unsigned long long missB = mV & ~__ballot(valid & frontB);
-                const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
-                // axis = bank plane q: all five (q,i) bits set
-                const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
-                // axis = ship plane i: no valid (q,i) bit missing
-                bool sepB = false;
-#pragma unroll
-                for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB | (((missB >> i) & P) == 0ull);
-                const bool separated = (allA != 0ull) | sepB;
-                col = col | !separated;
-            }
-            colliding = (lane == src) ? col : colliding;
-        }
-    }
-    SSG_STAMP(3);
-
-    // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
-    // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
-    bool goal_reached = false;
-    {
+    if (role == 2) {
+        // =====================================================================================================
+        // ROLE 2: player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery
+        //         distance of the centre to the ship hull <= radius (negative inside), after the cpBBIntersects
+        //         reject; then closest_goal over what remains (ship_env.py:102-108).
+        // =====================================================================================================
+        const double w_px = shiptab[4 * 8 + wi], w_py = shiptab[5 * 8 + wi]; // vertex i-1 (edge start)
+        bool goal_reached = false;
         unsigned nearmask = 0;
         for (int g = 0; g < c.n_goals; ++g) {
             const double gx = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g);
@@ -593,12 +544,117 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
                 gm &= ~gotmask;
             }
         }
+        SSG_STAMP(3);
+        // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position
+        double nf_gx = 0, nf_gy = 0;
+        if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm, x, y, nf_gx, nf_gy);
+        xchg[3 * EPW + tl] = nf_gx;
+        xchg[4 * EPW + tl] = nf_gy;
+        gres[tl] = (gm & 0x7Fu) | (goal_reached ? 0x80000000u : 0u);
+        SSG_STAMP(4);
+        __syncthreads(); // barrier 2
+        SSG_STAMP(5);
+        SSG_STAMP_FLUSH(6);
+        return;
     }
-    SSG_STAMP(4);
 
-    // ---- __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position ----
-    double nf_gx = 0, nf_gy = 0;
-    if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm, x, y, nf_gx, nf_gy);
+    // =========================================================================================================
+    // ROLE 3: bank narrowphase before the barrier; everything that closes the step after it
+    // =========================================================================================================
+    const int F = 6 + NB;
+    const bool hist2 = c.history >= 2;
+    if (act == 1 || act == 2) {
+        // Ship.rotate(-5 / +5) + clamp_rudder (models.py:136-146)
+        rudder += (act == 1) ? -c.rudder_step : c.rudder_step;
+        rudder = max(-c.rudder_max, min(c.rudder_max, rudder));
+        gm |= 0x80u;
+    }
+    const bool oob_x = (x < 0.0) | (x > c.width);
+    const bool oob_y = (y < 0.0) | (y > c.height);
+
+    // player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed convex sets
+    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
+    // has every vertex of the other polygon strictly in front.
+    bool colliding = false;
+    {
+        unsigned nearbits = 0;
+        int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+            const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
+            const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+            const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
+            const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
+            nearbits |= near ? (1u << s) : 0u;
+            cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
+        }
+        unsigned long long todo = __ballot(nearbits != 0u);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
+            const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
+            const int boff = __builtin_amdgcn_readlane(rec_off, src);
+            const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
+            const int bcnts = __builtin_amdgcn_readlane(cnts, src);
+            const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
+            const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
+            const double off_i = snx_ * svx + sny_ * svy;
+            bool col = false;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (!(bnear & (1u << s))) continue; // wave-uniform
+                const int cnt = (bcnts >> (8 * s)) & 0xFF;
+                const bool valid = (lane < 60) & (wq < cnt);
+                const int q = boff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) +
+                              SSG_PLANE_DOUBLES * ((wq < SSG_MAX_HULL) ? wq : 0);
+                const double v0x = bank_at<LDS_BANK>(c, q + 0), v0y = bank_at<LDS_BANK>(c, q + 1);
+                const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+                const double v0n = bank_at<LDS_BANK>(c, q + 4);
+                const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
+                const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
+                const unsigned long long mV = __ballot(valid);
+                const unsigned long long mA = __ballot(valid & frontA);
+                const unsigned long long missB = mV & ~__ballot(valid & frontB);
+                const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
+                // axis = bank plane q: all five (q,i) bits set
+                const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
+                // axis = ship plane i: no valid (q,i) bit missing
+                bool sepB = false;
+#pragma unroll
+                for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB | (((missB >> i) & P) == 0ull);
+                const bool separated = (allA != 0ull) | sepB;
+                col = col | !separated;
+            }
+            colliding = (lane == src) ? col : colliding;
+        }
+    }
+    SSG_STAMP(3);
+
+    // previous frame's nearest goal (oldest slot of the 2-frame history): a function of the pre-step state
+    double pf_gx = 0, pf_gy = 0;
+    if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm0, pf_x, pf_y, pf_gx, pf_gy);
+
+    SSG_STAMP(4);
+    __syncthreads(); // barrier 2: lidar results, force/torque and the goal results are complete
+    SSG_STAMP(5);
+
+    // ---- collide_goal results (role 2) ----
+    const unsigned gr = gres[tl];
+    const bool goal_reached = (gr >> 31) != 0u;
+    gm = (gm & 0x80u) | (gr & 0x7Fu);
+    const double nf_gx = xchg[3 * EPW + tl], nf_gy = xchg[4 * EPW + tl];
+
+    // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role 0 accumulated; forces are
+    //      cleared afterwards.  (The narrowphase reads positions only, so doing this last changes nothing.) ----
+    {
+        const double fx = xchg[0 * EPW + tl], fy = xchg[1 * EPW + tl], tq = xchg[2 * EPW + tl];
+        vx = vx * c.damp + (fx * c.m_inv) * c.dt;
+        vy = vy * c.damp + (fy * c.m_inv) * c.dt;
+        w = w * c.damp + tq * c.i_inv * c.dt;
+        // (4) impulse solver: its output cannot reach an observation before the env is reset (DESIGN.md §2).
+    }
 
     // ---- determine_reward (ship_env.py:62-77) ----
     double rew = goal_reached ? 1.0 : ((oob_x | oob_y) ? -1.0 : -0.01);
@@ -625,39 +681,24 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
         if (goal_reached) atomicAdd(slot + 3, 1ull);
     }
 
-    SSG_STAMP(5);
-    __syncthreads(); // barrier 2: role A's lidar results and exchange block are complete
-    SSG_STAMP(6);
-
-    // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role A accumulated; forces are
-    //      cleared afterwards.  (The narrowphase reads positions only, so doing this last changes nothing.) ----
-    {
-        const double fx = xchg[0 * EPW + tl], fy = xchg[1 * EPW + tl], tq = xchg[2 * EPW + tl];
-        vx = vx * c.damp + (fx * c.m_inv) * c.dt;
-        vy = vy * c.damp + (fy * c.m_inv) * c.dt;
-        w = w * c.damp + tq * c.i_inv * c.dt;
-        // (4) impulse solver: its output cannot reach an observation before the env is reset (DESIGN.md §2).
-    }
-    const double pf_gx = xchg[3 * EPW + tl], pf_gy = xchg[4 * EPW + tl];
-
     // observation values: the stepped frames, or (VecEnv auto-reset) ShipGame.reset + ShipEnv.reset onto the next
     // bank record: history of -1 then the spawn frame.
     double o_old[6 + NB], o_new[6 + NB];
     o_old[0] = pf_x; o_old[1] = pf_y; o_old[2] = pf_rud; o_old[3] = pf_a; o_old[4] = pf_gx; o_old[5] = pf_gy;
     o_new[0] = x; o_new[1] = y; o_new[2] = (double)rudder; o_new[3] = ang; o_new[4] = nf_gx; o_new[5] = nf_gy;
-    {
-        const char *ascr = scratch0 + ((threadIdx.x - EPW) >> 6) * lds_wave_scratch_bytes(NB); // the A wave of these envs
-        const double *res0 = reinterpret_cast<const double *>(ascr);
-        const double *res1 = res0 + NB * 64;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            // first shape in list order that reports a hit wins (models.py:61-72): the left bank before the right
-            const double r0 = res0[i * 64 + lane], r1 = res1[i * 64 + lane];
-            const double nl = (r0 >= 0.0) ? r0 : r1;
-            o_old[6 + i] = lid[i];                      // readings before this step's query
-            lid[i] = (nl >= 0.0) ? nl : lid[i];         // a miss keeps the previous reading (sticky, App. B-3)
-            o_new[6 + i] = lid[i];
-        }
+    for (int i = 0; i < NB; ++i) {
+        // results of the lidar wave that served these 64 envs: role 0 holds beams [0,NB0), role 1 the rest
+        const int lr = (i < NB0) ? 0 : 1, k = i - lr * NB0;
+        const char *ascr = scratch0 + (lr * (EPW / 64) + (tl >> 6)) * lds_wave_scratch_bytes(NB0);
+        const double *res0 = reinterpret_cast<const double *>(ascr);
+        const double *res1 = res0 + NB0 * 64;
+        // first shape in list order that reports a hit wins (models.py:61-72): the left bank before the right
+        const double r0 = res0[k * 64 + lane], r1 = res1[k * 64 + lane];
+        const double nl = (r0 >= 0.0) ? r0 : r1;
+        o_old[6 + i] = lid[i];                      // readings before this step's query
+        lid[i] = (nl >= 0.0) ? nl : lid[i];         // a miss keeps the previous reading (sticky, App. B-3)
+        o_new[6 + i] = lid[i];
     }
     if (do_reset) {
         map_id = map_id + 1;
@@ -673,8 +714,8 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
         o_new[4] = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
         o_new[5] = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
     }
-    SSG_STAMP(7);
-    SSG_STAMP_FLUSH(8);
+    SSG_STAMP(6);
+    SSG_STAMP_FLUSH(7);
     if (!live) return; // every cooperative section is behind us: lanes past n_envs store nothing
     double *__restrict__ orow = obs + (size_t)e * (size_t)(F * c.history);
     if (!SSG_ABL(7)) {
@@ -697,7 +738,7 @@ __global__ __launch_bounds__(2 * EPW) void step_kernel(const DevCfg c, const int
         unsigned ev = 0;
         if (colliding) ev |= SSG_EV_COLLIDING;
         if (goal_reached) ev |= SSG_EV_GOAL_REACHED;
-        if (oob_x || oob_y) ev |= SSG_EV_OUT_OF_BOUNDS;
+        if (oob_x | oob_y) ev |= SSG_EV_OUT_OF_BOUNDS;
         if (steps_after >= c.max_steps) ev |= SSG_EV_MAX_STEPS;
         if (alive == 0u) ev |= SSG_EV_NO_GOALS_LEFT;
         flags_out[e] = (uint8_t)ev;
@@ -780,7 +821,7 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// launchers (called from shipsim_api.cpp).  `epw` = envs per workgroup; the workgroup has 2*epw threads.
+// launchers (called from shipsim_api.cpp).  `epw` = envs per workgroup; the workgroup has 4*epw threads.
 // ---------------------------------------------------------------------------------------------------------
 using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *);
 
@@ -823,7 +864,7 @@ size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
 {
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
     b += (size_t)lds_fixed_bytes(epw);
-    b += (size_t)(epw / 64) * (size_t)lds_wave_scratch_bytes(n_beams);
+    b += (size_t)(2 * (epw / 64)) * (size_t)lds_wave_scratch_bytes(nb_lo(n_beams));
     return b;
 }
 
@@ -842,7 +883,7 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
     step_fn_t k = step_fn(c.n_beams, epw, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
     const int grid = (c.n_envs + epw - 1) / epw;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(2 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags);
     return hipGetLastError();
 }
 
