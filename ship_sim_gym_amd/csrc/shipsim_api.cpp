@@ -509,8 +509,16 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         return fail(h, SSG_ERR_BAD_ARG, "ssg_step/ssg_rollout: NULL buffer or K < 1");
     rc = prepare(h);
     if (rc != SSG_OK) return rc;
-    for (int k = 0; k < K; ++k) {
-        hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs,
+    // One launch runs up to kFuse consecutive steps (state in registers, bank staged once); SSG_FUSE=1 in the
+    // environment forces one launch per step (the path a policy-in-the-loop caller gets through ssg_step).
+    static const int kFuse = [] {
+        const char *s = std::getenv("SSG_FUSE");
+        const int v = s ? std::atoi(s) : 1 << 20;
+        return v < 1 ? 1 : v;
+    }();
+    for (int k = 0; k < K; k += kFuse) {
+        const int kk = (K - k < kFuse) ? (K - k) : kFuse;
+        hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,
                                         dev_obs, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
     }

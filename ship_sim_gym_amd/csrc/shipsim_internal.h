@@ -40,7 +40,7 @@ struct DevCfg {
     unsigned long long *dbg; // diagnostic builds only (-DSSG_STAMPS): per-wave s_memtime stamps
 };
 
-hipError_t launch_step(const DevCfg &c, int block, bool lds, size_t lds_bytes, const int32_t *actions, double *obs,
+hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions_kn, int K, double *obs,
                        double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream);
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);

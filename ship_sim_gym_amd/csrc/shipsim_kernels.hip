@@ -54,6 +54,27 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) // src_la
     return __hiloint2double(hi, lo);
 }
 
+// State loads.  In the fused multi-step loop the columns were rewritten by another wave of this workgroup one
+// barrier ago: `fresh` (wave-uniform) selects agent-scope relaxed atomic loads (global_load ... sc1), which are served
+// by the L2 instead of this CU's possibly stale vector L1.
+__device__ __forceinline__ double ld_f64(const double *p, bool fresh)
+{
+    if (fresh)
+        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+__device__ __forceinline__ int ld_i32(const int32_t *p, bool fresh)
+{
+    if (fresh) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+__device__ __forceinline__ unsigned ld_u8(const uint8_t *p, bool fresh)
+{
+    if (fresh) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 // Bank record element i (absolute index in doubles): LDS-staged bank or L2/HBM gather.
 template <bool LDS_BANK>
 __device__ __forceinline__ double bank_at(const DevCfg &c, int i)
@@ -117,8 +138,9 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 // LDS layout of the step kernel (doubles unless noted), after the optional bank copy:
 //   beamtab  [2][16]      cos/sin(phi_i)
 //   shiptab  [6][8]       per ship vertex i: local vertex, local plane normal, previous vertex
-//   xchg     [5][EPW]     -> role 3: force x, force y, torque (role 0); new-frame nearest goal x, y (role 2)
-//   gres     [EPW] u32    -> role 3: goal mask after collide_goal | goal_reached << 31 (role 2)
+//   xchg     [3][EPW]     -> role 3: force x, force y, torque (role 0)
+//   gres     [EPW] u32    -> role 3: colliding flag (role 2)
+//   goal scratch per role-3 wave: (lane, goal) pair queue u16[512] + consumed-goal masks u32[64]
 //   scratch  per lidar wave (roles 0,1): res0[NBH][64], res1[NBH][64], queue[2*NBH*64 + 64 trash] u16, NBH = ceil(NB/2)
 // ---------------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ constexpr int lds_wave_scratch_bytes(int nb)
@@ -127,7 +149,11 @@ __host__ __device__ __forceinline__ constexpr int lds_wave_scratch_bytes(int nb)
 }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-__host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw) { return kBeamTabBytes + kShipTabBytes + 5 * epw * 8 + epw * 4; }
+constexpr int kGoalScratchBytes = 64 * 8 * 2 + 64 * 4; // per goals wave: pair queue (u16) + per-lane consumed-goal masks
+__host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
+{
+    return kBeamTabBytes + kShipTabBytes + 3 * epw * 8 + epw * 4 + (epw / 64) * kGoalScratchBytes;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // LiDAR (models.py:39-76), wave-compacted.
@@ -147,7 +173,7 @@ __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw) { ret
 // Results travel back through two per-wave LDS arrays res0/res1[beam][lane] (-1 = no hit), one per hull; the reader
 // then applies "the first shape in list order that reports a hit wins" (models.py:61-72): left bank first.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kPlaneChunk = 6; // hull planes fetched from LDS ahead of their arithmetic, per loop trip
+constexpr int kPlaneChunk = 4; // hull planes fetched from LDS ahead of their arithmetic, per loop trip
 
 template <bool LDS_BANK, bool EXACT>
 __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue, double *res0,
@@ -266,9 +292,10 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
 // The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
 //   role 0  LIDAR-lo : body rotation on the pre-step pose, handle_discrete_action's force/torque, beams [0, NB0)
 //   role 1  LIDAR-hi : body rotation on the pre-step pose, beams [NB0, NB)
-//   role 2  GOALS    : integrator + ship transform, goal-circle narrowphase, nearest remaining goal
-//   role 3  BODY     : integrator + ship transform, bank narrowphase, then (after the workgroup barrier) velocity
-//                      update, reward/done, statistics, sticky-lidar merge, observation and state write-back
+//   role 2  BANKS    : integrator + ship transform, bank-hull narrowphase (collide_ship)
+//   role 3  BODY     : integrator + ship transform, goal-circle narrowphase, nearest goals, then (after the workgroup
+//                      barrier) velocity update, reward/done, statistics, sticky-lidar merge, observation and state
+//                      write-back; its registers carry the body state from step to step in a fused rollout
 // Roles 0-2 hand their results to role 3 through LDS.  A lone wave on a SIMD issues FP64 at half rate and runs
 // latency-bound; 65 536 envs are only one wave per SIMD, so each env's step is cut into four shorter instruction
 // streams that run as four co-resident waves per SIMD.
@@ -281,16 +308,20 @@ struct PostPose {
 };
 
 template <int NB, int EPW, bool LDS_BANK, bool EXACT>
-__global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
-                                                       uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out)
+                                                       uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out,
+                                                       const int K)
 {
+    // K consecutive steps in one launch (K = 1 for ssg_step): the bank is staged once, role 3 keeps the body state in
+    // registers, and the other roles re-read the few columns they need from the L2 after role 3 has stored them.
+    // Step k reads actions_kn + k*n_envs; obs / reward / done / flags are rewritten by every step.
     constexpr int NB0 = nb_lo(NB);
     const int role = threadIdx.x / EPW;                        // wave-uniform (EPW is a multiple of 64)
     const int tl = threadIdx.x - role * EPW;                   // env slot inside the workgroup
     const int e = blockIdx.x * EPW + tl;
     const bool live = e < c.n_envs;
-    const int el = live ? e : 0; // lanes past n_envs stay active as workers; they carry env 0 and store nothing
+    const int el_ = live ? e : 0; // lanes past n_envs stay active as workers; they carry env 0 and store nothing
     const size_t np = (size_t)c.n_pad;
     const int lane = threadIdx.x & 63;
 
@@ -310,8 +341,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *xchg = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [5][EPW]
-    unsigned *gres = reinterpret_cast<unsigned *>(xchg + 5 * EPW);                         // [EPW]
+    double *xchg = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [3][EPW]
+    unsigned *gres = reinterpret_cast<unsigned *>(xchg + 3 * EPW);                         // [EPW]
+    char *goal_scratch0 = reinterpret_cast<char *>(gres + EPW);
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
 
 #ifdef SSG_STAMPS
@@ -335,12 +367,23 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step);
         //              role 0 also evaluates handle_discrete_action's force and torque.
         // =====================================================================================================
-        const double x = colX[el], y = colY[el], ang = colA[el];
-        const int map_id = colMap[el];
+        if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+        for (int k = 0; k < K; ++k) {
+        const bool fresh = k > 0;
+        // Launder the env index once per step: the per-lane column addresses are loop-invariant, and hoisted out of
+        // the loop they cost ~70 VGPRs of live 64-bit pointers (spilled to scratch at the 128-VGPR budget of a
+        // 1024-thread workgroup); recomputing an address is one v_lshl_add_u64.
+        int el = el_;
+        asm volatile("" : "+v"(el));
+        const double x = ld_f64(colX + el, fresh), y = ld_f64(colY + el, fresh), ang = ld_f64(colA + el, fresh);
+        const int map_id = ld_i32(colMap + el, fresh);
         int rudder = 0, act = 3;
         unsigned gm = 0;
-        if (role == 0) { rudder = colRud[el]; gm = c.mask[el]; act = actions[el]; }
-        if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+        if (role == 0) {
+            rudder = ld_i32(colRud + el, fresh);
+            gm = ld_u8(c.mask + el, fresh);
+            act = actions_kn[(size_t)k * c.n_envs + el];
+        }
         const int rec_off = map_id * SSG_MAP_STRIDE;
 
         double sa0, ca0;
@@ -359,8 +402,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             xchg[2 * EPW + tl] = thrust ? (rx * fwy - ry * fwx) : 0.0;
         }
         SSG_STAMP(1);
-        if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-        __syncthreads();                             // barrier 1: bank + tables visible
+        if (k == 0) {
+            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+            __syncthreads();                             // barrier 1: bank + tables visible
+        }
         SSG_STAMP(2);
 
         // lidar origin: pos + half the world AABB extents (models.py:51-53)
@@ -378,7 +423,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             cy = y + (bt - bb) / 2;
         }
 
-        const int lw = role * (EPW / 64) + (tl >> 6); // lidar-wave index inside the workgroup
+        const int lw = 2 * (tl >> 6) + role; // scratch slot: the two lidar waves of an env tile are neighbours
         char *wscr = scratch0 + lw * lds_wave_scratch_bytes(NB0);
         double *res0 = reinterpret_cast<double *>(wscr);
         double *res1 = res0 + NB0 * 64;
@@ -426,6 +471,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         SSG_STAMP(4);
         __syncthreads(); // barrier 2: results complete
         SSG_STAMP(5);
+        if (k + 1 < K) __syncthreads(); // barrier 3: role 3 has stored the next step's state
+        } // k
         SSG_STAMP_FLUSH(6);
         return;
     }
@@ -433,22 +480,39 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // =========================================================================================================
     // ROLES 2 / 3 share the post-step pose: cpSpaceStep (1) cpBodyUpdatePosition, (2) cpPolyShapeCacheData
     // =========================================================================================================
-    double x = colX[el], y = colY[el], vx = colVX[el], vy = colVY[el], ang = colA[el], w = colW[el];
-    unsigned gm = c.mask[el];
-    int map_id = colMap[el];
-    // role 3 only
-    double cum = 0.0;
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+    // role 3's registers carry the whole body state from step to step; role 2 re-reads what it needs
+    double x = 0, y = 0, vx = 0, vy = 0, ang = 0, w = 0, cum = 0;
     double lid[NB];
-    int rudder = 0, steps = 0, act = 3;
+    unsigned gm = 0;
+    int map_id = 0, rudder = 0, steps = 0;
     if (role == 3) {
+        const int el = el_;
+        x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el];
+        gm = c.mask[el];
+        map_id = colMap[el];
         cum = colCum[el];
 #pragma unroll
         for (int i = 0; i < NB; ++i) lid[i] = colLid[(size_t)i * np + el];
         rudder = colRud[el];
         steps = colStep[el];
-        act = actions[el];
     }
-    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+    const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
+
+    for (int k = 0; k < K; ++k) {
+    const bool fresh = k > 0;
+    int el = el_; // laundered once per step (see the lidar roles): keeps column addresses out of long-lived registers
+    asm volatile("" : "+v"(el));
+    int act = 3;
+    if (role == 2) {
+        x = ld_f64(colX + el, fresh); y = ld_f64(colY + el, fresh);
+        vx = ld_f64(colVX + el, fresh); vy = ld_f64(colVY + el, fresh);
+        ang = ld_f64(colA + el, fresh); w = ld_f64(colW + el, fresh);
+        gm = ld_u8(c.mask + el, fresh);
+        map_id = ld_i32(colMap + el, fresh);
+    } else {
+        act = actions_kn[(size_t)k * c.n_envs + el];
+    }
     const int rec_off = map_id * SSG_MAP_STRIDE;
     const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang; // previous frame = pre-step state
     const unsigned gm0 = gm;
@@ -460,18 +524,22 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     sincos(ang, &sa, &ca);
 
     SSG_STAMP(1);
-    if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-    __syncthreads();                             // barrier 1: bank + tables visible
+    if (k == 0) {
+        if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+        __syncthreads();                             // barrier 1: bank + tables visible
+    }
     SSG_STAMP(2);
 
-    // world AABB of the ship (the planes are rebuilt by the cooperative workers)
+    // cpPolyShapeCacheData: world vertices and AABB of the ship
+    double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
     double sbl = INFINITY, sbr = -INFINITY, sbb = INFINITY, sbt = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
         const double hx = shiptab[0 * 8 + i], hy = shiptab[1 * 8 + i];
-        const double wx = ca * hx + (-sa) * hy + x, wy = sa * hx + ca * hy + y;
-        sbl = dmin(sbl, wx); sbr = dmax(sbr, wx);
-        sbb = dmin(sbb, wy); sbt = dmax(sbt, wy);
+        swx[i] = ca * hx + (-sa) * hy + x;
+        swy[i] = sa * hx + ca * hy + y;
+        sbl = dmin(sbl, swx[i]); sbr = dmax(sbr, swx[i]);
+        sbb = dmin(sbb, swy[i]); sbt = dmax(sbt, swy[i]);
     }
 
     // ---- narrowphase, wave-cooperative ----------------------------------------------------------------------
@@ -480,86 +548,104 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // env, whose pose is broadcast with v_readlane.  The arithmetic of every product and sum is exactly the
     // per-env formulation's (cpPolyShapeCacheData, SAT dot products, cpPolyShapePointQuery); only the min/any
     // reductions over vertices and planes are done with ballots instead of sequential loops.
-    const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
 
     if (role == 2) {
         // =====================================================================================================
-        // ROLE 2: player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery
-        //         distance of the centre to the ship hull <= radius (negative inside), after the cpBBIntersects
-        //         reject; then closest_goal over what remains (ship_env.py:102-108).
+        // ROLE 2: player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed
+        //         convex sets intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals:
+        //         separated iff some axis has every vertex of the other polygon strictly in front.
         // =====================================================================================================
-        const double w_px = shiptab[4 * 8 + wi], w_py = shiptab[5 * 8 + wi]; // vertex i-1 (edge start)
-        bool goal_reached = false;
-        unsigned nearmask = 0;
-        for (int g = 0; g < c.n_goals; ++g) {
-            const double gx = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g);
-            const double gy = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g + 1);
-            const double r = c.goal_r;
-            const bool near = live & !SSG_ABL(5) & (bool)((gm >> g) & 1u) & ((gx - r) <= sbr) & (sbl <= (gx + r)) &
-                              ((gy - r) <= sbt) & (sbb <= (gy + r));
-            nearmask |= near ? (1u << g) : 0u;
-        }
-        unsigned long long todo = __ballot(nearmask != 0u);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
-            const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
-            const int boff = __builtin_amdgcn_readlane(rec_off, src);
-            const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearmask, src);
-            // lane (q = goal, i = ship edge from vertex i-1 to vertex i)
-            const bool valid = (wq < SSG_MAX_GOALS - 1) & (bool)((bnear >> (wq & 31)) & 1u);
-            const int gq = valid ? wq : 0;
-            const double gx = bank_at<LDS_BANK>(c, boff + SSG_MAP_OFF_GOALS + 2 * gq);
-            const double gy = bank_at<LDS_BANK>(c, boff + SSG_MAP_OFF_GOALS + 2 * gq + 1);
-            const double v1x = bca * w_hx + (-bsa) * w_hy + bx, v1y = bsa * w_hx + bca * w_hy + by;
-            const double v0x = bca * w_px + (-bsa) * w_py + bx, v0y = bsa * w_px + bca * w_py + by;
-            const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
-            const bool out_i = (snx_ * (gx - v1x) + sny_ * (gy - v1y)) > 0.0;
-            // cpClosetPointOnSegment(p, v0, v1)
-            const double dx = v0x - v1x, dy = v0y - v1y;
-            const double tt = dmax(0.0, dmin((dx * (gx - v1x) + dy * (gy - v1y)) / (dx * dx + dy * dy), 1.0));
-            const double qx = v1x + dx * tt, qy = v1y + dy * tt;
-            const double ex_ = gx - qx, ey_ = gy - qy;
-            const double dist = sqrt(ex_ * ex_ + ey_ * ey_);
-            // min over the five edges of this goal (lanes 5q .. 5q+4), any(outside) over the same five lanes
-            double md = dist;
+        bool colliding = false;
+        {
+            unsigned nearbits = 0;
+            int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
 #pragma unroll
-            for (int k = 1; k < SSG_SHIP_VERTS; ++k) {
-                int o = wi + k;
-                o = (o >= SSG_SHIP_VERTS) ? o - SSG_SHIP_VERTS : o;
-                md = dmin(md, __shfl(dist, 5 * wq + o));
+            for (int s = 0; s < 2; ++s) {
+                const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+                const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
+                const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+                const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
+                const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
+                nearbits |= near ? (1u << s) : 0u;
+                cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
             }
-            const unsigned long long mo = __ballot(valid & out_i);
-            const bool outside = ((mo >> (5 * wq)) & 31ull) != 0ull;
-            const double sd = outside ? md : -md;
-            const unsigned long long got = __ballot(valid & (wi == 0) & (sd <= c.goal_r)); // bit 5q = goal q consumed
-            unsigned gotmask = 0;
+            // Stage 1, per lane, all near lanes at once: is some BANK plane a separating axis (all five ship vertices
+            // strictly in front)?  That settles almost every ship that is merely close to a bank; the loop ends as soon
+            // as every near lane of the wave has found its plane.
 #pragma unroll
-            for (int g = 0; g < SSG_MAX_GOALS - 1; ++g) gotmask |= ((got >> (5 * g)) & 1ull) ? (1u << g) : 0u;
-            if (lane == src) {
-                goal_reached = gotmask != 0u;
-                gm &= ~gotmask;
+            for (int s = 0; s < 2; ++s) {
+                const bool near_s = (nearbits >> s) & 1u;
+                if (!__any(near_s)) continue;
+                const int cnt = (cnts >> (8 * s)) & 0xFF;
+                bool sep = false;
+                for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
+                    const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
+                    const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+                    const double v0n = bank_at<LDS_BANK>(c, q + 4);
+                    bool allfront = j < cnt;
+#pragma unroll
+                    for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
+                    sep = sep | allfront;
+                }
+                nearbits = sep ? (nearbits & ~(1u << s)) : nearbits;
+            }
+            // Stage 2, wave-cooperative, for the few lanes still unresolved (mostly real collisions): the full SAT over
+            // both polygons' edge normals, lane L = 5*q + i on (bank plane q, ship vertex i) of the served env.
+            unsigned long long todo = __ballot(nearbits != 0u);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
+                const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
+                const int boff = __builtin_amdgcn_readlane(rec_off, src);
+                const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
+                const int bcnts = __builtin_amdgcn_readlane(cnts, src);
+                const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
+                const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
+                const double off_i = snx_ * svx + sny_ * svy;
+                bool col = false;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (!(bnear & (1u << s))) continue; // wave-uniform
+                    const int cnt = (bcnts >> (8 * s)) & 0xFF;
+                    const bool valid = (lane < 60) & (wq < cnt);
+                    const int q = boff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) +
+                                  SSG_PLANE_DOUBLES * ((wq < SSG_MAX_HULL) ? wq : 0);
+                    const double v0x = bank_at<LDS_BANK>(c, q + 0), v0y = bank_at<LDS_BANK>(c, q + 1);
+                    const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+                    const double v0n = bank_at<LDS_BANK>(c, q + 4);
+                    const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
+                    const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
+                    const unsigned long long mV = __ballot(valid);
+                    const unsigned long long mA = __ballot(valid & frontA);
+                    const unsigned long long missB = mV & ~__ballot(valid & frontB);
+                    const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
+                    // axis = bank plane q: all five (q,i) bits set
+                    const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
+                    // axis = ship plane i: no valid (q,i) bit missing
+                    bool sepB = false;
+#pragma unroll
+                    for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB | (((missB >> i) & P) == 0ull);
+                    const bool separated = (allA != 0ull) | sepB;
+                    col = col | !separated;
+                }
+                colliding = (lane == src) ? col : colliding;
             }
         }
+
         SSG_STAMP(3);
-        // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position
-        double nf_gx = 0, nf_gy = 0;
-        if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm, x, y, nf_gx, nf_gy);
-        xchg[3 * EPW + tl] = nf_gx;
-        xchg[4 * EPW + tl] = nf_gy;
-        gres[tl] = (gm & 0x7Fu) | (goal_reached ? 0x80000000u : 0u);
+        gres[tl] = colliding ? 1u : 0u;
         SSG_STAMP(4);
         __syncthreads(); // barrier 2
         SSG_STAMP(5);
-        SSG_STAMP_FLUSH(6);
-        return;
+        if (k + 1 < K) __syncthreads(); // barrier 3: role 3 has stored the next step's state
+        continue;
     }
 
     // =========================================================================================================
-    // ROLE 3: bank narrowphase before the barrier; everything that closes the step after it
+    // ROLE 3: goal narrowphase and nearest goals before the barrier; everything that closes the step after it
     // =========================================================================================================
     const int F = 6 + NB;
     const bool hist2 = c.history >= 2;
@@ -572,64 +658,68 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
 
-    // player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed convex sets
-    // intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
-    // has every vertex of the other polygon strictly in front.
-    bool colliding = false;
+    // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
+    // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
+    bool goal_reached;
     {
-        unsigned nearbits = 0;
-        int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
-            const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
-            const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
-            const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
-            const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
-            nearbits |= near ? (1u << s) : 0u;
-            cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
+        const double w_px = shiptab[4 * 8 + wi], w_py = shiptab[5 * 8 + wi]; // vertex i-1 (edge start)
+        // Every (lane, goal) pair that passes the bounding-box reject goes into a per-wave LDS queue; the wave then
+        // serves 12 pairs at a time, lane L = 5*p + i on (pair p, ship edge i).
+        unsigned short *gq = reinterpret_cast<unsigned short *>(goal_scratch0 + (tl >> 6) * kGoalScratchBytes);
+        unsigned *gw = reinterpret_cast<unsigned *>(gq + 64 * 8);
+        gw[lane] = 0u;
+        int n_pairs = 0;
+        for (int g = 0; g < c.n_goals; ++g) {
+            const double gx = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g);
+            const double gy = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g + 1);
+            const double r = c.goal_r;
+            const bool near = live & !SSG_ABL(5) & (bool)((gm >> g) & 1u) & ((gx - r) <= sbr) & (sbl <= (gx + r)) &
+                              ((gy - r) <= sbt) & (sbb <= (gy + r));
+            const unsigned long long m = __ballot(near);
+            const int pos = n_pairs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (near) gq[pos] = (unsigned short)(lane | (g << 6));
+            n_pairs += __popcll(m);
         }
-        unsigned long long todo = __ballot(nearbits != 0u);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
-            const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
-            const int boff = __builtin_amdgcn_readlane(rec_off, src);
-            const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
-            const int bcnts = __builtin_amdgcn_readlane(cnts, src);
-            const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
+        for (int base = 0; base < n_pairs; base += 12) {
+            const int p = base + wq;
+            const bool valid = (lane < 60) & (p < n_pairs);
+            const unsigned code = gq[valid ? p : 0];
+            const int src = code & 63, g = code >> 6;
+            const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
+            const int boff = __shfl(rec_off, src);
+            const double gx = bank_at<LDS_BANK>(c, boff + SSG_MAP_OFF_GOALS + 2 * g);
+            const double gy = bank_at<LDS_BANK>(c, boff + SSG_MAP_OFF_GOALS + 2 * g + 1);
+            // lane = (pair p, ship edge i from vertex i-1 to vertex i)
+            const double v1x = bca * w_hx + (-bsa) * w_hy + bx, v1y = bsa * w_hx + bca * w_hy + by;
+            const double v0x = bca * w_px + (-bsa) * w_py + bx, v0y = bsa * w_px + bca * w_py + by;
             const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
-            const double off_i = snx_ * svx + sny_ * svy;
-            bool col = false;
+            const bool out_i = (snx_ * (gx - v1x) + sny_ * (gy - v1y)) > 0.0;
+            // cpClosetPointOnSegment(p, v0, v1)
+            const double dx = v0x - v1x, dy = v0y - v1y;
+            const double tt = dmax(0.0, dmin((dx * (gx - v1x) + dy * (gy - v1y)) / (dx * dx + dy * dy), 1.0));
+            const double qx = v1x + dx * tt, qy = v1y + dy * tt;
+            const double ex_ = gx - qx, ey_ = gy - qy;
+            const double dist = sqrt(ex_ * ex_ + ey_ * ey_);
+            // min over the five edges of this pair (lanes 5p' .. 5p'+4), any(outside) over the same five lanes
+            double md = dist;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (!(bnear & (1u << s))) continue; // wave-uniform
-                const int cnt = (bcnts >> (8 * s)) & 0xFF;
-                const bool valid = (lane < 60) & (wq < cnt);
-                const int q = boff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) +
-                              SSG_PLANE_DOUBLES * ((wq < SSG_MAX_HULL) ? wq : 0);
-                const double v0x = bank_at<LDS_BANK>(c, q + 0), v0y = bank_at<LDS_BANK>(c, q + 1);
-                const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
-                const double v0n = bank_at<LDS_BANK>(c, q + 4);
-                const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
-                const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
-                const unsigned long long mV = __ballot(valid);
-                const unsigned long long mA = __ballot(valid & frontA);
-                const unsigned long long missB = mV & ~__ballot(valid & frontB);
-                const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
-                // axis = bank plane q: all five (q,i) bits set
-                const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
-                // axis = ship plane i: no valid (q,i) bit missing
-                bool sepB = false;
-#pragma unroll
-                for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB | (((missB >> i) & P) == 0ull);
-                const bool separated = (allA != 0ull) | sepB;
-                col = col | !separated;
+            for (int k = 1; k < SSG_SHIP_VERTS; ++k) {
+                int o = wi + k;
+                o = (o >= SSG_SHIP_VERTS) ? o - SSG_SHIP_VERTS : o;
+                md = dmin(md, __shfl(dist, 5 * wq + o));
             }
-            colliding = (lane == src) ? col : colliding;
+            const unsigned long long mo = __ballot(valid & out_i);
+            const bool outside = ((mo >> (5 * wq)) & 31ull) != 0ull;
+            const double sd = outside ? md : -md;
+            if (valid & (wi == 0) & (sd <= c.goal_r)) atomicOr(&gw[src], 1u << g); // goal g of env src consumed
         }
+        const unsigned gotmask = gw[lane];
+        goal_reached = gotmask != 0u;
+        gm &= ~gotmask;
     }
+    // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position
+    double nf_gx = 0, nf_gy = 0;
+    if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm, x, y, nf_gx, nf_gy);
     SSG_STAMP(3);
 
     // previous frame's nearest goal (oldest slot of the 2-frame history): a function of the pre-step state
@@ -640,11 +730,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     __syncthreads(); // barrier 2: lidar results, force/torque and the goal results are complete
     SSG_STAMP(5);
 
-    // ---- collide_goal results (role 2) ----
-    const unsigned gr = gres[tl];
-    const bool goal_reached = (gr >> 31) != 0u;
-    gm = (gm & 0x80u) | (gr & 0x7Fu);
-    const double nf_gx = xchg[3 * EPW + tl], nf_gy = xchg[4 * EPW + tl];
+    const bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
 
     // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role 0 accumulated; forces are
     //      cleared afterwards.  (The narrowphase reads positions only, so doing this last changes nothing.) ----
@@ -681,74 +767,122 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         if (goal_reached) atomicAdd(slot + 3, 1ull);
     }
 
-    // observation values: the stepped frames, or (VecEnv auto-reset) ShipGame.reset + ShipEnv.reset onto the next
-    // bank record: history of -1 then the spawn frame.
-    double o_old[6 + NB], o_new[6 + NB];
-    o_old[0] = pf_x; o_old[1] = pf_y; o_old[2] = pf_rud; o_old[3] = pf_a; o_old[4] = pf_gx; o_old[5] = pf_gy;
-    o_new[0] = x; o_new[1] = y; o_new[2] = (double)rudder; o_new[3] = ang; o_new[4] = nf_gx; o_new[5] = nf_gy;
+    // ---- observation (ship_env.py:79-113,156): row = [previous frame | new frame]; for a done env under VecEnv
+    //      auto-reset, ShipGame.reset + ShipEnv.reset onto the next bank record: a history of -1, then the spawn frame.
+    //      A lane's row is 8*D bytes and rows of neighbouring envs are adjacent in HBM, so the wave's 64 rows form one
+    //      contiguous tile: it is transposed through LDS (the scratch of this tile's two lidar waves, idle between
+    //      barrier 2 and barrier 3) and written with 16-byte-per-lane, 1 KiB-per-instruction coalesced stores.
+    //      Scattered 8-byte stores of the same data cost 64 write requests per instruction and dominated the step. ----
+    SSG_STAMP(6);
+    char *tile_scr = scratch0 + (2 * (tl >> 6)) * lds_wave_scratch_bytes(NB0);
+    double nl[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         // results of the lidar wave that served these 64 envs: role 0 holds beams [0,NB0), role 1 the rest
-        const int lr = (i < NB0) ? 0 : 1, k = i - lr * NB0;
-        const char *ascr = scratch0 + (lr * (EPW / 64) + (tl >> 6)) * lds_wave_scratch_bytes(NB0);
-        const double *res0 = reinterpret_cast<const double *>(ascr);
+        const int lr = (i < NB0) ? 0 : 1, kk = i - lr * NB0;
+        const double *res0 = reinterpret_cast<const double *>(tile_scr + lr * lds_wave_scratch_bytes(NB0));
         const double *res1 = res0 + NB0 * 64;
         // first shape in list order that reports a hit wins (models.py:61-72): the left bank before the right
-        const double r0 = res0[k * 64 + lane], r1 = res1[k * 64 + lane];
-        const double nl = (r0 >= 0.0) ? r0 : r1;
-        o_old[6 + i] = lid[i];                      // readings before this step's query
-        lid[i] = (nl >= 0.0) ? nl : lid[i];         // a miss keeps the previous reading (sticky, App. B-3)
-        o_new[6 + i] = lid[i];
+        const double r0 = res0[kk * 64 + lane], r1 = res1[kk * 64 + lane];
+        nl[i] = (r0 >= 0.0) ? r0 : r1;
     }
     if (do_reset) {
         map_id = map_id + 1;
         if (map_id >= c.n_maps) map_id = 0;
+    }
+    const double rs_gx = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
+    const double rs_gy = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
+    {
+        constexpr int D = 2 * (6 + NB);           // widest row (history 2); history 1 uses the first F columns
+        constexpr int LD = D + 1;                 // padded LDS row: odd stride in 8-byte units, conflict-free writes
+        constexpr int kAvail = 2 * lds_wave_scratch_bytes(NB0);
+        constexpr int RP = (64 * LD * 8 <= kAvail) ? 64 : (32 * LD * 8 <= kAvail) ? 32 : (16 * LD * 8 <= kAvail) ? 16 : 8;
+        static_assert(RP * LD * 8 <= kAvail, "observation tile does not fit the lidar scratch");
+        const int Dh = F * c.history;             // doubles per row actually written
+        double *tile = reinterpret_cast<double *>(tile_scr);
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the result reads above are done before we overwrite
+        double *__restrict__ obase = obs + (size_t)(blockIdx.x * EPW + (tl & ~63)) * (size_t)Dh; // tile start in HBM
+        const int rows_live = min(64, c.n_envs - (blockIdx.x * EPW + (tl & ~63)));              // rows of this tile in range
+#pragma unroll
+        for (int p0 = 0; p0 < 64; p0 += RP) {
+            const bool mine = (lane >= p0) & (lane < p0 + RP);
+            double *trow = tile + (lane - p0) * LD;
+            if (mine) {
+                int col = 0;
+                if (hist2) {
+                    trow[0] = do_reset ? -1.0 : pf_x;   trow[1] = do_reset ? -1.0 : pf_y;
+                    trow[2] = do_reset ? -1.0 : pf_rud; trow[3] = do_reset ? -1.0 : pf_a;
+                    trow[4] = do_reset ? -1.0 : pf_gx;  trow[5] = do_reset ? -1.0 : pf_gy;
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) trow[6 + i] = do_reset ? -1.0 : lid[i]; // readings before this query
+                    col = F;
+                }
+                trow[col + 0] = do_reset ? c.spawn_x : x;
+                trow[col + 1] = do_reset ? c.spawn_y : y;
+                trow[col + 2] = do_reset ? 0.0 : (double)rudder;
+                trow[col + 3] = do_reset ? 0.0 : ang;
+                trow[col + 4] = do_reset ? rs_gx : nf_gx;
+                trow[col + 5] = do_reset ? rs_gy : nf_gy;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const double v = (nl[i] >= 0.0) ? nl[i] : lid[i]; // a miss keeps the previous reading (sticky)
+                    trow[col + 6 + i] = do_reset ? -1.0 : v;
+                }
+            }
+            // linear read-back: element o of the pass (row-major, Dh per row) -> 16 bytes per lane per instruction
+            const int n_el = min(RP, max(0, rows_live - p0)) * Dh;
+            if (!SSG_ABL(7)) {
+                if (!(Dh & 1)) { // even row length: pairs never straddle rows and stay 16-byte aligned
+                    for (int o = 2 * lane; o < n_el; o += 128) {
+                        const int r = o / Dh, cc = o - r * Dh;
+                        double2 v2;
+                        v2.x = tile[r * LD + cc];
+                        v2.y = tile[r * LD + cc + 1];
+                        *reinterpret_cast<double2 *>(obase + (size_t)p0 * Dh + o) = v2;
+                    }
+                } else {
+                    for (int o = lane; o < n_el; o += 64) {
+                        const int r = o / Dh, cc = o - r * Dh;
+                        obase[(size_t)p0 * Dh + o] = tile[r * LD + cc];
+                    }
+                }
+            }
+            if (p0 + RP < 64) __builtin_amdgcn_s_waitcnt(0xC07F); // reads done before the next pass overwrites the tile
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) lid[i] = do_reset ? -1.0 : ((nl[i] >= 0.0) ? nl[i] : lid[i]);
+    if (live) {
+        reward_out[el] = rew;
+        done_out[el] = done ? 1 : 0;
+        if (flags_out) {
+            unsigned ev = 0;
+            if (colliding) ev |= SSG_EV_COLLIDING;
+            if (goal_reached) ev |= SSG_EV_GOAL_REACHED;
+            if (oob_x | oob_y) ev |= SSG_EV_OUT_OF_BOUNDS;
+            if (steps_after >= c.max_steps) ev |= SSG_EV_MAX_STEPS;
+            if (alive == 0u) ev |= SSG_EV_NO_GOALS_LEFT;
+            flags_out[el] = (uint8_t)ev;
+        }
+    }
+    if (do_reset) {
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
         rudder = 0; steps = 0;
         gm = (1u << c.n_goals) - 1u;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) lid[i] = -1.0;
-#pragma unroll
-        for (int i = 0; i < 6 + NB; ++i) { o_old[i] = -1.0; o_new[i] = -1.0; }
-        o_new[0] = x; o_new[1] = y; o_new[2] = 0.0; o_new[3] = 0.0;
-        o_new[4] = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
-        o_new[5] = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
     }
-    SSG_STAMP(6);
+    if (live) {
+        colX[el] = x; colY[el] = y; colVX[el] = vx; colVY[el] = vy; colA[el] = ang; colW[el] = w; colCum[el] = cum;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) colLid[(size_t)i * np + el] = lid[i];
+        colRud[el] = rudder; colStep[el] = steps; colMap[el] = map_id;
+        c.mask[el] = (uint8_t)gm;
+    }
+    if (k + 1 < K) {
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wave's state stores have reached the L2
+        __syncthreads();               // barrier 3: the other roles may now read the next step's state
+    }
+    } // k
     SSG_STAMP_FLUSH(7);
-    if (!live) return; // every cooperative section is behind us: lanes past n_envs store nothing
-    double *__restrict__ orow = obs + (size_t)e * (size_t)(F * c.history);
-    if (!SSG_ABL(7)) {
-        if (hist2) {
-#pragma unroll
-            for (int i = 0; i < 6 + NB; ++i) orow[i] = o_old[i];
-            orow += F;
-        }
-#pragma unroll
-        for (int i = 0; i < 6 + NB; ++i) orow[i] = o_new[i];
-    } else {
-        double acc = 0;
-        for (int i = 0; i < 6 + NB; ++i) acc += o_old[i] + o_new[i];
-        orow[0] = acc;
-    }
-
-    reward_out[e] = rew;
-    done_out[e] = done ? 1 : 0;
-    if (flags_out) {
-        unsigned ev = 0;
-        if (colliding) ev |= SSG_EV_COLLIDING;
-        if (goal_reached) ev |= SSG_EV_GOAL_REACHED;
-        if (oob_x | oob_y) ev |= SSG_EV_OUT_OF_BOUNDS;
-        if (steps_after >= c.max_steps) ev |= SSG_EV_MAX_STEPS;
-        if (alive == 0u) ev |= SSG_EV_NO_GOALS_LEFT;
-        flags_out[e] = (uint8_t)ev;
-    }
-
-    colX[e] = x; colY[e] = y; colVX[e] = vx; colVY[e] = vy; colA[e] = ang; colW[e] = w; colCum[e] = cum;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) colLid[(size_t)i * np + e] = lid[i];
-    colRud[e] = rudder; colStep[e] = steps; colMap[e] = map_id;
-    c.mask[e] = (uint8_t)gm;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -823,7 +957,7 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
 // ---------------------------------------------------------------------------------------------------------
 // launchers (called from shipsim_api.cpp).  `epw` = envs per workgroup; the workgroup has 4*epw threads.
 // ---------------------------------------------------------------------------------------------------------
-using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *);
+using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *, int);
 
 template <int NB, int EPW>
 static step_fn_t step_fn_nb(bool lds, bool exact)
@@ -877,13 +1011,13 @@ hipError_t prepare_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes)
                                (int)lds_bytes);
 }
 
-hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions, double *obs,
+hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions, int K, double *obs,
                        double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream)
 {
     step_fn_t k = step_fn(c.n_beams, epw, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
     const int grid = (c.n_envs + epw - 1) / epw;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K);
     return hipGetLastError();
 }
 

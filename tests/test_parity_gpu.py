@@ -139,6 +139,25 @@ def test_state_columns_match_oracle(torch_cuda, oracle, native):
     np.testing.assert_array_equal(vec.field(N.F_GOAL_MASK).cpu().numpy() & 0x7F, pk[:, 13].astype(np.uint8))
 
 
+def test_fused_rollout_equals_single_steps(torch_cuda, native):
+    """ssg_rollout (K steps fused in one launch, state in registers, other roles re-reading it from L2) must leave
+    exactly the state and outputs that K separate ssg_step launches leave."""
+    torch = torch_cuda
+    for n, nb in ((1000, 10), (65536, 8)):
+        a = _vec(n, n_maps=64, n_beams=nb)
+        b = _vec(n, n_maps=64, n_beams=nb)
+        a.reset_tensor(); b.reset_tensor()
+        acts = a.random_actions(77, 0, 150)
+        for k in range(150):
+            a.step_tensor(acts[k])
+        b.rollout_tensor(acts)
+        torch.cuda.synchronize()
+        assert torch.equal(a.state, b.state)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+        assert torch.equal(a.flags, b.flags)
+        assert a.stats() == b.stats()
+
+
 def test_shard_equivalence(torch_cuda, native):
     """N envs on one handle == the same envs split over two handles (env_id_base keyed), bitwise."""
     n = 1024

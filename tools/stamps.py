@@ -19,8 +19,8 @@ vec.rollout_tensor(acts[:200])
 names = {
     0: ["loads+sincos+force", "wait DMA+barrier1", "bb+cull+queue", "lidar passes", "wait barrier2"],
     1: ["loads+sincos", "wait DMA+barrier1", "bb+cull+queue", "lidar passes", "wait barrier2"],
-    2: ["loads+integrate+sincos", "wait DMA+barrier1", "bb+goals", "nearest goal+publish", "wait barrier2"],
-    3: ["loads+integrate+sincos", "wait DMA+barrier1", "bb+SAT", "prev nearest goal", "wait barrier2", "tail+obs assembly"],
+    2: ["loads+integrate+sincos", "wait DMA+barrier1", "bb+SAT+publish", "-", "wait barrier2"],
+    3: ["loads+integrate+sincos", "wait DMA+barrier1", "bb+goals+nearest", "prev nearest goal", "wait barrier2", "tail"],
 }
 wpr = epw // 64
 acc = {r: np.zeros(len(v)) for r, v in names.items()}
