@@ -885,6 +885,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     SSG_STAMP_FLUSH(7);
 }
 
+#ifndef SSG_NB_GROUP
 // ---------------------------------------------------------------------------------------------------------
 // reset kernel: ShipEnv.reset / ShipGame.reset for the masked envs (ship_env.py:171-184, game.py:260-277)
 // ---------------------------------------------------------------------------------------------------------
@@ -954,46 +955,75 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
     out[idx] = (int32_t)(((uint64_t)ctr[0] * 3u) >> 32);
 }
 
+#endif // !SSG_NB_GROUP
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers (called from shipsim_api.cpp).  `epw` = envs per workgroup; the workgroup has 4*epw threads.
+// The step kernel is instantiated per beam count; the instantiations are spread over four translation units
+// (this file compiled with -DSSG_NB_GROUP=0..3, four beam counts each) so the library builds in parallel.
 // ---------------------------------------------------------------------------------------------------------
 using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *, int);
 
+#ifdef SSG_NB_GROUP
 template <int NB, int EPW>
 static step_fn_t step_fn_nb(bool lds, bool exact)
 {
-    if (exact) return lds ? step_kernel<NB, EPW, true, true> : step_kernel<NB, EPW, false, true>;
+    // the plane-by-plane lidar (SSG_FLAG_EXACT_LIDAR, a validation aid) is built for the two BASELINE beam counts
+    if (exact) {
+        if constexpr (NB == 8 || NB == 10) return lds ? step_kernel<NB, EPW, true, true> : step_kernel<NB, EPW, false, true>;
+        else return nullptr;
+    }
     return lds ? step_kernel<NB, EPW, true, false> : step_kernel<NB, EPW, false, false>;
 }
 
-template <int EPW>
-static step_fn_t step_fn_epw(int nb, bool lds, bool exact)
+template <int NB>
+static step_fn_t step_fn_epw(int epw, bool lds, bool exact)
 {
-    switch (nb) {
-#define SSG_CASE(NB_) \
-    case NB_: return step_fn_nb<NB_, EPW>(lds, exact);
-#ifdef SSG_DEV_BUILD /* development builds instantiate the two BASELINE beam counts only */
-        SSG_CASE(8) SSG_CASE(10)
-#else
-        SSG_CASE(1) SSG_CASE(2) SSG_CASE(3) SSG_CASE(4) SSG_CASE(5) SSG_CASE(6) SSG_CASE(7) SSG_CASE(8)
-        SSG_CASE(9) SSG_CASE(10) SSG_CASE(11) SSG_CASE(12) SSG_CASE(13) SSG_CASE(14) SSG_CASE(15) SSG_CASE(16)
-#endif
-#undef SSG_CASE
+    switch (epw) {
+    case 64: return step_fn_nb<NB, 64>(lds, exact);
+    case 128: return step_fn_nb<NB, 128>(lds, exact);
+    case 256: return step_fn_nb<NB, 256>(lds, exact);
     default: return nullptr;
     }
 }
+
+#define SSG_GROUP_FN_(g) step_fn_group##g
+#define SSG_GROUP_FN(g) SSG_GROUP_FN_(g)
+step_fn_t SSG_GROUP_FN(SSG_NB_GROUP)(int nb, int epw, bool lds, bool exact)
+{
+#ifdef SSG_GROUP_STUB /* development builds may leave a beam-count group out */
+    (void)nb; (void)epw; (void)lds; (void)exact;
+    return nullptr;
+#else
+    switch (nb - 4 * SSG_NB_GROUP) {
+    case 1: return step_fn_epw<4 * SSG_NB_GROUP + 1>(epw, lds, exact);
+    case 2: return step_fn_epw<4 * SSG_NB_GROUP + 2>(epw, lds, exact);
+    case 3: return step_fn_epw<4 * SSG_NB_GROUP + 3>(epw, lds, exact);
+    case 4: return step_fn_epw<4 * SSG_NB_GROUP + 4>(epw, lds, exact);
+    default: return nullptr;
+    }
+#endif
+}
+
+#else // main translation unit: reset / action kernels and the launch entry points
+
+step_fn_t step_fn_group0(int nb, int epw, bool lds, bool exact);
+step_fn_t step_fn_group1(int nb, int epw, bool lds, bool exact);
+step_fn_t step_fn_group2(int nb, int epw, bool lds, bool exact);
+step_fn_t step_fn_group3(int nb, int epw, bool lds, bool exact);
 
 static step_fn_t step_fn(int nb, int epw, bool lds, bool exact)
 {
-    switch (epw) {
-    case 64: return step_fn_epw<64>(nb, lds, exact);
-    case 128: return step_fn_epw<128>(nb, lds, exact);
-    case 256: return step_fn_epw<256>(nb, lds, exact);
-    default: return nullptr;
+    if (nb < 1 || nb > SSG_MAX_BEAMS) return nullptr;
+    switch ((nb - 1) / 4) {
+    case 0: return step_fn_group0(nb, epw, lds, exact);
+    case 1: return step_fn_group1(nb, epw, lds, exact);
+    case 2: return step_fn_group2(nb, epw, lds, exact);
+    default: return step_fn_group3(nb, epw, lds, exact);
     }
 }
 
-// dynamic LDS: [bank (if staged)] [tables + exchange] [per-A-wave lidar scratch]
+// dynamic LDS: [bank (if staged)] [tables + exchange] [per-lidar-wave scratch]
 size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
 {
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
@@ -1038,5 +1068,6 @@ hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long e
                        out);
     return hipGetLastError();
 }
+#endif // SSG_NB_GROUP
 
 } // namespace ssg

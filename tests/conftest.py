@@ -26,6 +26,6 @@ def native():
     from ship_sim_gym_amd import _native as N
     if not os.path.exists(N.LIB_PATH):
         import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ship_sim_gym_amd", "csrc"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ship_sim_gym_amd", "csrc"), "-s", "-j8"])
     N.lib()
     return N
