@@ -45,13 +45,13 @@ def cpu_baseline(vec, seconds_target=12.0):
     from helpers import oracle_cfg
     from oracle import oracle as O
     threads = O.max_threads()
-    n = 4096
+    n = 16384
     ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
     ob.reset()
     t0 = time.perf_counter()
     ob.rollout(12345, 0, 20, n_threads=threads)  # calibration
     per_step = (time.perf_counter() - t0) / 20
-    K = max(20, min(4000, int(seconds_target / max(per_step, 1e-9))))
+    K = max(20, min(100000, int(seconds_target / max(per_step, 1e-9))))
     ob.reset()
     t0 = time.perf_counter()
     done_steps = ob.rollout(12345, 0, K, n_threads=threads)
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-step", action="store_true", help="skip the informational one-launch-per-step timing")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +120,18 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
+    # for information: the policy-in-the-loop path, one ssg_step launch per step (not the headline number)
+    single_us = None
+    if world == 1 and not args.no_single_step:
+        ks = min(K, 500)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(ks):
+            vec.step_tensor(acts[W + k])
+        e1.record()
+        torch.cuda.synchronize()
+        single_us = e0.elapsed_time(e1) * 1e3 / ks
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -127,13 +140,17 @@ def main():
     if rank == 0:
         total_steps = float(n) * world * K
         B = algorithmic_bytes(1, N_BEAMS, 2)
-        launch_s = ev_ms * 1e-3 / K
-        achieved = B * n / launch_s / 1e9
+        # ssg_rollout fuses SSG_ROLLOUT_STEPS_PER_LAUNCH (100) steps into each launch of the step kernel:
+        # algorithmic bytes per launch = B * n * steps_per_launch, launch duration = HIP-event time / launches
+        spl = int(os.environ.get("SSG_FUSE", "100"))
+        n_launch = (K + spl - 1) // spl
+        launch_s = ev_ms * 1e-3 / n_launch
+        achieved = B * n * (K / n_launch) / launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")  # rocprofv3 PMC, same command (profiles/)
             except Exception:
                 traffic = None
         out = {
@@ -146,8 +163,10 @@ def main():
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "ssg::step_kernel<8,256,true>", "algorithmic_bytes_per_env_step": B,
-                         "avg_launch_us": launch_s * 1e6},
+                         "kernel": "ssg::step_kernel<8, 256, true, false>", "algorithmic_bytes_per_env_step": B,
+                         "steps_per_launch": K / n_launch, "avg_launch_us": launch_s * 1e6,
+                         "us_per_step_in_launch": launch_s * 1e6 * n_launch / K},
+            "single_step_launch_us": single_us,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vec)

@@ -177,15 +177,22 @@ int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double 
 #define SSG_EV_MAX_STEPS 0x8u
 #define SSG_EV_NO_GOALS_LEFT 0x10u
 
-/* K consecutive ssg_step launches enqueued back to back on `stream`, step k reading dev_actions + k*n_envs
- * (the random-action rollout loop of train/random.py:14-27, batched).  obs/reward/done/flags are overwritten by
- * every step, exactly as K separate ssg_step calls would. */
+/* K consecutive steps, step k reading dev_actions + k*n_envs (the random-action rollout loop of
+ * train/random.py:14-27, batched), enqueued on `stream` as ceil(K / SSG_ROLLOUT_STEPS_PER_LAUNCH) launches of the step
+ * kernel: inside a launch the map bank stays in LDS and the body state in registers from step to step.
+ * obs/reward/done/flags are overwritten by every step and the state blob is updated every step; the final contents of
+ * every buffer are bit for bit those of K separate ssg_step calls. */
+#define SSG_ROLLOUT_STEPS_PER_LAUNCH 100 /* steps fused into one launch of the step kernel by ssg_rollout */
 int ssg_rollout(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev_obs, double *dev_reward,
                 uint8_t *dev_done, uint8_t *dev_flags /* nullable */, void *stream);
 
 /* Random-action rollout driver (train/random.py:14-27 batched): fills i32[K][n_envs] with a counter-based
  * Philox4x32-10 stream keyed by (seed, step0+k, env_id_base+e), uniform on Discrete(3) (ship_env.py:19). */
 int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_t *dev_actions, void *stream);
+
+/* Measurement aid (no reference counterpart): coalesced 8-byte-per-lane device copy of n_doubles doubles, the
+ * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
+int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Host-side geometry (what pymunk's cffi exposed at reset time); no GPU needed.

@@ -509,11 +509,12 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         return fail(h, SSG_ERR_BAD_ARG, "ssg_step/ssg_rollout: NULL buffer or K < 1");
     rc = prepare(h);
     if (rc != SSG_OK) return rc;
-    // One launch runs up to kFuse consecutive steps (state in registers, bank staged once); SSG_FUSE=1 in the
-    // environment forces one launch per step (the path a policy-in-the-loop caller gets through ssg_step).
+    // One launch runs up to kFuse consecutive steps (state in registers, bank staged once): 100 by default, which
+    // keeps a launch near a millisecond and amortises the fixed launch cost to < 1 %.  SSG_FUSE=1 in the environment
+    // forces one launch per step (the path a policy-in-the-loop caller gets through ssg_step).
     static const int kFuse = [] {
         const char *s = std::getenv("SSG_FUSE");
-        const int v = s ? std::atoi(s) : 1 << 20;
+        const int v = s ? std::atoi(s) : SSG_ROLLOUT_STEPS_PER_LAUNCH;
         return v < 1 ? 1 : v;
     }();
     for (int k = 0; k < K; k += kFuse) {
@@ -543,6 +544,12 @@ int ssg_debug_set_stamp_buffer(ssg_handle *h, void *dev_buf)
     return SSG_OK;
 }
 #endif
+
+int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream)
+{
+    if (!dev_src || !dev_dst) return SSG_ERR_BAD_ARG;
+    return ssg::launch_calib_copy8(dev_src, dev_dst, n_doubles, static_cast<hipStream_t>(stream)) == hipSuccess ? SSG_OK : SSG_ERR_HIP;
+}
 
 // ---- host geometry ----
 int ssg_host_convex_hull(int count, const double *verts_xy, double *out_xy, int *out_count)

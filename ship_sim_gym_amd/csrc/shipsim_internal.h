@@ -45,6 +45,7 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
+hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
 hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long env_base, int n, int32_t *out,
                                hipStream_t stream);
 

@@ -924,6 +924,16 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PMC calibration aid: a coalesced 8-byte-per-lane copy (the step kernel's access width), so FETCH_SIZE/WRITE_SIZE
+// can be calibrated on a known byte count in this access pattern (MI355X_MICROARCH.md, HBM section).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void calib_copy8_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // counter-based action stream: Philox4x32-10, counter = (env_lo, env_hi, step_lo, step_hi), key = seed
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], const uint32_t (&key)[2])
@@ -1055,6 +1065,13 @@ hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map
 {
     const int block = 256, grid = (c.n_envs + block - 1) / block;
     hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(block), 0, stream, c, mask, map_ids, obs);
+    return hipGetLastError();
+}
+
+hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream)
+{
+    const int block = 256;
+    hipLaunchKernelGGL(calib_copy8_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, src, dst, n);
     return hipGetLastError();
 }
 

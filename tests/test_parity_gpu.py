@@ -244,3 +244,40 @@ def test_single_env_fresh_mode_matches_oracle(torch_cuda, oracle, native):
             if d:
                 break
         env.close()
+
+
+def test_vec_env_protocols(torch_cuda, native):
+    """stable-baselines VecEnv and RLlib VectorEnv surfaces + the ship_gym alias package."""
+    from ship_gym.ship_env import ShipEnv as AliasEnv          # what the reference's scripts import
+    from ship_gym.config import EnvConfig, GameConfig
+    from ship_sim_gym_amd.ship_env import ShipEnv
+    assert AliasEnv is ShipEnv and GameConfig.BOUNDS == (600, 600) and EnvConfig.HISTORY_SIZE == 2
+    v = _vec(8, n_maps=4)
+    assert v.num_envs == 8 and v.action_space.n == 3 and v.observation_space.shape == (32,)
+    assert v.observation_space.dtype == np.uint8 and v.reward_range == (-1, 1)      # ship_env.py:18-20,48
+    o = v.reset()
+    assert o.shape == (8, 32) and o.dtype == np.float64 and np.all(o[:, :16] == -1)
+    v.step_async(np.zeros(8, dtype=np.int64))
+    o, r, d, infos = v.step_wait()
+    assert o.shape == (8, 32) and r.shape == (8,) and d.dtype == bool and infos == [{}] * 8
+    with pytest.raises(AssertionError):
+        v.step(np.full(8, 3))                                   # Discrete(3): action 3 is rejected (ship_env.py:143)
+    obs_l, rew_l, done_l, infos = v.vector_step([0] * 8)        # RLlib VectorEnv
+    assert len(obs_l) == 8 and obs_l[0].shape == (32,) and len(v.vector_reset()) == 8
+    o1 = v.reset_at(3)
+    assert o1.shape == (32,) and np.all(o1[:16] == -1) and o1[16] == 300 and v.get_unwrapped() == []
+    assert v.seed(7) == [7]
+    # auto-reset returns the reset observation: run until some env is done
+    seen = False
+    for _ in range(400):
+        o, r, d, _ = v.step(np.zeros(8, dtype=np.int64))
+        if d.any():
+            seen = True
+            assert np.all(o[d][:, :16] == -1) and np.all(o[d][:, 16] == 300)
+            break
+    assert seen
+    v.close()
+    with pytest.raises(ValueError):
+        class E(EnvConfig):
+            HISTORY_SIZE = 0
+        _vec(4, env_config=E)

@@ -17,6 +17,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     for n, v in d.items():
         v2 = sorted(v)
         print("trace:", n[:60], "calls", len(v), "avg_us %.3f med_us %.3f min_us %.3f" % (sum(v) / len(v) / 1e3, v2[len(v2) // 2] / 1e3, v2[0] / 1e3), meta[n])
+big = {}
 print("== PMC (mean per dispatch of the step kernel) ==")
 for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
@@ -25,4 +26,24 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
             continue
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in acc.items():
-        print("%-28s mean %.6g  (n=%d)" % (k, sum(v) / len(v), len(v)))
+        print("%-28s mean %.6g  (n=%d)   largest dispatch %.6g" % (k, sum(v) / len(v), len(v), max(v)))
+        if k in ("FETCH_SIZE", "WRITE_SIZE"):
+            big[k] = sum(v) / len(v)  # every rollout launch runs the same 100 steps
+
+print("== FETCH_SIZE / WRITE_SIZE calibration (tools/calib_pmc.py: 1 GiB read + 1 GiB written per dispatch, 8 B per lane) ==")
+cal = {}
+for name in ("cal_fetch", "cal_write"):
+    for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "calib_copy8" in r.get("Kernel_Name", "")]
+        if v:
+            cal[name] = sum(v) / len(v)
+            print("%s mean per dispatch: %.6g (KB units -> %.4f of the true 1 GiB)" % (name, cal[name], cal[name] * 1024 / 2**30))
+
+if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
+    fcal = cal.get("cal_fetch", 524288.0) * 1024 / 2**30
+    wcal = cal.get("cal_write", 1048576.0) * 1024 / 2**30
+    hbm = (big["FETCH_SIZE"] / fcal + big["WRITE_SIZE"] / wcal) * 1024
+    print("== HBM traffic of one 100-step rollout launch: (FETCH_SIZE/%.3f + WRITE_SIZE/%.3f) KB = %.6g bytes per launch ==" % (fcal, wcal, hbm))
+    import json
+    json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": big["FETCH_SIZE"], "write_size_kb": big["WRITE_SIZE"],
+               "fetch_calibration": fcal, "write_calibration": wcal}, open(os.path.join(out, "traffic.json"), "w"))
