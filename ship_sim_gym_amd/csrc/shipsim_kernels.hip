@@ -54,6 +54,16 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) // src_la
     return __hiloint2double(hi, lo);
 }
 
+// cpvforangle(a) = (cos a, sin a).  Deliberately NOT inlined: inside the fused K-step loop the compiler otherwise hoists
+// the polynomial coefficients of the inlined sincos out of the loop as live VGPR constants and, at the 128-VGPR
+// budget of a 1024-thread workgroup, spills them to scratch and reloads them on the critical path every step.
+__device__ __attribute__((noinline)) double2 sincos_call(double a) // returns (sin a, cos a) in registers
+{
+    double2 r;
+    sincos(a, &r.x, &r.y);
+    return r;
+}
+
 // State loads.  In the fused multi-step loop the columns were rewritten by another wave of this workgroup one
 // barrier ago: `fresh` (wave-uniform) selects agent-scope relaxed atomic loads (global_load ... sc1), which are served
 // by the L2 instead of this CU's possibly stale vector L1.
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         const int rec_off = map_id * SSG_MAP_STRIDE;
 
         double sa0, ca0;
-        sincos(ang, &sa0, &ca0); // cpvforangle(a) = (cos a, sin a): body->transform rotation
+        { const double2 sc = sincos_call(ang); sa0 = sc.x; ca0 = sc.y; } // body->transform rotation
         if (role == 0) {
             // handle_discrete_action (game.py:140-153): Ship.move_forward ->
             // cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust); the rudder update itself is role 3's
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     y = y + vy * c.dt;
     ang = ang + w * c.dt;
     double sa, ca;
-    sincos(ang, &sa, &ca);
+    { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; }
 
     SSG_STAMP(1);
     if (k == 0) {
@@ -774,7 +784,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     //      barrier 2 and barrier 3) and written with 16-byte-per-lane, 1 KiB-per-instruction coalesced stores.
     //      Scattered 8-byte stores of the same data cost 64 write requests per instruction and dominated the step. ----
     SSG_STAMP(6);
-    char *tile_scr = scratch0 + (2 * (tl >> 6)) * lds_wave_scratch_bytes(NB0);
+    int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);                 // wave-uniform; laundered like `el`:
+    int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                        // no hoisted tile addresses
+    asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
+    char *tile_scr = scratch0 + (2 * tile_w) * lds_wave_scratch_bytes(NB0);
     double nl[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -801,8 +814,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         const int Dh = F * c.history;             // doubles per row actually written
         double *tile = reinterpret_cast<double *>(tile_scr);
         __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the result reads above are done before we overwrite
-        double *__restrict__ obase = obs + (size_t)(blockIdx.x * EPW + (tl & ~63)) * (size_t)Dh; // tile start in HBM
-        const int rows_live = min(64, c.n_envs - (blockIdx.x * EPW + (tl & ~63)));              // rows of this tile in range
+        double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)Dh; // tile start in HBM
+        const int rows_live = min(64, c.n_envs - tile_e0);               // rows of this tile in range
 #pragma unroll
         for (int p0 = 0; p0 < 64; p0 += RP) {
             const bool mine = (lane >= p0) & (lane < p0 + RP);
