@@ -79,10 +79,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -99,7 +100,7 @@ def main():
         N.check(N.lib().ssg_create(C.byref(vec.cfg), C.byref(vec._h)), None, "ssg_create")
         N.check(N.lib().ssg_bind_state(vec._h, C.c_void_p(vec.state.data_ptr())), vec._h, "bind")
         vec.set_bank(vec.bank)
-    if world > 1:
+    if use_dist:
         sharding.broadcast_bank(vec, src=0)  # RCCL broadcast of the map bank over xGMI; the only collective on the path
 
     K, W = args.steps, args.warmup
@@ -107,7 +108,7 @@ def main():
     vec.reset_tensor()
     vec.rollout_tensor(acts[:W]) if W > 0 else None
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -116,7 +117,7 @@ def main():
     vec.rollout_tensor(acts[W:])  # K launches of the step kernel on torch's current stream
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
@@ -132,9 +133,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         single_us = e0.elapsed_time(e1) * 1e3 / ks
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time
         wall = float(t.item())
 
     if rank == 0:
@@ -173,7 +174,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
