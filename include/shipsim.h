@@ -36,7 +36,7 @@ typedef enum ssg_status {
 
 /* ---- limits ---- */
 #define SSG_MAX_BEAMS 16
-#define SSG_MAX_GOALS 8       /* bits 0..6 of the goal mask; bit 7 = "rudder has been moved" */
+#define SSG_MAX_GOALS 6       /* bits 0..5 of the goal mask; bit 7 = "rudder has been moved"; reference N_GOALS = 5 */
 #define SSG_MAX_HULL 12       /* game_map.gen_river_poly: 10 jittered points + 2 corners, game_map.py:22-73 */
 #define SSG_SHIP_VERTS 5      /* SHIP_TEMPLATE, models.py:6 */
 
@@ -69,12 +69,12 @@ typedef enum ssg_status {
  * (lanes of a wave sit on different maps; an even stride made such reads 8-way bank conflicts).  A 64-map bank is
  * 100 864 bytes and fits the CU's 160 KiB of LDS beside the lidar waves' scratch.
  */
-#define SSG_MAP_STRIDE 197
+#define SSG_MAP_STRIDE 193
 #define SSG_MAP_OFF_COUNTS 0
 #define SSG_MAP_OFF_AABB 2
 #define SSG_MAP_OFF_GOALS 10
-#define SSG_MAP_OFF_SPAWN_GOAL 26
-#define SSG_MAP_OFF_PLANES 28
+#define SSG_MAP_OFF_SPAWN_GOAL 22
+#define SSG_MAP_OFF_PLANES 24
 #define SSG_PLANE_DOUBLES 7
 
 typedef struct ssg_config {
@@ -87,7 +87,7 @@ typedef struct ssg_config {
     int32_t n_beams;       /* 1..SSG_MAX_BEAMS; reference LiDAR default 10 */
     int32_t history;       /* EnvConfig.HISTORY_SIZE; 1 or 2 in ABI v1 */
     int32_t max_steps;     /* EnvConfig.MAX_STEPS */
-    int32_t n_goals;       /* N_GOALS = 5, game.py:17; <= 7 */
+    int32_t n_goals;       /* N_GOALS = 5, game.py:17; <= SSG_MAX_GOALS */
     double lidar_spread_deg; /* 90 */
     double lidar_dist;       /* 100 */
     double goal_radius;      /* 5, game.py:82 */

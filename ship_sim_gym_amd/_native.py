@@ -10,9 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libshipsim.so")
 
 ABI_VERSION = 1
-MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS = 16, 8, 12, 5
-MAP_STRIDE = 197
-MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 26, 28, 7
+MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS = 16, 6, 12, 5
+MAP_STRIDE = 193
+MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 7
 FLAG_AUTO_RESET, FLAG_FIX_COLLISION_REWARD, FLAG_BANK_IN_GLOBAL, FLAG_EXACT_LIDAR = 0x1, 0x2, 0x4, 0x8
 EV_COLLIDING, EV_GOAL_REACHED, EV_OUT_OF_BOUNDS, EV_MAX_STEPS, EV_NO_GOALS_LEFT = 0x1, 0x2, 0x4, 0x8, 0x10
 (F_X, F_Y, F_VX, F_VY, F_ANGLE, F_W, F_CUM_REWARD, F_LIDAR, F_RUDDER, F_STEP_COUNT, F_MAP_ID, F_GOAL_MASK,

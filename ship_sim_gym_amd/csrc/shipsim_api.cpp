@@ -386,7 +386,7 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     // ship_env.py:46-47 raises ValueError("history_size must be greater than zero")
     if (cfg->history < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "history_size must be greater than zero");
     if (cfg->history > 2) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: history > 2 is not supported by ABI v1");
-    if (cfg->n_goals < 1 || cfg->n_goals > 7) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_goals must be in 1..7");
+    if (cfg->n_goals < 1 || cfg->n_goals > SSG_MAX_GOALS) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_goals must be in 1..6");
     if (!(cfg->dt > 0.0)) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: dt must be > 0");
     if (cfg->max_steps < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: max_steps must be >= 1");
     ssg_handle *h = new (std::nothrow) ssg_handle();

@@ -159,7 +159,7 @@ __host__ __device__ __forceinline__ constexpr int lds_wave_scratch_bytes(int nb)
 }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-constexpr int kGoalScratchBytes = 64 * 8 * 2 + 64 * 4; // per goals wave: pair queue (u16) + per-lane consumed-goal masks
+constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
     return kBeamTabBytes + kShipTabBytes + 3 * epw * 8 + epw * 4 + (epw / 64) * kGoalScratchBytes;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // Every (lane, goal) pair that passes the bounding-box reject goes into a per-wave LDS queue; the wave then
         // serves 12 pairs at a time, lane L = 5*p + i on (pair p, ship edge i).
         unsigned short *gq = reinterpret_cast<unsigned short *>(goal_scratch0 + (tl >> 6) * kGoalScratchBytes);
-        unsigned *gw = reinterpret_cast<unsigned *>(gq + 64 * 8);
+        unsigned *gw = reinterpret_cast<unsigned *>(gq + 64 * SSG_MAX_GOALS);
         gw[lane] = 0u;
         int n_pairs = 0;
         for (int g = 0; g < c.n_goals; ++g) {
