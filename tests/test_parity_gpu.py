@@ -281,3 +281,18 @@ def test_vec_env_protocols(torch_cuda, native):
         class E(EnvConfig):
             HISTORY_SIZE = 0
         _vec(4, env_config=E)
+
+
+def test_curriculum_maps_switch_banks(torch_cuda, oracle, native):
+    """BASELINE configs[3]'s "curriculum maps": a lesson change installs the next width's bank and resets; the HIP
+    path on the new bank still matches the oracle on the same bank."""
+    from ship_sim_gym_amd.curriculum import CurriculumMaps
+    vec = _vec(512, n_maps=8)
+    cm = CurriculumMaps(vec, widths=(0.5, 0.7), conditions=(0.0,), repeat_condition=0, n_maps=8)
+    assert cm.width_frac == 0.5 and cm.progress(-1.0) is None
+    obs = cm.progress(1.0)
+    assert obs is not None and cm.width_frac == 0.7 and cm.progress(5.0) is None
+    # wider banks: left-bank hull reaches further into the river than at width 0.5
+    assert float(vec.bank[:, 4].max()) > 150.0 + 1e-9
+    err, n_done = run_pair(oracle, native, vec, K=150)
+    assert err <= ATOL and n_done > 50
