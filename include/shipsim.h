@@ -39,6 +39,7 @@ typedef enum ssg_status {
 #define SSG_MAX_GOALS 6       /* bits 0..5 of the goal mask; bit 7 = "rudder has been moved"; reference N_GOALS = 5 */
 #define SSG_MAX_HULL 12       /* game_map.gen_river_poly: 10 jittered points + 2 corners, game_map.py:22-73 */
 #define SSG_SHIP_VERTS 5      /* SHIP_TEMPLATE, models.py:6 */
+#define SSG_MAX_HISTORY 8
 
 /* ---- flags ---- */
 #define SSG_FLAG_AUTO_RESET        0x1u /* VecEnv semantics: a done env is reset inside ssg_step and the returned
@@ -85,7 +86,8 @@ typedef struct ssg_config {
     int64_t env_id_base;   /* global id of local env 0: keys the action stream and default map assignment */
     /* EnvConfig / LiDAR (config.py:14-17, models.py:29) */
     int32_t n_beams;       /* 1..SSG_MAX_BEAMS; reference LiDAR default 10 */
-    int32_t history;       /* EnvConfig.HISTORY_SIZE; 1 or 2 in ABI v1 */
+    int32_t history;       /* EnvConfig.HISTORY_SIZE, 1..SSG_MAX_HISTORY (reference default 2); above 2 every step is its own
+                              launch followed by a frame-shift kernel (the fused rollout path needs history <= 2) */
     int32_t max_steps;     /* EnvConfig.MAX_STEPS */
     int32_t n_goals;       /* N_GOALS = 5, game.py:17; <= SSG_MAX_GOALS */
     double lidar_spread_deg; /* 90 */

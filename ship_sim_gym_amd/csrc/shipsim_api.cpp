@@ -17,7 +17,7 @@ struct ssg_handle {
     ssg_config cfg;
     ssg::DevCfg dev{};
     int n_pad = 0;
-    size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, nbytes = 0;
+    size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, nbytes = 0;
     void *state = nullptr;
     const double *bank = nullptr;
     int n_maps = 0;
@@ -244,7 +244,8 @@ void refresh_dev(ssg_handle *h)
     d.n_pad = h->n_pad;
     d.env_id_base = c.env_id_base;
     d.n_beams = c.n_beams;
-    d.history = c.history;
+    d.history = c.history < 2 ? c.history : 2;
+    d.full_history = c.history;
     d.max_steps = c.max_steps;
     d.n_goals = c.n_goals;
     d.flags = c.flags;
@@ -283,6 +284,7 @@ void refresh_dev(ssg_handle *h)
     d.f64cols = base ? reinterpret_cast<double *>(base + h->off_f64) : nullptr;
     d.i32cols = base ? reinterpret_cast<int32_t *>(base + h->off_i32) : nullptr;
     d.mask = base ? reinterpret_cast<uint8_t *>(base + h->off_mask) : nullptr;
+    d.obs2 = (base && c.history > 2) ? reinterpret_cast<double *>(base + h->off_obs2) : nullptr;
     d.bank = h->bank;
 }
 
@@ -385,7 +387,7 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_beams must be in 1..16");
     // ship_env.py:46-47 raises ValueError("history_size must be greater than zero")
     if (cfg->history < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "history_size must be greater than zero");
-    if (cfg->history > 2) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: history > 2 is not supported by ABI v1");
+    if (cfg->history > SSG_MAX_HISTORY) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: history must be <= 8");
     if (cfg->n_goals < 1 || cfg->n_goals > SSG_MAX_GOALS) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_goals must be in 1..6");
     if (!(cfg->dt > 0.0)) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: dt must be > 0");
     if (cfg->max_steps < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: max_steps must be >= 1");
@@ -398,7 +400,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     h->off_f64 = ssg::kStatsDoubles * sizeof(double);
     h->off_i32 = h->off_f64 + (size_t)(ssg::COL_LIDAR + cfg->n_beams) * np * sizeof(double);
     h->off_mask = h->off_i32 + (size_t)ssg::ICOL_COUNT * np * sizeof(int32_t);
-    h->nbytes = h->off_mask + np;
+    h->off_obs2 = (h->off_mask + np + 255) & ~(size_t)255;
+    h->nbytes = (cfg->history > 2) ? h->off_obs2 + np * (size_t)(2 * (6 + cfg->n_beams)) * sizeof(double) : h->off_mask + np;
     h->block = pick_block(cfg->n_envs);
     refresh_dev(h);
     *out = h;
@@ -517,6 +520,16 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         const int v = s ? std::atoi(s) : SSG_ROLLOUT_STEPS_PER_LAUNCH;
         return v < 1 ? 1 : v;
     }();
+    if (h->cfg.history > 2) {
+        // non-default history: one launch per step into the staging rows, then the frame shift (see the kernel)
+        for (int k = 0; k < K; ++k) {
+            hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
+                                            h->dev.obs2, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
+            if (e == hipSuccess) e = ssg::launch_history_shift(h->dev, dev_done, dev_obs, static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+        }
+        return SSG_OK;
+    }
     for (int k = 0; k < K; k += kFuse) {
         const int kk = (K - k < kFuse) ? (K - k) : kFuse;
         hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,

@@ -24,7 +24,9 @@ constexpr int kStatsDoubles = 4 * kStatsSlots;
 struct DevCfg {
     int n_envs, n_pad;
     long long env_id_base;
-    int n_beams, history, max_steps, n_goals;
+    int n_beams, history /* frames the step kernel writes: min(full_history, 2) */, max_steps, n_goals;
+    int full_history;     // EnvConfig.HISTORY_SIZE
+    double *obs2;         // [n_envs][2F] staging rows of the step kernel when full_history > 2 (inside the state blob)
     unsigned flags;
     int n_maps;
     int rudder_step, rudder_max;
@@ -46,6 +48,7 @@ size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
+hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);
 hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long env_base, int n, int32_t *out,
                                hipStream_t stream);
 

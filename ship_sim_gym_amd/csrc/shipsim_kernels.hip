@@ -927,13 +927,31 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
     c.mask[e] = (uint8_t)((1u << c.n_goals) - 1u);
     if (obs) {
         const int F = 6 + c.n_beams;
-        double *orow = obs + (size_t)e * (size_t)(F * c.history);
-        for (int i = 0; i < F * (c.history - 1); ++i) orow[i] = -1.0; // deque([-1]*n), ship_env.py:180-181
-        orow += F * (c.history - 1);
+        double *orow = obs + (size_t)e * (size_t)(F * c.full_history);
+        for (int i = 0; i < F * (c.full_history - 1); ++i) orow[i] = -1.0; // deque([-1]*n), ship_env.py:180-181
+        orow += F * (c.full_history - 1);
         orow[0] = c.spawn_x; orow[1] = c.spawn_y; orow[2] = 0.0; orow[3] = 0.0;
         orow[4] = rec[SSG_MAP_OFF_SPAWN_GOAL]; orow[5] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
         for (int i = 0; i < c.n_beams; ++i) orow[6 + i] = -1.0;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// HISTORY_SIZE > 2 (non-default; every reference script uses 2): the step kernel writes its two frames into the
+// staging rows obs2 and this kernel maintains the caller's [n_envs][H*F] rows like the reference's deque
+// (ship_env.py:113,180-181): drop the oldest frame, append the new one; an auto-reset env gets (H-1) frames of -1
+// and the spawn frame.  One lane per env, sequential over the row (a lane only reads ahead of what it writes).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void history_shift_kernel(const DevCfg c, const uint8_t *__restrict__ done, double *__restrict__ obs)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.n_envs) return;
+    const int F = 6 + c.n_beams, H = c.full_history;
+    double *row = obs + (size_t)e * (size_t)(F * H);
+    const double *nf = c.obs2 + (size_t)e * (size_t)(2 * F) + F; // newest frame (or the spawn frame after a reset)
+    const bool was_reset = done[e] && (c.flags & SSG_FLAG_AUTO_RESET);
+    for (int j = 0; j < F * (H - 1); ++j) row[j] = was_reset ? -1.0 : row[j + F];
+    for (int j = 0; j < F; ++j) row[F * (H - 1) + j] = nf[j];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1078,6 +1096,13 @@ hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map
 {
     const int block = 256, grid = (c.n_envs + block - 1) / block;
     hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(block), 0, stream, c, mask, map_ids, obs);
+    return hipGetLastError();
+}
+
+hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream)
+{
+    const int block = 256, grid = (c.n_envs + block - 1) / block;
+    hipLaunchKernelGGL(history_shift_kernel, dim3(grid), dim3(block), 0, stream, c, done, obs);
     return hipGetLastError();
 }
 

@@ -68,7 +68,7 @@ def test_create_validates_and_reports(native):
     c.history = 0
     rc = L.ssg_create(C.byref(c), C.byref(h))
     assert rc < 0 and b"history_size must be greater than zero" in L.ssg_last_error(None)  # ship_env.py:46-47
-    for field, bad in (("n_beams", 0), ("n_beams", 17), ("n_envs", 0), ("n_goals", 7), ("struct_size", 4), ("history", 3)):
+    for field, bad in (("n_beams", 0), ("n_beams", 17), ("n_envs", 0), ("n_goals", 7), ("struct_size", 4), ("history", 9)):
         c = native.default_config()
         setattr(c, field, bad)
         assert L.ssg_create(C.byref(c), C.byref(h)) < 0, field
