@@ -316,3 +316,59 @@ def test_history_sizes_parity(torch_cuda, oracle, native):
             a.step_tensor(acts[k])
         b.rollout_tensor(acts)
         assert torch_cuda.equal(a.obs, b.obs) and torch_cuda.equal(a.state, b.state)
+
+
+def test_edge_configurations(torch_cuda, oracle, native):
+    """Edges: a one-map bank, a one-step episode limit, 16 beams (gathers the bank from L2: does not fit LDS at 256
+    envs per workgroup), a single beam, bounds 1000 with the RLlib script's SPEED 40, FIX_COLLISION_REWARD."""
+    from ship_sim_gym_amd.config import EnvConfig, GameConfig
+
+    class E1(EnvConfig):
+        MAX_STEPS = 1
+    v = _vec(130, env_config=E1, n_maps=1)
+    err, n_done = run_pair(oracle, native, v, K=5)
+    assert n_done == 130 * 5 and err <= ATOL          # every step ends an episode; auto-reset onto the same single map
+
+    for nb in (1, 16):
+        v = _vec(70000 if nb == 16 else 200, n_maps=64, n_beams=nb)
+        acts = v.random_actions(3, 0, 40)
+        v.reset_tensor(); v.rollout_tensor(acts)
+        small = _vec(200, n_maps=64, n_beams=nb)
+        err, n_done = run_pair(oracle, native, small, K=80)
+        assert err <= ATOL
+        # the big run and the small run agree on the envs they share (same global ids, same actions)
+        small2 = _vec(200, n_maps=64, n_beams=nb)
+        small2.reset_tensor(); small2.rollout_tensor(small2.random_actions(3, 0, 40))
+        assert torch_cuda.equal(v.obs[:200], small2.obs)
+
+    class G(GameConfig):
+        SPEED = 40
+        BOUNDS = (1000, 1000)
+    v = _vec(256, game_config=G, n_maps=8)              # train/rllib/ppo.py:12-16
+    err, n_done = run_pair(oracle, native, v, K=100)
+    assert err <= ATOL and n_done > 500
+
+    v = _vec(512, n_maps=16, fix_collision_reward=True)
+    v.reset_tensor()
+    acts = v.random_actions(8, 0, 300)
+    hit = 0
+    for k in range(300):
+        _, rew, done, flags = v.step_tensor(acts[k])
+        col = (flags & native.EV_COLLIDING) != 0
+        goal = (flags & native.EV_GOAL_REACHED) != 0
+        assert torch_cuda.all(rew[col & ~goal] == -1.0)
+        hit += int((col & ~goal).sum())
+    assert hit > 20
+
+
+def test_million_envs_smoke(torch_cuda, native):
+    """BASELINE configs[4] size on ONE device (1 048 576 envs, 10 beams): runs, stays finite, statistics add up."""
+    torch = torch_cuda
+    v = _vec(1 << 20, n_maps=64, n_beams=10)
+    v.reset_tensor()
+    acts = v.random_actions(1, 0, 30)
+    eps = 0
+    for k in range(30):
+        obs, rew, done, flags = v.step_tensor(acts[k])
+        eps += int(done.sum())
+    assert bool(torch.isfinite(obs).all()) and v.stats()["episodes"] == eps and eps > 1000
