@@ -24,12 +24,20 @@ names = {
 }
 wpr = epw // 64
 acc = {r: np.zeros(len(v)) for r, v in names.items()}
+fused = int(os.environ.get("SSG_STAMP_FUSED", "1"))
 for k in range(200, 300):
-    vec.step_tensor(acts[k]); torch.cuda.synchronize()
+    if fused:
+        vec.rollout_tensor(acts[k - 50:k])   # 50 fused steps; the stamps left behind are the last iteration's
+    else:
+        vec.step_tensor(acts[k])
+    torch.cuda.synchronize()
     b = buf.cpu().numpy().astype(np.int64).reshape(-1, 4, wpr, 16)
     for r in range(4):
         m = len(names[r])
         acc[r] += np.diff(b[:, r, :, :m + 1], axis=-1).mean(axis=(0, 1))
+b3 = b[:, 3, :, :]
+print("role 3 goals fine: 2->10 bb+consts %.0f | 10->11 near tests+queue %.0f | 11->12 pair passes %.0f | 12->3 gw read+nearest goal %.0f" % (
+    (b3[..., 10] - b3[..., 2]).mean(), (b3[..., 11] - b3[..., 10]).mean(), (b3[..., 12] - b3[..., 11]).mean(), (b3[..., 3] - b3[..., 12]).mean()))
 for r in range(4):
     print("role %d" % r)
     for nme, v in zip(names[r], acc[r] / 100):
