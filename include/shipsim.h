@@ -192,6 +192,16 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev
  * Philox4x32-10 stream keyed by (seed, step0+k, env_id_base+e), uniform on Discrete(3) (ship_env.py:19). */
 int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_t *dev_actions, void *stream);
 
+/* Reset-time world generation on the device: fills dev_bank with n_maps fresh records — river
+ * banks as game_map.gen_river_poly draws them (game_map.py:22-73), hulls/planes as pm.Poly derives them, goals as
+ * gen_goal_path places them (game.py:300-330) — from a Philox4x32-10 stream keyed by (seed, map index).  NOT
+ * seed-compatible with the reference's Mersenne-Twister draws: a separate mode for refreshing the bank without the
+ * host.  dev_raw (nullable): per map 48 + 3*n_goals doubles = the raw 2x12 polygon vertices, then per goal (y, the
+ * uniform draw u, the fallback x), so a test can rebuild every record on the host and compare bit for bit.
+ * Call ssg_set_map_bank afterwards (or pass the already-installed bank pointer to refresh it in place). */
+int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *dev_bank, int n_maps, double *dev_raw,
+                      void *stream);
+
 /* Measurement aid (no reference counterpart): coalesced 8-byte-per-lane device copy of n_doubles doubles, the
  * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);

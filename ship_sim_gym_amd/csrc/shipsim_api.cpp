@@ -558,6 +558,17 @@ int ssg_debug_set_stamp_buffer(ssg_handle *h, void *dev_buf)
 }
 #endif
 
+int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *dev_bank, int n_maps, double *dev_raw,
+                      void *stream)
+{
+    if (!h || !dev_bank || n_maps < 1 || !(width_frac > 0.0) || !(width_frac <= 1.0))
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_generate_bank: bad argument");
+    hipError_t e = ssg::launch_generate_bank(seed, n_maps, h->cfg.n_goals, h->cfg.width, h->cfg.height, width_frac,
+                                             h->cfg.spawn_x, h->cfg.spawn_y, dev_bank, dev_raw, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("generate_bank launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream)
 {
     if (!dev_src || !dev_dst) return SSG_ERR_BAD_ARG;

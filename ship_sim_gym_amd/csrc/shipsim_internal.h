@@ -49,6 +49,8 @@ hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
 hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);
+hipError_t launch_generate_bank(uint64_t seed, int n_maps, int n_goals, double width, double height, double width_frac,
+                                double spawn_x, double spawn_y, double *bank, double *raw, hipStream_t stream);
 hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long env_base, int n, int32_t *out,
                                hipStream_t stream);
 

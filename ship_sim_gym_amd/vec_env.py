@@ -151,6 +151,26 @@ class ShipVecEnv(object):
             N.check(N.lib().ssg_set_map_bank(self._h, C.c_void_p(bank.data_ptr()), self.n_maps), self._h,
                     "ssg_set_map_bank")
 
+    def regenerate_bank(self, seed, width_frac=None, n_maps=None, return_raw=False):
+        """Refresh the map bank ON THE DEVICE (no host geometry, no upload): n_maps brand-new rivers and goal paths
+        from a Philox stream keyed by (seed, map index).  Not seed-compatible with the reference's python/numpy RNG —
+        use the host `worldgen` path for that.  Envs keep their map ids; the new geometry applies from the next step
+        on, so callers normally follow with reset_tensor()."""
+        torch = _torch()
+        n_maps = self.n_maps if n_maps is None else int(n_maps)
+        wf = self.width_frac if width_frac is None else float(width_frac)
+        with torch.cuda.device(self.device):
+            bank = self.bank if n_maps == self.n_maps else torch.empty((n_maps, N.MAP_STRIDE), dtype=torch.float64,
+                                                                      device=self.device)
+            raw = torch.empty((n_maps, 48 + 3 * self.cfg.n_goals), dtype=torch.float64, device=self.device) if return_raw else None
+            N.check(N.lib().ssg_generate_bank(self._h, int(seed), wf, C.c_void_p(bank.data_ptr()), n_maps,
+                                              C.c_void_p(raw.data_ptr()) if raw is not None else None, self._stream()),
+                    self._h, "ssg_generate_bank")
+        self.bank_polys = self.bank_goals = None  # host copies no longer describe the bank
+        if bank is not self.bank:
+            self.set_bank(bank)
+        return raw
+
     def field(self, fid):
         """Typed torch view [n_columns, num_envs] (or [num_envs]) into the state blob."""
         torch = _torch()

@@ -385,3 +385,35 @@ def test_trainer_glue_runs_end_to_end(torch_cuda, native):
     hist = mod.train(envs=1024, updates=3, horizon=32, log=lines.append)
     assert len(hist) == 3 and all(np.isfinite(h[1]) and np.isfinite(h[3]) for h in hist)
     assert "env-steps/s" in lines[-1]
+
+
+def test_device_bank_generation_matches_host_geometry(torch_cuda, oracle, native):
+    """records generated on the device (ssg_generate_bank) are, bit for bit, what the host path
+    builds from the same raw polygons and goal draws; the draws respect gen_river_poly's ranges; the env steps on a
+    device-generated bank exactly like the oracle fed the same polygons and goals."""
+    from ship_sim_gym_amd import worldgen
+    vec = _vec(512, n_maps=32)
+    raw = vec.regenerate_bank(seed=99, return_raw=True).cpu().numpy()
+    bank = vec.bank.cpu().numpy()
+    polys = raw[:, :48].reshape(32, 2, 12, 2)
+    goals = np.zeros((32, 5, 2))
+    for m in range(32):
+        bare = worldgen.build_record(polys[m, 0], polys[m, 1], np.zeros((0, 2)), (300.0, 25.0))
+        for i in range(5):
+            y, u, fb = raw[m, 48 + 3 * i: 51 + 3 * i]
+            hit, lo, hi = worldgen.goal_x_range(bare, 600.0, y)
+            goals[m, i] = [lo + (hi - lo) * u if hit else fb, y]
+            assert 100 * (i + 1) - 20 <= y <= 100 * (i + 1) + 20 and 0 <= u < 1
+        rec = worldgen.build_record(polys[m, 0], polys[m, 1], goals[m], (300.0, 25.0))
+        np.testing.assert_array_equal(bank[m], rec)
+        # game_map.py:22-73 ranges: left bank x in [0, 150], right in [450, 600]; corners appended last
+        assert np.all((polys[m, 0, :10, 0] >= 0) & (polys[m, 0, :10, 0] <= 150))
+        assert np.all((polys[m, 1, :10, 0] >= 450) & (polys[m, 1, :10, 0] <= 600))
+        assert polys[m, 0, 10:].tolist() == [[0, 600], [0, 0]] and polys[m, 1, 10:].tolist() == [[600, 600], [600, 0]]
+    assert len({tuple(bank[m, :4]) for m in range(32)}) == 32  # all maps differ
+    other = _vec(64, n_maps=32)
+    other.regenerate_bank(seed=100)
+    assert not torch_cuda.equal(other.bank, vec.bank)
+    vec.bank_polys, vec.bank_goals = polys, goals
+    err, n_done = run_pair(oracle, native, vec, K=150)
+    assert err <= ATOL and n_done > 50
