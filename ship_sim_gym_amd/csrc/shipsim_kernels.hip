@@ -501,11 +501,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el];
         gm = c.mask[el];
         map_id = colMap[el];
-        cum = colCum[el];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) lid[i] = colLid[(size_t)i * np + el];
         rudder = colRud[el];
-        steps = colStep[el];
     }
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
 
@@ -740,6 +736,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     __syncthreads(); // barrier 2: lidar results, force/torque and the goal results are complete
     SSG_STAMP(5);
 
+    {
+        // the columns only needed to close the step are (re)read here instead of being carried through the goal
+        // narrowphase in registers; the index is laundered again so their addresses are not computed (and kept) early
+        int el2 = el_;
+        asm volatile("" : "+v"(el2));
+        cum = ld_f64(colCum + el2, fresh);
+        steps = ld_i32(colStep + el2, fresh);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) lid[i] = ld_f64(colLid + (size_t)i * np + el2, fresh);
+    }
     const bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
 
     // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role 0 accumulated; forces are
