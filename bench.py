@@ -38,7 +38,7 @@ def algorithmic_bytes(n_ships, nb, hist):
     return 96 * n_ships + 8 + 8 + 2 + 80 + 4 + 4 + 16 * nb + 8 * (6 + nb) + 8 * hist * (6 + nb) + 9
 
 
-def cpu_baseline(vec, seconds_target=12.0):
+def cpu_baseline(vec, seconds_target=6.0):
     """Time the CPU oracle on a bounded sample of the same workload: same bank, same Philox action stream."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
