@@ -1079,13 +1079,14 @@ size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
     return b;
 }
 
-// Raise the dynamic-LDS cap of the selected instantiation once (whenever the bank size changes).
+// Raise the dynamic-LDS cap of the selected instantiation to the CU's whole 160 KiB.  The attribute belongs to the
+// kernel function, not to a handle: setting it to one handle's need would lower it under another handle's feet.
 hipError_t prepare_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes)
 {
     step_fn_t k = step_fn(c.n_beams, epw, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
     if (!k) return hipErrorInvalidValue;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds_bytes);
+    if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions, int K, double *obs,

@@ -417,3 +417,21 @@ def test_device_bank_generation_matches_host_geometry(torch_cuda, oracle, native
     vec.bank_polys, vec.bank_goals = polys, goals
     err, n_done = run_pair(oracle, native, vec, K=150)
     assert err <= ATOL and n_done > 50
+
+
+def test_two_handles_with_different_bank_sizes_interleave(torch_cuda, native):
+    """The dynamic-LDS cap is a property of the kernel, not of a handle: a small-bank handle created after a
+    big-bank one must not break the big one's launches."""
+    big = _vec(65536, n_maps=64, n_beams=8)
+    big.reset_tensor(); big.step_tensor(big.random_actions(1, 0, 1)[0])
+    small = _vec(65536, n_maps=2, n_beams=8)
+    small.reset_tensor(); small.step_tensor(small.random_actions(1, 0, 1)[0])
+    ref = _vec(65536, n_maps=64, n_beams=8)
+    ref.reset_tensor()
+    acts = ref.random_actions(1, 0, 3)
+    for k in range(3):
+        ref.step_tensor(acts[k])
+    for k in range(1, 3):
+        big.step_tensor(acts[k])
+    torch_cuda.cuda.synchronize()
+    assert torch_cuda.equal(big.obs, ref.obs)
