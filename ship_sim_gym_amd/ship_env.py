@@ -119,8 +119,13 @@ class ShipEnv(_GymEnv):
         np.random.seed(seed)  # ship_env.py:57-59
         return [seed]
 
-    def reset(self):
+    def reset(self, spawn_point=None, goals=None):
+        """ShipEnv.reset (ship_env.py:171-184).  Extensions for scenario tests, mirroring what the reference's own
+        (older-API) tests did with `reset(spawn_point=...)` and `game.add_goal(x, y)` (tests/test_ship_env.py:26-38):
+        `goals` replaces the generated goal path with the given N_GOALS centres, `spawn_point` moves the ship."""
         obs = self._vec.reset()[0]
+        if goals is not None or spawn_point is not None:
+            obs = self._override(obs, spawn_point, goals)
         self.last_action = None
         self.reward = 0
         self.cumulative_reward = 0
@@ -128,6 +133,27 @@ class ShipEnv(_GymEnv):
         self.episodes_count += 1
         self._last_flags = 0
         self.states = obs
+        return obs
+
+    def _override(self, obs, spawn_point, goals):
+        import torch
+        from . import worldgen
+        v = self._vec
+        polys, g0 = v.worlds[0]
+        g = np.asarray(goals if goals is not None else g0, dtype=np.float64).reshape(v.cfg.n_goals, 2)
+        sp = (float(spawn_point[0]), float(spawn_point[1])) if spawn_point is not None else (v.cfg.spawn_x, v.cfg.spawn_y)
+        v.worlds[0] = (polys, g)
+        v.bank_host[0] = worldgen.build_record(polys[0], polys[1], g, sp)
+        v.bank.copy_(torch.from_numpy(v.bank_host))
+        v.field(N.F_X)[0] = sp[0]
+        v.field(N.F_Y)[0] = sp[1]
+        obs = obs.copy()
+        F = self.n_states
+        obs[-F + 0], obs[-F + 1] = sp
+        obs[-F + 4] = v.bank_host[0][N.MAP_OFF_SPAWN_GOAL]      # closest_goal from the new position
+        obs[-F + 5] = v.bank_host[0][N.MAP_OFF_SPAWN_GOAL + 1]
+        v.obs[0].copy_(torch.from_numpy(obs))
+        torch.cuda.synchronize()
         return obs
 
     def step(self, action):
