@@ -61,6 +61,30 @@ def cpu_baseline(vec, seconds_target=6.0):
                       "%.1f s" % (n, K, dt)}
 
 
+def measured_copy_gbps(dev, stream_ptr=None):
+    """SURVEY.md §8(d) "measured roofline": our own 8-byte-per-lane device-to-device copy (the step kernel's access
+    width) over 2 x 1 GiB on the same GPU in the same run; returns (read + write) GB/s, best of 5."""
+    import ctypes as C
+    import torch
+    from ship_sim_gym_amd import _native as N
+    nd = (1 << 30) // 8
+    a = torch.ones(nd, dtype=torch.float64, device=dev)
+    b = torch.empty_like(a)
+    L = N.lib()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    best = 0.0
+    for it in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        N.check(L.ssg_debug_copy8(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), nd, sp), None, "copy8")
+        e1.record()
+        torch.cuda.synchronize()
+        if it > 0:
+            best = max(best, 2.0 * nd * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +178,7 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")  # rocprofv3 PMC, same command (profiles/)
             except Exception:
                 traffic = None
+        copy_gbps = measured_copy_gbps(dev)
         out = {
             "metric": "env steps/sec (batched ShipEnv)", "value": total_steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
@@ -164,6 +189,7 @@ def main():
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                          "kernel": "ssg::step_kernel<8, 256, true, false>", "algorithmic_bytes_per_env_step": B,
                          "steps_per_launch": K / n_launch, "avg_launch_us": launch_s * 1e6,
                          "us_per_step_in_launch": launch_s * 1e6 * n_launch / K},

@@ -14,6 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libssg_oracle.so")
 
 MAX_VERTS, MAX_GOALS, MAX_BEAMS, MAX_HISTORY = 16, 8, 32, 8
 PEEK_LEN = 19
+PEEK_DYN_LEN = 6 * 3 + 4 * 5 + 2
 PEEK_FIELDS = ("x", "y", "vx", "vy", "angle", "w", "rudder", "step_count", "n_goals_alive", "colliding",
                "goal_reached", "map_id", "cumulative_reward", "alive_mask", "episodes", "bb_l", "bb_b", "bb_r",
                "bb_t")
@@ -41,7 +42,7 @@ class Config(C.Structure):
                 ("ship_w", C.c_double), ("ship_h", C.c_double), ("ship_mass", C.c_double), ("force_y", C.c_double),
                 ("rudder_step", C.c_int), ("rudder_max", C.c_int),
                 ("thrust_px0", C.c_double), ("thrust_py0", C.c_double),
-                ("spawn_x", C.c_double), ("spawn_y", C.c_double)]
+                ("spawn_x", C.c_double), ("spawn_y", C.c_double), ("n_traffic", C.c_int)]
 
 
 class Bank(C.Structure):
@@ -51,7 +52,7 @@ class Bank(C.Structure):
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                              for f in ("ssg_oracle.c", "ssg_oracle.h", "Makefile"))):
+                                              for f in ("ssg_oracle.c", "ssg_dynamics.c", "ssg_oracle.h", "ssg_vec.h", "Makefile"))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return _LIB_PATH
 
@@ -87,6 +88,14 @@ def lib():
         L.ora_goal_x_range.argtypes = [C.c_void_p, C.c_double, dp, dp]
         L.ora_world_step.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(C.c_uint8)]
         L.ora_world_peek.argtypes = [C.c_void_p, dp]
+        L.ora_world_peek_dyn.argtypes = [C.c_void_p, dp]
+        L.ora_world_poke_traffic.argtypes = [C.c_void_p, C.c_int, dp]
+        L.ora_collide_poly_poly.restype = C.c_int
+        L.ora_collide_poly_poly.argtypes = [C.POINTER(Poly), C.POINTER(Poly), C.c_int, C.c_int, C.POINTER(V2),
+                                            C.POINTER(V2), C.POINTER(V2), C.POINTER(C.c_uint32), dp]
+        L.ora_collide_circle_poly.restype = C.c_int
+        L.ora_collide_circle_poly.argtypes = [V2, C.c_double, C.POINTER(Poly), C.POINTER(V2), C.POINTER(V2),
+                                              C.POINTER(V2), dp]
         L.ora_world_at.restype = C.c_void_p
         L.ora_world_at.argtypes = [C.c_void_p, C.c_int]
         L.ora_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -188,6 +197,34 @@ class World:
         lib().ora_world_peek(self._p, _dp(out))
         return dict(zip(PEEK_FIELDS, out.tolist()))
 
+    def peek_dyn(self):
+        return _peek_dyn(self._p)
+
+    def poke_traffic(self, k, x, y, angle=0.0, vx=0.0, vy=0.0, w=0.0):
+        lib().ora_world_poke_traffic(self._p, int(k), _dp(np.array([x, y, angle, vx, vy, w], dtype=np.float64)))
+
+
+def _peek_dyn(p):
+    """config 4 bodies: {'traffic': [3][x,y,angle,vx,vy,w], 'goals': [5][x,y,vx,vy], 'in_space': mask, 'arbiters': n}"""
+    out = np.empty(PEEK_DYN_LEN)
+    lib().ora_world_peek_dyn(p, _dp(out))
+    return {"traffic": out[:18].reshape(3, 6).copy(), "goals": out[18:38].reshape(5, 4).copy(),
+            "in_space": int(out[38]), "arbiters": int(out[39])}
+
+
+def collide_poly_poly(a, b, slot_a=8, slot_b=0):
+    """cpCollide(poly, poly) restated: (count, n, [p1], [p2], [hash], gjk distance)."""
+    n, p1, p2, h, d = V2(), (V2 * 2)(), (V2 * 2)(), (C.c_uint32 * 2)(), C.c_double()
+    cnt = lib().ora_collide_poly_poly(C.byref(a), C.byref(b), slot_a, slot_b, C.byref(n), p1, p2, h, C.byref(d))
+    return cnt, (n.x, n.y), [(p1[i].x, p1[i].y) for i in range(cnt)], [(p2[i].x, p2[i].y) for i in range(cnt)], \
+        [h[i] for i in range(cnt)], d.value
+
+
+def collide_circle_poly(c, r, poly):
+    n, p1, p2, d = V2(), V2(), V2(), C.c_double()
+    cnt = lib().ora_collide_circle_poly(V2(*c), float(r), C.byref(poly), C.byref(n), C.byref(p1), C.byref(p2), C.byref(d))
+    return cnt, (n.x, n.y), (p1.x, p1.y), (p2.x, p2.y), d.value
+
 
 class Batch:
     """N oracle worlds over a map bank with VecEnv auto-reset; mirrors the HIP path's bank mode."""
@@ -227,6 +264,13 @@ class Batch:
         out = np.empty(PEEK_LEN)
         lib().ora_world_peek(lib().ora_world_at(self._p, int(i)), _dp(out))
         return dict(zip(PEEK_FIELDS, out.tolist()))
+
+    def peek_dyn(self, i):
+        return _peek_dyn(lib().ora_world_at(self._p, int(i)))
+
+    def poke_traffic(self, i, k, x, y, angle=0.0, vx=0.0, vy=0.0, w=0.0):
+        lib().ora_world_poke_traffic(lib().ora_world_at(self._p, int(i)), int(k),
+                                     _dp(np.array([x, y, angle, vx, vy, w], dtype=np.float64)))
 
     def peek_all(self):
         out = np.empty((self.n, PEEK_LEN))

@@ -30,32 +30,7 @@
 #include <omp.h>
 #endif
 
-/* ------------------------------------------------------------------------------------------------
- * cpVect helpers (chipmunk/cpVect.h)
- * ---------------------------------------------------------------------------------------------- */
-static inline ora_v2 V(double x, double y) { ora_v2 r = {x, y}; return r; }
-static inline ora_v2 vadd(ora_v2 a, ora_v2 b) { return V(a.x + b.x, a.y + b.y); }
-static inline ora_v2 vsub(ora_v2 a, ora_v2 b) { return V(a.x - b.x, a.y - b.y); }
-static inline ora_v2 vmult(ora_v2 a, double s) { return V(a.x * s, a.y * s); }
-static inline double vdot(ora_v2 a, ora_v2 b) { return a.x * b.x + a.y * b.y; }
-static inline double vcross(ora_v2 a, ora_v2 b) { return a.x * b.y - a.y * b.x; }
-static inline ora_v2 vrperp(ora_v2 a) { return V(a.y, -a.x); }
-static inline double vlength(ora_v2 a) { return sqrt(vdot(a, a)); }
-static inline ora_v2 vlerp(ora_v2 a, ora_v2 b, double t) { return vadd(vmult(a, 1.0 - t), vmult(b, t)); }
-static inline ora_v2 vnormalize(ora_v2 a) { return vmult(a, 1.0 / (vlength(a) + DBL_MIN)); }
-static inline double vdist(ora_v2 a, ora_v2 b) { return vlength(vsub(a, b)); }
-static inline double fclamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
-
-/* cpTransformPoint / cpTransformVect for the rigid transform built by cpBody SetTransform with cog=(0,0):
- *   a = rot.x, b = rot.y, c = -rot.y, d = rot.x, tx = p.x, ty = p.y                                 */
-static inline ora_v2 xf_point(ora_v2 p, ora_v2 rot, ora_v2 v)
-{
-    return V(rot.x * v.x + (-rot.y) * v.y + p.x, rot.y * v.x + rot.x * v.y + p.y);
-}
-static inline ora_v2 xf_vect(ora_v2 rot, ora_v2 v)
-{
-    return V(rot.x * v.x + (-rot.y) * v.y, rot.y * v.x + rot.x * v.y);
-}
+#include "ssg_vec.h"
 
 /* ------------------------------------------------------------------------------------------------
  * cpConvexHull (QuickHull, tol = 0): CCW hull, first vertex = lexicographic (x, then y) minimum,
@@ -400,6 +375,7 @@ void ora_world_reset(ora_world *w, const double *left_xy, const double *right_xy
     w->reward = 0; w->cumulative_reward = 0; w->step_count = 0;
     int total = w->n_states * c->history;
     for (int i = 0; i < total; i++) w->states[i] = DEFAULT_STATE_VAL;
+    if (c->n_traffic > 0) ora_dyn_reset(w); /* env.game.add_default_traffic() after reset (config 4) */
     add_states(w);
     if (obs_out) memcpy(obs_out, w->states, sizeof(double) * (size_t)total);
 }
@@ -456,14 +432,20 @@ static void space_step(ora_world *w)
     b->p = vadd(b->p, vmult(vadd(b->v, V(0, 0)), dt));
     b->a = b->a + (b->w + 0.0) * dt;
     b->rot = V(cos(b->a), sin(b->a));
+    const int dyn = c->n_traffic > 0;
+    int reached_mask = 0;
+    if (dyn) ora_dyn_integrate(w); /* config 4: traffic + goal bodies move in the same pass (ssg_dynamics.c) */
     /* (2) cpShapeUpdateFunc + collide */
     ora_poly_update(&w->ship_shape, b->p, b->rot);
     for (int k = 0; k < 2; k++)
         if (ora_polys_collide(&w->ship_shape, &w->bank[k])) w->colliding = 1; /* collide_ship game.py:232-241 */
+    for (int k = 0; dyn && k < c->n_traffic; k++) /* traffic ships are collision_type 1 too (models.py:100) */
+        if (ora_polys_collide(&w->ship_shape, &w->dyn.tshape[k])) w->colliding = 1;
     for (int g = 0; g < w->n_goals_alive;) {
         if (ora_circle_poly_collide(w->goal_p[g], c->goal_radius, &w->ship_shape)) {
             /* collide_goal game.py:243-257: goal dropped from the list, no physical response */
             w->goal_reached = 1;
+            reached_mask |= 1 << w->goal_id[g];
             for (int j = g; j + 1 < w->n_goals_alive; j++) { w->goal_p[j] = w->goal_p[j + 1]; w->goal_id[j] = w->goal_id[j + 1]; }
             w->n_goals_alive--;
         } else {
@@ -476,7 +458,8 @@ static void space_step(ora_world *w)
     b->w = b->w * damping + b->t * b->i_inv * dt;
     b->f = V(0, 0);
     b->t = 0.0;
-    /* (4) impulse solver: not restated (see file header) */
+    /* (4) impulse solver: not restated for the player (see file header); config 4 solves the other bodies */
+    if (dyn) ora_dyn_collide_solve(w, reached_mask);
 }
 
 static void apply_action(ora_world *w, int action)

@@ -43,6 +43,8 @@ typedef struct {
     ora_v2 p, v, f, rot;
     double a, w, t;
     double m_inv, i_inv;
+    ora_v2 v_bias;  /* cpBody.v_bias / w_bias: penetration-correction pseudo-velocities (config 4 only) */
+    double w_bias;
 } ora_body;
 
 typedef struct {
@@ -67,7 +69,46 @@ typedef struct {
     int rudder_step, rudder_max; /* rotate(+-5), max_angle=10        game.py:149-151, models.py:110 */
     double thrust_px0, thrust_py0; /* shape.bb.center() before space.add = (0,0)  models.py:109, App. A.3 */
     double spawn_x, spawn_y;  /* (BOUNDS[0]/2, 25)                   game.py:274   */
+    int n_traffic;            /* 0, or 3 = add_default_traffic() after every reset   game.py:279-286 (config 4) */
 } ora_config;
+
+/* ---- config 4 (BASELINE configs[3]): traffic ships, dynamic goal bodies, Chipmunk contact solver ----
+ * Shape slots in space-insertion order: 0,1 banks (static) | 2..6 goal circles | 7 player | 8..10 traffic.   */
+#define ORA_N_TRAFFIC 3
+#define ORA_SLOT_GOAL0 2
+#define ORA_SLOT_PLAYER 7
+#define ORA_SLOT_TRAFFIC0 8
+#define ORA_N_SLOTS 11
+#define ORA_ARB_NONE 0    /* not in space->cachedArbiters                         */
+#define ORA_ARB_FIRST 1   /* CP_ARBITER_STATE_FIRST_COLLISION                     */
+#define ORA_ARB_NORMAL 2  /* CP_ARBITER_STATE_NORMAL                              */
+#define ORA_ARB_IGNORE 3  /* CP_ARBITER_STATE_IGNORE                              */
+#define ORA_ARB_CACHED 4  /* CP_ARBITER_STATE_CACHED (separated, kept <3 stamps)  */
+
+typedef struct {           /* struct cpContact */
+    ora_v2 r1, r2;
+    double nMass, tMass, bounce, jnAcc, jtAcc, jBias, bias;
+    uint32_t hash;
+} ora_contact;
+
+typedef struct {           /* struct cpArbiter (the fields the solver reads) */
+    int state, stamp, count, a, b; /* a, b: shape slots in cpCollide's order */
+    ora_contact con[2];
+    ora_v2 n;
+    double u;              /* friction a->u * b->u; elasticity is 0 for every shape on this path */
+} ora_arbiter;
+
+typedef struct {
+    int stamp;                          /* space->stamp */
+    double prev_dt;                     /* space->curr_dt of the previous step (0 before the first) */
+    ora_body tbody[ORA_N_TRAFFIC];
+    ora_poly tshape[ORA_N_TRAFFIC];
+    ora_body gbody[ORA_MAX_GOALS];      /* goal circle bodies, by original goal index */
+    int goal_in_space;                  /* bit g: goal g's body/shape still in the space */
+    int last_arbiters;                  /* solver list length of the last step (inspection) */
+    ora_body static_body;               /* the banks' body: all zero (cpBodyNewStatic at the origin) */
+    ora_arbiter arb[ORA_N_SLOTS][ORA_N_SLOTS]; /* cachedArbiters keyed by (lower slot, higher slot) */
+} ora_dyn;
 
 typedef struct {
     ora_config cfg;
@@ -89,6 +130,7 @@ typedef struct {
     /* bank mode (auto-reset) */
     int map_id;
     int64_t episodes;
+    ora_dyn dyn;                       /* used only when cfg.n_traffic > 0 */
 } ora_world;
 
 /* ---- geometry primitives (Chipmunk restated) ---- */
@@ -116,6 +158,20 @@ int ora_world_sizeof(void);
 #define ORA_PEEK_LEN 19
 void ora_world_peek(const ora_world *w, double *out);
 ora_world *ora_world_at(ora_world *ws, int i);
+/* config 4 inspection: [T_k: x,y,angle,vx,vy,w]x3, [goal g (original index): x,y,vx,vy]x5, goal_in_space mask,
+ * number of arbiters processed by the solver in the last step */
+#define ORA_PEEK_DYN_LEN (6 * ORA_N_TRAFFIC + 4 * 5 + 2)
+void ora_world_peek_dyn(const ora_world *w, double *out);
+/* ---- config 4 internals (ssg_dynamics.c), called by ora_world_reset / space_step ---- */
+void ora_world_poke_traffic(ora_world *w, int k, const double *v6 /* x,y,angle,vx,vy,w */);
+void ora_dyn_reset(ora_world *w);
+void ora_dyn_integrate(ora_world *w);
+void ora_dyn_collide_solve(ora_world *w, int reached_mask);
+/* narrowphase exposed for unit tests: cpCollide(a, b) restated.  Returns the contact count (0..2) and fills
+ * n, and per contact the absolute points p1/p2 and the hash. */
+int ora_collide_poly_poly(const ora_poly *a, const ora_poly *b, int slot_a, int slot_b, ora_v2 *n, ora_v2 *p1,
+                          ora_v2 *p2, uint32_t *hash, double *dist);
+int ora_collide_circle_poly(ora_v2 c, double r, const ora_poly *b, ora_v2 *n, ora_v2 *p1, ora_v2 *p2, double *dist);
 void ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 /* ---- batched driver with a map bank and auto-reset (VecEnv semantics), OpenMP over envs ---- */
