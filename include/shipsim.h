@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 1
+#define SSG_ABI_VERSION 2 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4) */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -40,6 +40,7 @@ typedef enum ssg_status {
 #define SSG_MAX_HULL 12       /* game_map.gen_river_poly: 10 jittered points + 2 corners, game_map.py:22-73 */
 #define SSG_SHIP_VERTS 5      /* SHIP_TEMPLATE, models.py:6 */
 #define SSG_MAX_HISTORY 8
+#define SSG_N_TRAFFIC 3       /* ShipGame.add_default_traffic, game.py:279-286 */
 
 /* ---- flags ---- */
 #define SSG_FLAG_AUTO_RESET        0x1u /* VecEnv semantics: a done env is reset inside ssg_step and the returned
@@ -59,14 +60,14 @@ typedef enum ssg_status {
  * Map bank record: SSG_MAP_STRIDE doubles per map, built on the host by ssg_host_build_map().
  *   [0] nL  [1] nR                      hull plane counts (as doubles)
  *   [2..5]  left  hull AABB l,b,r,t     [6..9] right hull AABB
- *   [10..26)  goal centres x0,y0,x1,y1,...  (SSG_MAX_GOALS pairs)
- *   [26] [27] the goal nearest to the spawn point (the reset observation's goal, ship_env.py:102-108)
- *   [28 + 7*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax       j < 12
- *   [112 + 7*j ..) right plane j
+ *   [10..22)  goal centres x0,y0,x1,y1,...  (SSG_MAX_GOALS pairs)
+ *   [22] [23] the goal nearest to the spawn point (the reset observation's goal, ship_env.py:102-108)
+ *   [24 + 7*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax       j < 12
+ *   [108 + 7*j ..) right plane j
  * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180); v0.n, dtMin =
  * cross(n, v[j-1]) and dtMax = cross(n, v[j]) are the per-plane constants cpPolyShapeSegmentQuery derives.
- *   [196] spare
- * 197 doubles: an ODD stride in 8-byte units, so the same field of different maps falls on different LDS banks
+ *   [192] spare
+ * 193 doubles: an ODD stride in 8-byte units, so the same field of different maps falls on different LDS banks
  * (lanes of a wave sit on different maps; an even stride made such reads 8-way bank conflicts).  A 64-map bank is
  * 100 864 bytes and fits the CU's 160 KiB of LDS beside the lidar waves' scratch.
  */
@@ -105,6 +106,11 @@ typedef struct ssg_config {
     double force_y;                          /* force_vector = (0,100) */
     double thrust_px0, thrust_py0;           /* point_of_thrust before the first rotate(), models.py:109 */
     int32_t rudder_step, rudder_max;         /* 5, 10 */
+    /* config 4 (BASELINE configs[3]) */
+    int32_t n_ships;       /* 1 (default), or 4 = the player + ShipGame.add_default_traffic() after every reset
+                              (game.py:279-286): goal bodies become dynamic and Chipmunk's contact solver runs for the
+                              traffic ships and goals; every step is then two launches (no fused rollout) */
+    int32_t reserved0;
 } ssg_config;
 
 typedef struct ssg_handle ssg_handle;
@@ -121,6 +127,10 @@ typedef enum ssg_field {
     SSG_F_STATS,                                                   /* i64 [256 slots][4] per handle, to be summed
                                                                       over slots: 100*sum_return, sum_length,
                                                                       n_episodes, n_goals_hit */
+    SSG_F_TRAFFIC,      /* f64 x 27, n_ships == 4 only: ship k = columns 9k..9k+8: x, y, angle, vx, vy, w, v_bias.x,
+                           v_bias.y, w_bias (cpBody fields of add_default_traffic's ships) */
+    SSG_F_GOAL_BODIES,  /* f64 x 8*SSG_MAX_GOALS, n_ships == 4 only: goal g = columns 8g..8g+7: x, y, vx, vy, v_bias.x,
+                           v_bias.y, w, w_bias (add_goal's dynamic circle bodies, game.py:77-95) */
     SSG_F_COUNT
 } ssg_field;
 

@@ -665,5 +665,6 @@ void ora_world_poke_traffic(ora_world *w, int k, const double *v6)
     ora_body *b = &w->dyn.tbody[k];
     b->p = V(v6[0], v6[1]); b->a = v6[2]; b->rot = V(cos(b->a), sin(b->a));
     b->v = V(v6[3], v6[4]); b->w = v6[5];
+    b->v_bias = V(0, 0); b->w_bias = 0.0;
     ora_poly_update(&w->dyn.tshape[k], b->p, b->rot);
 }

@@ -9,14 +9,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libshipsim.so")
 
-ABI_VERSION = 1
-MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS = 16, 6, 12, 5
+ABI_VERSION = 2
+MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3
 MAP_STRIDE = 193
 MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 7
 FLAG_AUTO_RESET, FLAG_FIX_COLLISION_REWARD, FLAG_BANK_IN_GLOBAL, FLAG_EXACT_LIDAR = 0x1, 0x2, 0x4, 0x8
 EV_COLLIDING, EV_GOAL_REACHED, EV_OUT_OF_BOUNDS, EV_MAX_STEPS, EV_NO_GOALS_LEFT = 0x1, 0x2, 0x4, 0x8, 0x10
 (F_X, F_Y, F_VX, F_VY, F_ANGLE, F_W, F_CUM_REWARD, F_LIDAR, F_RUDDER, F_STEP_COUNT, F_MAP_ID, F_GOAL_MASK,
- F_STATS) = range(13)
+ F_STATS, F_TRAFFIC, F_GOAL_BODIES) = range(15)
 
 # every symbol include/shipsim.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = (
@@ -43,6 +43,7 @@ class Config(C.Structure):
         ("ship_m_inv", C.c_double), ("ship_i_inv", C.c_double), ("force_y", C.c_double),
         ("thrust_px0", C.c_double), ("thrust_py0", C.c_double),
         ("rudder_step", C.c_int32), ("rudder_max", C.c_int32),
+        ("n_ships", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

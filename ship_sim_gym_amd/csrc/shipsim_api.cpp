@@ -18,6 +18,8 @@ struct ssg_handle {
     ssg::DevCfg dev{};
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, nbytes = 0;
+    size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
+    ssg::DynCfg dyn{};
     void *state = nullptr;
     const double *bank = nullptr;
     int n_maps = 0;
@@ -236,6 +238,33 @@ int set_ship(ssg_config *cfg, double ws, double hs, double mass)
     return SSG_OK;
 }
 
+// ShipGame.add_default_traffic (game.py:279-286): add_ship(x, y, width, height) -> Ship.__init__ (models.py:87-111),
+// mass = the Ship default, moment about the local origin, hull in cpConvexHull order; plus Chipmunk's space defaults.
+int set_traffic(ssg_handle *h)
+{
+    static const double kTraffic[SSG_N_TRAFFIC][4] = {{100, 200, 1, 1}, {300, 200, 1.5, 2}, {400, 350, 1, 3}};
+    ssg::DynCfg &d = h->dyn;
+    const double mass = 1.0 / h->cfg.ship_m_inv;
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        ssg_config tmp = h->cfg;
+        const int rc = set_ship(&tmp, kTraffic[k][2], kTraffic[k][3], mass);
+        if (rc != SSG_OK) return rc;
+        std::memcpy(d.thull[k], tmp.ship_hull, sizeof(d.thull[k]));
+        std::memcpy(d.tnrm[k], tmp.ship_normals, sizeof(d.tnrm[k]));
+        d.t_i_inv[k] = tmp.ship_i_inv;
+        d.tx[k] = kTraffic[k][0];
+        d.ty[k] = kTraffic[k][1];
+    }
+    d.t_m_inv = h->cfg.ship_m_inv;
+    // add_goal (game.py:77-95): mass 1, pm.moment_for_circle(1, 0, radius) = m * 0.5 * (r1^2 + r2^2)
+    d.goal_m_inv = 1.0 / 1.0;
+    d.goal_i_inv = 1.0 / (1.0 * 0.5 * (0.0 * 0.0 + h->cfg.goal_radius * h->cfg.goal_radius));
+    d.ship_friction = 0.7;                                      // models.py:98
+    d.slop = 0.1;                                               // cpSpace collisionSlop
+    d.bias_coef = 1.0 - std::pow(std::pow(1.0 - 0.1, 60.0), h->cfg.dt); // 1 - collisionBias^dt (cpSpaceStep)
+    return SSG_OK;
+}
+
 void refresh_dev(ssg_handle *h)
 {
     const ssg_config &c = h->cfg;
@@ -286,6 +315,12 @@ void refresh_dev(ssg_handle *h)
     d.mask = base ? reinterpret_cast<uint8_t *>(base + h->off_mask) : nullptr;
     d.obs2 = (base && c.history > 2) ? reinterpret_cast<double *>(base + h->off_obs2) : nullptr;
     d.bank = h->bank;
+    d.n_ships = c.n_ships;
+    const bool dyn = base && c.n_ships > 1;
+    d.dyn_f64 = dyn ? reinterpret_cast<double *>(base + h->off_dyn_f64) : nullptr;
+    d.dyn_live = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_live) : nullptr;
+    d.dyn_u32 = dyn ? reinterpret_cast<uint32_t *>(base + h->off_dyn_u32) : nullptr;
+    d.dyn_flag = dyn ? reinterpret_cast<uint8_t *>(base + h->off_dyn_flag) : nullptr;
 }
 
 
@@ -368,6 +403,7 @@ int ssg_default_config(ssg_config *cfg)
     cfg->thrust_py0 = 0.0;
     cfg->rudder_step = 5;       // game.py:149-151
     cfg->rudder_max = 10;       // models.py:110
+    cfg->n_ships = 1;           // ShipGame.reset adds the player only (game.py:274-275)
     return set_ship(cfg, 2.0, 3.0, 5.0); // game.py:275, models.py:87
 }
 
@@ -391,9 +427,14 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     if (cfg->n_goals < 1 || cfg->n_goals > SSG_MAX_GOALS) return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_goals must be in 1..6");
     if (!(cfg->dt > 0.0)) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: dt must be > 0");
     if (cfg->max_steps < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: max_steps must be >= 1");
+    if (cfg->n_ships != 0 && cfg->n_ships != 1 && cfg->n_ships != 1 + SSG_N_TRAFFIC)
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_ships must be 1 or 4 (player + add_default_traffic)");
+    if (cfg->n_ships > 1 && (cfg->flags & SSG_FLAG_EXACT_LIDAR))
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: SSG_FLAG_EXACT_LIDAR is not built for n_ships = 4");
     ssg_handle *h = new (std::nothrow) ssg_handle();
     if (!h) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: out of host memory");
     h->cfg = *cfg;
+    if (h->cfg.n_ships == 0) h->cfg.n_ships = 1;
     h->n_pad = (cfg->n_envs + ssg::kPadEnvs - 1) / ssg::kPadEnvs * ssg::kPadEnvs;
     const size_t np = (size_t)h->n_pad;
     h->off_stats = 0;
@@ -402,7 +443,17 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     h->off_mask = h->off_i32 + (size_t)ssg::ICOL_COUNT * np * sizeof(int32_t);
     h->off_obs2 = (h->off_mask + np + 255) & ~(size_t)255;
     h->nbytes = (cfg->history > 2) ? h->off_obs2 + np * (size_t)(2 * (6 + cfg->n_beams)) * sizeof(double) : h->off_mask + np;
-    h->block = pick_block(cfg->n_envs);
+    if (h->cfg.n_ships > 1) {
+        // config 4: columns of the traffic ships, goal bodies and cached arbiters (shipsim_internal.h DC_* / DU_*)
+        h->off_dyn_f64 = (h->nbytes + 255) & ~(size_t)255;
+        h->off_dyn_live = h->off_dyn_f64 + (size_t)ssg::DC_COUNT * np * sizeof(double);
+        h->off_dyn_u32 = h->off_dyn_live + np * sizeof(unsigned long long);
+        h->off_dyn_flag = h->off_dyn_u32 + (size_t)ssg::DU_COUNT * np * sizeof(uint32_t);
+        h->nbytes = h->off_dyn_flag + np;
+        const int rc = set_traffic(h);
+        if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
+    }
+    h->block = h->cfg.n_ships > 1 ? 64 : pick_block(cfg->n_envs);
     refresh_dev(h);
     *out = h;
     return SSG_OK;
@@ -436,6 +487,11 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
         off = h->off_i32 + (size_t)(field - SSG_F_RUDDER) * np * 4; es = 4; nc = 1;
     } else if (field == SSG_F_GOAL_MASK) {
         off = h->off_mask; es = 1; nc = 1;
+    } else if (field == SSG_F_TRAFFIC || field == SSG_F_GOAL_BODIES) {
+        if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
+        const int c0 = field == SSG_F_TRAFFIC ? ssg::DC_TRAFFIC : ssg::DC_GOALS;
+        off = h->off_dyn_f64 + (size_t)c0 * np * 8; es = 8;
+        nc = field == SSG_F_TRAFFIC ? 9 * SSG_N_TRAFFIC : ssg::DC_GOAL_COLS * SSG_MAX_GOALS;
     } else if (field == SSG_F_STATS) {
         // kStatsSlots rows of 4 int64 counters; sum over rows: [0] sum_return*100 [1] sum_length [2] episodes [3] goals
         off = h->off_stats; es = 8; nc = 4 * ssg::kStatsSlots;
@@ -465,7 +521,7 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
     // Envs per workgroup: start from the size preferred for this env count and halve it until the staged bank fits
     // the CU's LDS beside the lidar scratch; if even 64 does not fit, gather records from L2/HBM instead.
-    h->block = pick_block(h->cfg.n_envs);
+    h->block = h->cfg.n_ships > 1 ? 64 : pick_block(h->cfg.n_envs);
     if (!(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL))
         while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) > 160u * 1024u) h->block /= 2;
     h->bank = dev_bank;
@@ -484,6 +540,8 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
     int rc = check_ready(h, true);
     if (rc != SSG_OK) return rc;
     hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess && h->cfg.n_ships > 1) // add_default_traffic + fresh goal bodies for the reset envs
+        e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("reset launch: ") + hipGetErrorString(e));
     return SSG_OK;
 }
@@ -520,12 +578,21 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         const int v = s ? std::atoi(s) : SSG_ROLLOUT_STEPS_PER_LAUNCH;
         return v < 1 ? 1 : v;
     }();
-    if (h->cfg.history > 2) {
-        // non-default history: one launch per step into the staging rows, then the frame shift (see the kernel)
+    const bool dyn = h->cfg.n_ships > 1;
+    if (h->cfg.history > 2 || dyn) {
+        // non-default history: one launch per step into the staging rows, then the frame shift (see the kernel).
+        // config 4: every step is the dyn kernel (traffic ships, goal bodies, contact solver) followed by the step
+        // kernel, which reads this step's goal positions and the traffic-contact bit it left in the dyn columns.
+        const bool shift = h->cfg.history > 2;
         for (int k = 0; k < K; ++k) {
+            if (dyn) {
+                hipError_t e = ssg::launch_dyn_step(h->dev, h->dyn, static_cast<hipStream_t>(stream));
+                if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
+            }
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
-                                            h->dev.obs2, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
-            if (e == hipSuccess) e = ssg::launch_history_shift(h->dev, dev_done, dev_obs, static_cast<hipStream_t>(stream));
+                                            shift ? h->dev.obs2 : dev_obs, dev_reward, dev_done, dev_flags,
+                                            static_cast<hipStream_t>(stream));
+            if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, dev_done, dev_obs, static_cast<hipStream_t>(stream));
             if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
         }
         return SSG_OK;

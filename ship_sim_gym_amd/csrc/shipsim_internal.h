@@ -16,6 +16,21 @@ enum { COL_X = 0, COL_Y, COL_VX, COL_VY, COL_A, COL_W, COL_CUM, COL_LIDAR /* + n
 // i32 column indices
 enum { ICOL_RUDDER = 0, ICOL_STEP, ICOL_MAP, ICOL_COUNT };
 
+// config 4 (n_ships = 4) f64 columns of the dyn region
+enum {
+    DC_TRAFFIC = 0,                                   // 3 ships x (x, y, angle, vx, vy, w, v_bias.x, v_bias.y, w_bias)
+    DC_GOAL_COLS = 8,
+    DC_GOALS = DC_TRAFFIC + 9 * SSG_N_TRAFFIC,        // SSG_MAX_GOALS x (x, y, vx, vy, v_bias.x, v_bias.y, w, w_bias)
+    DC_ARB = DC_GOALS + DC_GOAL_COLS * SSG_MAX_GOALS, // per pair: jnAcc[2], jtAcc[2]
+    kDynPairs = 54,                                   // ship-bank 6, ship-ship 3, goal-bank 12, goal-ship 18, goal-goal 15
+    kPolyPairs = 9,                                   // the first 9 pair ids are polygon pairs (two hashed contacts)
+    DC_PREV_GOAL = DC_ARB + 4 * kDynPairs,            // (gx, gy) of the newest frame: the next observation's older frame
+    DC_COUNT = DC_PREV_GOAL + 2
+};
+// u32 columns of the dyn region
+enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* contact hashes, polygon pairs */,
+       DU_COUNT = kDynPairs + kPolyPairs };
+
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
 constexpr int kStatsDoubles = 4 * kStatsSlots;
@@ -40,6 +55,22 @@ struct DevCfg {
     double *stats;
     const double *bank;
     unsigned long long *dbg; // diagnostic builds only (-DSSG_STAMPS): per-wave s_memtime stamps
+    // config 4 (n_ships == 4): columns of the non-player bodies (shipsim_dynamics.hip); null otherwise
+    int n_ships;
+    double *dyn_f64;
+    uint32_t *dyn_u32;
+    unsigned long long *dyn_live; // bit p: pair p has a cached arbiter
+    uint8_t *dyn_flag;            // bit 0: player touches a traffic ship this step (dyn -> step kernel);
+                                  // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
+};
+
+// Constants of the traffic ships and of Chipmunk's solver, by value to the dyn kernels only.
+struct DynCfg {
+    double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS];
+    double tx[SSG_N_TRAFFIC], ty[SSG_N_TRAFFIC], t_i_inv[SSG_N_TRAFFIC], t_m_inv;
+    double goal_m_inv, goal_i_inv;
+    double ship_friction;  // 0.7 (models.py:98); banks and goals keep Chipmunk's default 0
+    double bias_coef, slop; // 1 - pow(collisionBias, dt), collisionSlop
 };
 
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions_kn, int K, double *obs,
@@ -47,6 +78,8 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
+hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream);
+hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
 hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);
 hipError_t launch_generate_bank(uint64_t seed, int n_maps, int n_goals, double width, double height, double width_frac,

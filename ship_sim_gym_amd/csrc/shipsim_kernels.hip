@@ -113,17 +113,27 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
     static_assert(THREADS * 8 >= 1024, "tail copy needs one thread per 8 bytes of a 1 KiB chunk");
 }
 
+// Goal g's centre (comp 0 = x, 1 = y).  Configs 1-3: the goal bodies never move, so the map record holds them
+// (goff = the record's goal block).  Config 4 (DYN): goals are dynamic bodies; the dyn kernel has just written this
+// step's positions into the env's goal columns (goff = env index, shipsim_dynamics.hip).
+template <bool LDS_BANK, bool DYN>
+__device__ __forceinline__ double goal_at(const DevCfg &c, int goff, int g, int comp)
+{
+    if constexpr (DYN) return c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g + comp) * (size_t)c.n_pad + goff];
+    else return bank_at<LDS_BANK>(c, goff + 2 * g + comp);
+}
+
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
-template <bool LDS_BANK>
-__device__ __forceinline__ void nearest_goal(const DevCfg &c, int rec_off, unsigned gm, double x, double y, double &gx,
+template <bool LDS_BANK, bool DYN>
+__device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned gm, double x, double y, double &gx,
                                              double &gy)
 {
     gx = -1.0;
     gy = -1.0;
     double best = INFINITY;
     for (int g = 0; g < c.n_goals; ++g) {
-        const double px = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g);
-        const double py = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g + 1);
+        const double px = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
+        const double py = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
         const double dx = px - x, dy = py - y;
         const double d = dx * dx + dy * dy; // squared distance orders exactly like Vec2d.get_distance's sqrt
         const bool take = ((gm >> g) & 1u) & (d < best); // first alive goal always beats +inf
@@ -317,7 +327,7 @@ struct PostPose {
     double x, y, ang, ca, sa, sbl, sbr, sbb, sbt;
 };
 
-template <int NB, int EPW, bool LDS_BANK, bool EXACT>
+template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
                                                        uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out,
@@ -520,6 +530,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         act = actions_kn[(size_t)k * c.n_envs + el];
     }
     const int rec_off = map_id * SSG_MAP_STRIDE;
+    const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
     const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang; // previous frame = pre-step state
     const unsigned gm0 = gm;
 
@@ -676,8 +687,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         gw[lane] = 0u;
         int n_pairs = 0;
         for (int g = 0; g < c.n_goals; ++g) {
-            const double gx = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g);
-            const double gy = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * g + 1);
+            const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
+            const double gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
             const double r = c.goal_r;
             const bool near = live & !SSG_ABL(5) & (bool)((gm >> g) & 1u) & ((gx - r) <= sbr) & (sbl <= (gx + r)) &
                               ((gy - r) <= sbt) & (sbb <= (gy + r));
@@ -692,9 +703,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const unsigned code = gq[valid ? p : 0];
             const int src = code & 63, g = code >> 6;
             const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
-            const int boff = __shfl(rec_off, src);
-            const double gx = bank_at<LDS_BANK>(c, boff + SSG_MAP_OFF_GOALS + 2 * g);
-            const double gy = bank_at<LDS_BANK>(c, boff + SSG_MAP_OFF_GOALS + 2 * g + 1);
+            const int boff = __shfl(goff, src);
+            const double gx = goal_at<LDS_BANK, DYN>(c, boff, g, 0);
+            const double gy = goal_at<LDS_BANK, DYN>(c, boff, g, 1);
             // lane = (pair p, ship edge i from vertex i-1 to vertex i)
             const double v1x = bca * w_hx + (-bsa) * w_hy + bx, v1y = bsa * w_hx + bca * w_hy + by;
             const double v0x = bca * w_px + (-bsa) * w_py + bx, v0y = bsa * w_px + bca * w_py + by;
@@ -725,12 +736,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position
     double nf_gx = 0, nf_gy = 0;
-    if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm, x, y, nf_gx, nf_gy);
+    if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, goff, gm, x, y, nf_gx, nf_gy);
     SSG_STAMP(3);
 
     // previous frame's nearest goal (oldest slot of the 2-frame history): a function of the pre-step state
     double pf_gx = 0, pf_gy = 0;
-    if (!SSG_ABL(0)) nearest_goal<LDS_BANK>(c, rec_off, gm0, pf_x, pf_y, pf_gx, pf_gy);
+    if constexpr (DYN) {
+        // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
+        pf_gx = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_];
+        pf_gy = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_];
+    } else {
+        if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, goff, gm0, pf_x, pf_y, pf_gx, pf_gy);
+    }
 
     SSG_STAMP(4);
     __syncthreads(); // barrier 2: lidar results, force/torque and the goal results are complete
@@ -746,7 +763,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 #pragma unroll
         for (int i = 0; i < NB; ++i) lid[i] = ld_f64(colLid + (size_t)i * np + el2, fresh);
     }
-    const bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
+    bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
+    if constexpr (DYN) colliding |= (c.dyn_flag[el_] & 1) != 0; // ... and against the traffic ships (dyn kernel)
 
     // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role 0 accumulated; forces are
     //      cleared afterwards.  (The narrowphase reads positions only, so doing this last changes nothing.) ----
@@ -884,6 +902,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             flags_out[el] = (uint8_t)ev;
         }
     }
+    if constexpr (DYN) {
+        if (live) {
+            c.dyn_flag[el_] = do_reset ? 2 : 0; // tells the dyn kernel to rebuild this env's traffic / goal bodies
+            c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = do_reset ? rs_gx : nf_gx;
+            c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = do_reset ? rs_gy : nf_gy;
+        }
+    }
     if (do_reset) {
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
         rudder = 0; steps = 0;
@@ -1010,43 +1035,49 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
 // (this file compiled with -DSSG_NB_GROUP=0..3, four beam counts each) so the library builds in parallel.
 // ---------------------------------------------------------------------------------------------------------
 using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *, int);
+// variant: 0 = default, 1 = SSG_FLAG_EXACT_LIDAR (beam counts 8 and 10), 2 = config 4 / DYN (64 envs per workgroup)
 
 #ifdef SSG_NB_GROUP
 template <int NB, int EPW>
-static step_fn_t step_fn_nb(bool lds, bool exact)
+static step_fn_t step_fn_nb(bool lds, int variant)
 {
     // the plane-by-plane lidar (SSG_FLAG_EXACT_LIDAR, a validation aid) is built for the two BASELINE beam counts
-    if (exact) {
-        if constexpr (NB == 8 || NB == 10) return lds ? step_kernel<NB, EPW, true, true> : step_kernel<NB, EPW, false, true>;
+    if (variant == 1) {
+        if constexpr (NB == 8 || NB == 10)
+            return lds ? step_kernel<NB, EPW, true, true, false> : step_kernel<NB, EPW, false, true, false>;
         else return nullptr;
     }
-    return lds ? step_kernel<NB, EPW, true, false> : step_kernel<NB, EPW, false, false>;
+    if (variant == 2) {
+        if constexpr (EPW == 64) return lds ? step_kernel<NB, EPW, true, false, true> : step_kernel<NB, EPW, false, false, true>;
+        else return nullptr;
+    }
+    return lds ? step_kernel<NB, EPW, true, false, false> : step_kernel<NB, EPW, false, false, false>;
 }
 
 template <int NB>
-static step_fn_t step_fn_epw(int epw, bool lds, bool exact)
+static step_fn_t step_fn_epw(int epw, bool lds, int variant)
 {
     switch (epw) {
-    case 64: return step_fn_nb<NB, 64>(lds, exact);
-    case 128: return step_fn_nb<NB, 128>(lds, exact);
-    case 256: return step_fn_nb<NB, 256>(lds, exact);
+    case 64: return step_fn_nb<NB, 64>(lds, variant);
+    case 128: return step_fn_nb<NB, 128>(lds, variant);
+    case 256: return step_fn_nb<NB, 256>(lds, variant);
     default: return nullptr;
     }
 }
 
 #define SSG_GROUP_FN_(g) step_fn_group##g
 #define SSG_GROUP_FN(g) SSG_GROUP_FN_(g)
-step_fn_t SSG_GROUP_FN(SSG_NB_GROUP)(int nb, int epw, bool lds, bool exact)
+step_fn_t SSG_GROUP_FN(SSG_NB_GROUP)(int nb, int epw, bool lds, int variant)
 {
 #ifdef SSG_GROUP_STUB /* development builds may leave a beam-count group out */
-    (void)nb; (void)epw; (void)lds; (void)exact;
+    (void)nb; (void)epw; (void)lds; (void)variant;
     return nullptr;
 #else
     switch (nb - 4 * SSG_NB_GROUP) {
-    case 1: return step_fn_epw<4 * SSG_NB_GROUP + 1>(epw, lds, exact);
-    case 2: return step_fn_epw<4 * SSG_NB_GROUP + 2>(epw, lds, exact);
-    case 3: return step_fn_epw<4 * SSG_NB_GROUP + 3>(epw, lds, exact);
-    case 4: return step_fn_epw<4 * SSG_NB_GROUP + 4>(epw, lds, exact);
+    case 1: return step_fn_epw<4 * SSG_NB_GROUP + 1>(epw, lds, variant);
+    case 2: return step_fn_epw<4 * SSG_NB_GROUP + 2>(epw, lds, variant);
+    case 3: return step_fn_epw<4 * SSG_NB_GROUP + 3>(epw, lds, variant);
+    case 4: return step_fn_epw<4 * SSG_NB_GROUP + 4>(epw, lds, variant);
     default: return nullptr;
     }
 #endif
@@ -1054,19 +1085,25 @@ step_fn_t SSG_GROUP_FN(SSG_NB_GROUP)(int nb, int epw, bool lds, bool exact)
 
 #else // main translation unit: reset / action kernels and the launch entry points
 
-step_fn_t step_fn_group0(int nb, int epw, bool lds, bool exact);
-step_fn_t step_fn_group1(int nb, int epw, bool lds, bool exact);
-step_fn_t step_fn_group2(int nb, int epw, bool lds, bool exact);
-step_fn_t step_fn_group3(int nb, int epw, bool lds, bool exact);
+step_fn_t step_fn_group0(int nb, int epw, bool lds, int variant);
+step_fn_t step_fn_group1(int nb, int epw, bool lds, int variant);
+step_fn_t step_fn_group2(int nb, int epw, bool lds, int variant);
+step_fn_t step_fn_group3(int nb, int epw, bool lds, int variant);
 
-static step_fn_t step_fn(int nb, int epw, bool lds, bool exact)
+static int variant_of(const DevCfg &c)
+{
+    if (c.n_ships > 1) return 2;
+    return (c.flags & SSG_FLAG_EXACT_LIDAR) ? 1 : 0;
+}
+
+static step_fn_t step_fn(int nb, int epw, bool lds, int variant)
 {
     if (nb < 1 || nb > SSG_MAX_BEAMS) return nullptr;
     switch ((nb - 1) / 4) {
-    case 0: return step_fn_group0(nb, epw, lds, exact);
-    case 1: return step_fn_group1(nb, epw, lds, exact);
-    case 2: return step_fn_group2(nb, epw, lds, exact);
-    default: return step_fn_group3(nb, epw, lds, exact);
+    case 0: return step_fn_group0(nb, epw, lds, variant);
+    case 1: return step_fn_group1(nb, epw, lds, variant);
+    case 2: return step_fn_group2(nb, epw, lds, variant);
+    default: return step_fn_group3(nb, epw, lds, variant);
     }
 }
 
@@ -1083,7 +1120,7 @@ size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
 // kernel function, not to a handle: setting it to one handle's need would lower it under another handle's feet.
 hipError_t prepare_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes)
 {
-    step_fn_t k = step_fn(c.n_beams, epw, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
+    step_fn_t k = step_fn(c.n_beams, epw, lds, variant_of(c));
     if (!k) return hipErrorInvalidValue;
     if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1092,7 +1129,7 @@ hipError_t prepare_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes)
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions, int K, double *obs,
                        double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream)
 {
-    step_fn_t k = step_fn(c.n_beams, epw, lds, (c.flags & SSG_FLAG_EXACT_LIDAR) != 0);
+    step_fn_t k = step_fn(c.n_beams, epw, lds, variant_of(c));
     if (!k) return hipErrorInvalidValue;
     const int grid = (c.n_envs + epw - 1) / epw;
     hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K);

@@ -42,7 +42,7 @@ class ShipVecEnv(object):
 
     def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
                  map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
-                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False):
+                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1):
         torch = _torch()
         if not torch.cuda.is_available():
             raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -88,6 +88,10 @@ class ShipVecEnv(object):
         if exact_lidar:
             flags |= N.FLAG_EXACT_LIDAR
         c.flags = flags
+        # n_ships = 4: BASELINE configs[3] — env.game.add_default_traffic() (game.py:279-286) after every reset: three
+        # traffic ships, dynamic goal bodies and Chipmunk's contact solver (csrc/shipsim_dynamics.hip)
+        c.n_ships = int(n_ships)
+        self.n_ships = int(n_ships)
         self.cfg = c
         self.n_states = 6 + c.n_beams                              # ship_env.py:43
         self.states_history = self.n_states * c.history            # ship_env.py:44

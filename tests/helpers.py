@@ -9,7 +9,8 @@ def oracle_cfg(O, vec):
     return O.default_config(width=c.width, height=c.height, dt=c.dt, space_damping=0.4, max_steps=c.max_steps,
                             history=c.history, n_beams=c.n_beams, lidar_spread_deg=c.lidar_spread_deg,
                             lidar_dist=c.lidar_dist, n_goals=c.n_goals, goal_radius=c.goal_radius,
-                            spawn_x=c.spawn_x, spawn_y=c.spawn_y, thrust_px0=c.thrust_px0, thrust_py0=c.thrust_py0)
+                            spawn_x=c.spawn_x, spawn_y=c.spawn_y, thrust_px0=c.thrust_px0, thrust_py0=c.thrust_py0,
+                            n_traffic=(3 if getattr(vec, "n_ships", 1) > 1 else 0))
 
 
 def run_pair(O, N, vec, K, seed=12345, check_every=1, atol=1e-5):

@@ -1,0 +1,151 @@
+"""Config 4 (BASELINE configs[3]: 65 536 envs x 4 ships, curriculum maps): the HIP dyn kernel (traffic ships, dynamic
+goal bodies, Chipmunk contact solver) + the DYN step kernel against the oracle's restatement (oracle/ssg_dynamics.c)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import torch
+    assert torch.cuda.is_available()
+    from oracle import oracle as O
+    from ship_sim_gym_amd import _native as N
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    return torch, O, N, ShipVecEnv
+
+
+def _dyn_state(N, vec):
+    t = vec.field(N.F_TRAFFIC).cpu().numpy()          # [27, n]
+    g = vec.field(N.F_GOAL_BODIES).cpu().numpy()      # [48, n]
+    n = t.shape[1]
+    traffic = t.reshape(3, 9, n).transpose(2, 0, 1)[:, :, :6]                      # [n, 3, (x,y,a,vx,vy,w)]
+    goals = g.reshape(6, 8, n).transpose(2, 0, 1)[:, :5, :4]                       # [n, 5, (x,y,vx,vy)]
+    return traffic, goals
+
+
+def _oracle_dyn(ob, idx):
+    tr, go = [], []
+    for i in idx:
+        d = ob.peek_dyn(int(i))
+        tr.append(d["traffic"]); go.append(d["goals"])
+    return np.stack(tr), np.stack(go)
+
+
+def _compare_dyn(N, vec, ob, just_reset=None, atol=1e-9):
+    """Traffic / goal body columns against the oracle's bodies.  The HIP path rebuilds the bodies of an auto-reset
+    env at the start of that env's next step (the dyn kernel sees the step kernel's reset bit), so envs that were
+    reset by the step just taken are compared one step later."""
+    idx = np.arange(vec.num_envs)
+    keep = np.ones(vec.num_envs, dtype=bool) if just_reset is None else ~just_reset.astype(bool)
+    t_g, g_g = _dyn_state(N, vec)
+    t_o, g_o = _oracle_dyn(ob, idx)
+    np.testing.assert_allclose(t_g[keep], t_o[keep], atol=atol, rtol=0)
+    mask = vec.field(N.F_GOAL_MASK).cpu().numpy()
+    for g in range(5):                                   # bodies of goals that left the space are not maintained
+        alive = (mask >> g & 1).astype(bool) & keep
+        np.testing.assert_allclose(g_g[alive, g], g_o[alive, g], atol=atol, rtol=0)
+
+
+@pytest.mark.parametrize("n,nb,K", [(4096, 10, 160), (777, 8, 120)])
+def test_config4_parity(n, nb, K):
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    vec = ShipVecEnv(n, n_beams=nb, n_maps=64, n_ships=4)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    _compare_dyn(N, vec, ob, atol=0)
+    acts = vec.random_actions(4242, 0, K)
+    acts_h = acts.cpu().numpy()
+    max_err, n_done, n_col = 0.0, 0, 0
+    for k in range(K):
+        obs, rew, done, flags = vec.step_tensor(acts[k])
+        r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_rew, err_msg="reward differs at step %d" % k)
+        err = float(np.max(np.abs(obs.cpu().numpy() - r_obs)))
+        assert err <= 1e-5, "obs differ by %g at step %d" % (err, k)     # BASELINE tolerance
+        max_err = max(max_err, err)
+        n_done += int(r_done.sum())
+        n_col += int(((flags.cpu().numpy() & N.EV_COLLIDING) != 0).sum())
+        if k in (0, 1, 2, 7, 40, K - 1):
+            _compare_dyn(N, vec, ob, just_reset=r_done)
+    assert n_done > n // 4 and n_col > 0
+    assert max_err <= 1e-9
+    vec.close()
+
+
+def test_config4_solver_scenarios():
+    """Scenarios that exercise what random rollouts rarely reach: ship-ship impact with friction, a goal shoved by a
+    moving ship, a ship driven into a bank, the player running into parked traffic."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    n = 256
+    vec = ShipVecEnv(n, n_maps=16, n_ships=4)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    vec.reset_tensor(); ob.reset()
+    vec.step_tensor(torch.ones(n, dtype=torch.int32, device=vec.device)); ob.step(np.ones(n, dtype=np.int32))
+    rng = np.random.RandomState(7)
+    T = vec.field(N.F_TRAFFIC)                            # [27, n] view into the state blob
+    poke = np.zeros((n, 3, 6))
+    for e in range(n):
+        kind = e % 4
+        if kind == 0:      # ship 2 thrown at ship 3, off-centre, spinning
+            poke[e, 1] = [370 + rng.uniform(-5, 5), 352 + rng.uniform(-10, 25), rng.uniform(-.3, .3), 12, rng.uniform(-2, 2), rng.uniform(-.05, .05)]
+            poke[e, 0] = [100, 200, 0, 0, 0, 0]; poke[e, 2] = [400, 350, 0, 0, 0, 0]
+        elif kind == 1:    # ship 3 driven into the right bank
+            poke[e, 2] = [430 + rng.uniform(0, 15), 300 + rng.uniform(-50, 50), rng.uniform(-1, 1), 15, rng.uniform(-3, 3), rng.uniform(-.1, .1)]
+            poke[e, 0] = [100, 200, 0, 0, 0, 0]; poke[e, 1] = [300, 200, 0, 0, 0, 0]
+        elif kind == 2:    # ship 2 sweeping up the fairway through the goals
+            poke[e, 1] = [rng.uniform(270, 320), 60, rng.uniform(-.2, .2), rng.uniform(-1, 1), 14, 0]
+            poke[e, 0] = [100, 200, 0, 0, 0, 0]; poke[e, 2] = [400, 350, 0, 0, 0, 0]
+        else:              # ship 1 parked in front of the player
+            poke[e, 0] = [295 + rng.uniform(-8, 8), 90 + rng.uniform(0, 30), rng.uniform(-.5, .5), 0, 0, 0]
+            poke[e, 1] = [300, 200, 0, 0, 0, 0]; poke[e, 2] = [400, 350, 0, 0, 0, 0]
+    for e in range(n):
+        for k in range(3):
+            ob.poke_traffic(e, k, *poke[e, k])
+    cols = np.zeros((27, n))
+    for k in range(3):
+        cols[9 * k: 9 * k + 6] = poke[:, k].T
+    T.copy_(torch.from_numpy(cols).to(vec.device))
+    # the live arbiters of ship 1 (resting on the left bank) refer to its old pose in both implementations alike
+    K = 60
+    acts = (np.arange(n)[None, :] % 4 == 3) * 0 + np.where(np.arange(n)[None, :] % 4 == 3, 0, 1) * np.ones((K, 1), dtype=np.int64)
+    acts = acts.astype(np.int32)                          # kind 3 drives forward, the others only move the rudder
+    n_col = 0
+    struck = np.zeros(n, dtype=bool)
+    for k in range(K):
+        a = torch.from_numpy(acts[k]).to(vec.device)
+        obs, rew, done, flags = vec.step_tensor(a)
+        r_obs, r_rew, r_done = ob.step(acts[k], auto_reset=True)
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
+        assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
+        _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
+        n_col += int(((flags.cpu().numpy() & N.EV_COLLIDING) != 0)[3::4].sum())
+        struck |= np.abs(_dyn_state(N, vec)[0][:, 2, 3:]).max(axis=1) > 0      # ship 3 acquired a real velocity
+    assert n_col >= n // 8                                # the player did run into the parked ships
+    assert struck[0::4].sum() >= n // 16                  # ship-ship impacts happened (kind 0)
+    vec.close()
+
+
+def test_config4_full_size_properties():
+    """65 536 envs x 4 ships: properties that need no oracle at this size."""
+    torch, O, N, ShipVecEnv = _mods()
+    n = 65536
+    vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
+    vec.reset_tensor()
+    acts = vec.random_actions(99, 0, 50)
+    for k in range(50):
+        obs, rew, done, flags = vec.step_tensor(acts[k])
+    assert torch.isfinite(obs).all()
+    t, g = _dyn_state(N, vec)
+    assert np.isfinite(t).all() and np.isfinite(g).all()
+    # envs that share a map and an action history are bit-identical (64 maps, env e starts on map e % 64, and the
+    # Philox stream differs per env, so compare the traffic only: it never depends on the actions before a contact)
+    assert np.abs(t[:, :, 3:]).max() < 50
+    # no real velocity ever appears on a ship that only rests against its bank
+    st = vec.stats()
+    assert st["episodes"] > n // 2
+    vec.close()
