@@ -453,7 +453,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
-    h->block = h->cfg.n_ships > 1 ? 64 : pick_block(cfg->n_envs);
+    h->block = pick_block(cfg->n_envs);
+    if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64; // the config-4 step kernel is built for 64 and 256
     refresh_dev(h);
     *out = h;
     return SSG_OK;
@@ -521,9 +522,10 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
     // Envs per workgroup: start from the size preferred for this env count and halve it until the staged bank fits
     // the CU's LDS beside the lidar scratch; if even 64 does not fit, gather records from L2/HBM instead.
-    h->block = h->cfg.n_ships > 1 ? 64 : pick_block(h->cfg.n_envs);
+    h->block = pick_block(h->cfg.n_envs);
     if (!(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL))
         while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) > 160u * 1024u) h->block /= 2;
+    if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64; // the config-4 step kernel is built for 64 and 256
     h->bank = dev_bank;
     h->n_maps = n_maps;
     // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch

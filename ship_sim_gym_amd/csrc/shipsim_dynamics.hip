@@ -9,12 +9,20 @@
 //   cpSpaceArbiterSetFilter (collision persistence 3), cpBodyUpdateVelocity.
 // and the player's `collide_ship` begin-callback against traffic (collision_type 1, models.py:100; game.py:232-241).
 //
-// One lane per env (a 64-lane workgroup = one wave): the work per env is a short, branchy chain (at most a
-// handful of touching pairs), and envs diverge, so this kernel is latency/occupancy bound rather than HBM bound;
-// it keeps its own launch so that the hot step kernel's register budget is untouched.  Per step it runs BEFORE the
-// step kernel, which then reads this step's goal positions and the traffic-contact bit from the dyn columns
-// (DevCfg::dyn_*).  State lives in struct-of-arrays columns like the player's; arbiter records (accumulated
-// impulses, contact hashes, state) are only touched for pairs whose bit is set in the env's 64-bit live mask.
+// Design (MI355X).  One lane per env, one wave per workgroup.  The work per env is a short, branchy, strictly
+// sequential chain (Gauss-Seidel over at most a handful of contacts), so the kernel is bound by the latency of that
+// chain, not by HBM: what matters is that nothing on the chain goes to memory.
+//  * Body state and the solver's arbiter records live in LDS, one column per field, lane-contiguous
+//    (`lds[field*64 + lane]`): a lane's dynamic slot index changes the field, never the LDS bank, so the per-lane
+//    gathers of the solver are conflict-free.  (A first version kept them in per-lane arrays: 8.7 KB of scratch per
+//    lane, 1 GB of HBM traffic per step, 420 us.)
+//  * Shapes are never materialised: a ship's world vertices are its pose applied on the fly to the hull constants
+//    (staged once per workgroup in LDS, broadcast reads), a bank's planes are read from the map
+//    record in L2.  Only EPA's growing hull sits in scratch, and only the few entries it touches.
+//  * Arbiter records (accumulated impulses, contact hashes, state, age) persist in struct-of-arrays columns but are
+//    read or written only for pairs whose bit is set in the env's 64-bit live mask.
+// Per step this kernel runs BEFORE the step kernel, which then reads this step's goal positions and the
+// traffic-contact bit from the dyn columns (DevCfg::dyn_*).
 //
 // The canonical pair order, the cold GJK start and the unsolved player arbiters are the named assumptions of the
 // oracle (oracle/ssg_dynamics.c header); this file follows the same ones.
@@ -22,19 +30,31 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "shipsim_internal.h"
 
 namespace ssg {
 namespace {
 
+extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-uniform hull constants
+
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
 constexpr int kMaxGjk = 30, kMaxEpa = 30;
-constexpr int kMaxActive = 8;      // arbiters on one env's solver list (5 circles + 3 ships never reach this)
+constexpr int kLdsArb = 3;         // arbiter records per env held in LDS; further ones (rare) go to scratch
+constexpr int kMaxActive = 8;      // arbiters on one env's solver list
 enum { ST_NONE = 0, ST_FIRST = 1, ST_NORMAL = 2, ST_IGNORE = 3, ST_CACHED = 4 };
-// shape slots: 0,1 banks | 2..7 goals | 8..10 traffic ships
-constexpr int kSlotGoal0 = 2, kSlotTraffic0 = 2 + SSG_MAX_GOALS, kSlots = kSlotTraffic0 + SSG_N_TRAFFIC;
+
+// ---- per-lane LDS columns ----------------------------------------------------------------------------------
+// body slot s (goals 0..ng-1, ships ng..ng+2, the static body ng+3): 8 doubles
+enum { B_PX = 0, B_PY, B_VX, B_VY, B_W, B_VBX, B_VBY, B_WB, B_STRIDE };
+// ship k extras after the body slots: angle, cos, sin
+enum { X_A = 0, X_CA, X_SA, X_STRIDE };
+// arbiter record: header + 2 contacts
+enum { A_NX = 0, A_NY, A_U, A_INTS /* pid | a << 8 | b << 16 | count << 24 | state << 28 */, A_HASH /* 2 x u32 */, A_CON0 };
+enum { AC_R1X = 0, AC_R1Y, AC_R2X, AC_R2Y, AC_NMASS, AC_TMASS, AC_BIAS, AC_JBIAS, AC_JN, AC_JT, AC_STRIDE };
+constexpr int A_STRIDE = A_CON0 + 2 * AC_STRIDE;
 
 struct V2 { double x, y; };
 __device__ __forceinline__ V2 mk(double x, double y) { V2 r; r.x = x; r.y = y; return r; }
@@ -57,73 +77,136 @@ __device__ __forceinline__ double cmax(double a, double b) { return (a > b) ? a 
 __device__ __forceinline__ double cclamp(double f, double lo, double hi) { return cmin(cmax(f, lo), hi); }
 __device__ __forceinline__ double cclamp01(double f) { return cmax(0.0, cmin(f, 1.0)); }
 
-struct Poly {
-    int n;
-    double l, b, r, t;
-    V2 v[SSG_MAX_HULL], nr[SSG_MAX_HULL];
-};
-struct Ref {
-    const Poly *poly; // nullptr = circle
-    V2 c;
-    double rad;
-    double l, b, r, t;
-    unsigned hashid;
-};
-struct Body {
-    V2 p, v, vb;
-    double a, w, wb, m_inv, i_inv;
-};
-struct Mink { V2 a, b, ab; };
-struct Closest { V2 a, b, n; double d; };
-struct Info { int count; V2 n; V2 p1[2], p2[2]; unsigned hash[2]; };
-struct Active {
-    int pid, a, b, count, state;
-    V2 n;
-    double u;
-    V2 r1[2], r2[2];
-    double nMass[2], tMass[2], bias[2], bounce[2], jBias[2], jn[2], jt[2];
-    unsigned hash[2];
-};
-
-__device__ __forceinline__ Ref ref_poly(const Poly *p, unsigned hashid)
-{
-    Ref s;
-    s.poly = p; s.c = mk(0, 0); s.rad = 0.0; s.l = p->l; s.b = p->b; s.r = p->r; s.t = p->t; s.hashid = hashid;
-    return s;
-}
-__device__ __forceinline__ Ref ref_circle(V2 c, double rad, unsigned hashid)
-{
-    Ref s;
-    s.poly = nullptr; s.c = c; s.rad = rad; s.hashid = hashid;
-    s.l = c.x - rad; s.b = c.y - rad; s.r = c.x + rad; s.t = c.y + rad; // cpCircleShapeCacheData
-    return s;
-}
-__device__ __forceinline__ bool bb_hit(const Ref &a, const Ref &b)
+struct BB { double l, b, r, t; };
+__device__ __forceinline__ bool bb_hit(const BB &a, const BB &b)
 {
     return (a.l <= b.r) & (b.l <= a.r) & (a.b <= b.t) & (b.b <= a.t);
 }
-__device__ __forceinline__ V2 bb_center(const Ref &s) { return lerp(mk(s.l, s.b), mk(s.r, s.t), 0.5); }
+__device__ __forceinline__ V2 bb_center(const BB &s) { return lerp(mk(s.l, s.b), mk(s.r, s.t), 0.5); }
 
-__device__ int support_index(const Poly *p, V2 n)
-{
-    double mx = -INFINITY;
-    int index = 0;
-    for (int i = 0; i < p->n; ++i) {
-        const double d = dot(p->v[i], n);
-        if (d > mx) { mx = d; index = i; }
+struct Sup { V2 p; int i; };
+struct Edge { V2 ap, bp; unsigned ah, bh; V2 n; };
+// Contact hashes only ever get compared for equality (cpArbiterUpdate): edge point = slot*16 + vertex + 1,
+// contact = (hash1 << 8) | hash2, collision free and never 0.
+__device__ __forceinline__ unsigned edge_hash(unsigned hashid, int i) { return hashid * 16u + (unsigned)i + 1u; }
+
+// ---- shapes (cpPolyShapeCacheData / cpCircleShapeCacheData evaluated on the fly) ----------------------------
+// A ship hull: 5 local vertices then 5 local normals at lds[hoff ..] (wave-uniform constants staged once per
+// workgroup: broadcast LDS reads), pose (p, ca, sa).
+constexpr int kHullDoubles = 4 * SSG_SHIP_VERTS;
+struct ShipShape {
+    int hoff;
+    V2 p;
+    double ca, sa;
+    unsigned hashid;
+    static constexpr bool is_circle = false;
+    __device__ __forceinline__ V2 vert(int i) const
+    {
+        const double hx = lds[hoff + 2 * i], hy = lds[hoff + 2 * i + 1];
+        return mk(ca * hx + (-sa) * hy + p.x, sa * hx + ca * hy + p.y);
     }
-    return index;
-}
-__device__ __forceinline__ V2 support_point(const Ref &s, V2 n)
-{
-    if (!s.poly) return s.c;
-    return s.poly->v[support_index(s.poly, n)];
-}
-__device__ __forceinline__ Mink support(const Ref &s1, const Ref &s2, V2 n)
+    __device__ __forceinline__ V2 normal(int i) const
+    {
+        const double nx = lds[hoff + 2 * SSG_SHIP_VERTS + 2 * i], ny = lds[hoff + 2 * SSG_SHIP_VERTS + 2 * i + 1];
+        return mk(ca * nx + (-sa) * ny, sa * nx + ca * ny);
+    }
+    __device__ __forceinline__ BB bb() const
+    {
+        BB o; o.l = INFINITY; o.r = -INFINITY; o.b = INFINITY; o.t = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+            const V2 v = vert(i);
+            o.l = fmin(o.l, v.x); o.r = fmax(o.r, v.x); o.b = fmin(o.b, v.y); o.t = fmax(o.t, v.y);
+        }
+        return o;
+    }
+    __device__ __forceinline__ Sup support(V2 n) const // PolySupportPointIndex: first maximum
+    {
+        double mx = -INFINITY;
+        Sup s; s.p = mk(0, 0); s.i = 0;
+#pragma unroll
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+            const V2 v = vert(i);
+            const double d = dot(v, n);
+            if (d > mx) { mx = d; s.p = v; s.i = i; }
+        }
+        return s;
+    }
+    __device__ __forceinline__ Edge support_edge(V2 n) const // SupportEdgeForPoly
+    {
+        const int i1 = support(n).i;
+        const int i0 = (i1 == 0) ? SSG_SHIP_VERTS - 1 : i1 - 1;
+        const int i2 = (i1 == SSG_SHIP_VERTS - 1) ? 0 : i1 + 1;
+        V2 v0 = mk(0, 0), v1 = v0, v2 = v0, n1 = v0, n2 = v0;
+#pragma unroll
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) { // select without dynamic indexing of the argument arrays
+            const V2 v = vert(i), nn = normal(i);
+            if (i == i0) v0 = v;
+            if (i == i1) { v1 = v; n1 = nn; }
+            if (i == i2) { v2 = v; n2 = nn; }
+        }
+        Edge e;
+        if (dot(n, n1) > dot(n, n2)) { e.ap = v0; e.ah = edge_hash(hashid, i0); e.bp = v1; e.bh = edge_hash(hashid, i1); e.n = n1; }
+        else { e.ap = v1; e.ah = edge_hash(hashid, i1); e.bp = v2; e.bh = edge_hash(hashid, i2); e.n = n2; }
+        return e;
+    }
+};
+
+// A river bank: static body at the origin, planes straight from the map record (v0x v0y nx ny ... per plane).
+struct BankShape {
+    const double *pl; // plane j at pl + SSG_PLANE_DOUBLES * j
+    int n;
+    BB box;
+    unsigned hashid;
+    static constexpr bool is_circle = false;
+    __device__ __forceinline__ V2 vert(int i) const { return mk(pl[SSG_PLANE_DOUBLES * i], pl[SSG_PLANE_DOUBLES * i + 1]); }
+    __device__ __forceinline__ V2 normal(int i) const { return mk(pl[SSG_PLANE_DOUBLES * i + 2], pl[SSG_PLANE_DOUBLES * i + 3]); }
+    __device__ __forceinline__ BB bb() const { return box; }
+    __device__ __forceinline__ Sup support(V2 nn) const
+    {
+        double mx = -INFINITY;
+        Sup s; s.p = mk(0, 0); s.i = 0;
+        for (int i = 0; i < n; ++i) {
+            const V2 v = vert(i);
+            const double d = dot(v, nn);
+            if (d > mx) { mx = d; s.p = v; s.i = i; }
+        }
+        return s;
+    }
+    __device__ __forceinline__ Edge support_edge(V2 nn) const
+    {
+        const int i1 = support(nn).i;
+        const int i0 = (i1 - 1 + n) % n;
+        const int i2 = (i1 + 1) % n;
+        Edge e;
+        if (dot(nn, normal(i1)) > dot(nn, normal(i2))) {
+            e.ap = vert(i0); e.ah = edge_hash(hashid, i0); e.bp = vert(i1); e.bh = edge_hash(hashid, i1); e.n = normal(i1);
+        } else {
+            e.ap = vert(i1); e.ah = edge_hash(hashid, i1); e.bp = vert(i2); e.bh = edge_hash(hashid, i2); e.n = normal(i2);
+        }
+        return e;
+    }
+};
+
+struct CircleShape {
+    V2 c;
+    double rad;
+    static constexpr bool is_circle = true;
+    __device__ __forceinline__ BB bb() const { BB o; o.l = c.x - rad; o.b = c.y - rad; o.r = c.x + rad; o.t = c.y + rad; return o; }
+    __device__ __forceinline__ Sup support(V2) const { Sup s; s.p = c; s.i = 0; return s; }
+};
+
+// ---- cpCollision.c ---------------------------------------------------------------------------------------------
+struct Mink { V2 a, b, ab; };
+struct Closest { V2 a, b, n; double d; };
+struct Info { int count; V2 n; V2 p1[2], p2[2]; unsigned hash[2]; };
+
+template <class SA, class SB>
+__device__ __forceinline__ Mink support(const SA &s1, const SB &s2, V2 n)
 {
     Mink m;
-    m.a = support_point(s1, neg(n));
-    m.b = support_point(s2, n);
+    m.a = s1.support(neg(n)).p;
+    m.b = s2.support(n).p;
     m.ab = m.b - m.a;
     return m;
 }
@@ -139,7 +222,7 @@ __device__ __forceinline__ V2 lerp_t(V2 a, V2 b, double t)
 }
 __device__ __forceinline__ double closest_dist(V2 v0, V2 v1) { return lensq(lerp_t(v0, v1, closest_t(v0, v1))); }
 
-__device__ Closest closest_new(const Mink &v0, const Mink &v1)
+__device__ __forceinline__ Closest closest_new(const Mink &v0, const Mink &v1)
 {
     const double t = closest_t(v0.ab, v1.ab);
     const V2 p = lerp_t(v0.ab, v1.ab, t);
@@ -159,9 +242,11 @@ __device__ Closest closest_new(const Mink &v0, const Mink &v1)
     return r;
 }
 
-__device__ __attribute__((noinline)) Closest epa(const Ref &s1, const Ref &s2, const Mink &v0, const Mink &v1, const Mink &v2)
+template <class SA, class SB>
+__device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v0, const Mink &v1, const Mink &v2)
 {
-    Mink hull[kMaxEpa + 4], hull2[kMaxEpa + 4];
+    Mink bufa[kMaxEpa + 4], bufb[kMaxEpa + 4]; // scratch; only the entries a query touches ever reach memory
+    Mink *hull = bufa, *hull2 = bufb;
     int count = 3;
     hull[0] = v0; hull[1] = v1; hull[2] = v2;
     for (int iteration = 1;; ++iteration) {
@@ -184,7 +269,7 @@ __device__ __attribute__((noinline)) Closest epa(const Ref &s1, const Ref &s2, c
                 const V2 h2 = (i + 1 < count) ? hull[(index + 1) % count].ab : p.ab;
                 if (cross(h2 - h0, h1 - h0) > 0.0) hull2[count2++] = hull[index];
             }
-            for (int i = 0; i < count2; ++i) hull[i] = hull2[i];
+            Mink *tmp = hull; hull = hull2; hull2 = tmp;
             count = count2;
         } else {
             return closest_new(e0, e1);
@@ -192,9 +277,10 @@ __device__ __attribute__((noinline)) Closest epa(const Ref &s1, const Ref &s2, c
     }
 }
 
-__device__ __attribute__((noinline)) Closest gjk(const Ref &s1, const Ref &s2)
+template <class SA, class SB>
+__device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2)
 {
-    const V2 axis = perp(bb_center(s1) - bb_center(s2)); // cold start (no cached collision id)
+    const V2 axis = perp(bb_center(s1.bb()) - bb_center(s2.bb())); // cold start (no cached collision id)
     Mink v0 = support(s1, s2, axis);
     Mink v1 = support(s1, s2, neg(axis));
     int iteration = 1;
@@ -216,32 +302,7 @@ __device__ __attribute__((noinline)) Closest gjk(const Ref &s1, const Ref &s2)
     }
 }
 
-// Contact hashes only ever get compared for equality (cpArbiterUpdate): edge point = slot*16 + vertex + 1,
-// contact = (hash1 << 8) | hash2, collision free and never 0.
-__device__ __forceinline__ unsigned edge_hash(unsigned hashid, int i) { return hashid * 16u + (unsigned)i + 1u; }
-
-struct Edge { V2 ap, bp; unsigned ah, bh; V2 n; };
-__device__ Edge support_edge(const Ref &s, V2 n)
-{
-    const Poly *p = s.poly;
-    const int count = p->n;
-    const int i1 = support_index(p, n);
-    const int i0 = (i1 - 1 + count) % count;
-    const int i2 = (i1 + 1) % count;
-    Edge e;
-    if (dot(n, p->nr[i1]) > dot(n, p->nr[i2])) {
-        e.ap = p->v[i0]; e.ah = edge_hash(s.hashid, i0);
-        e.bp = p->v[i1]; e.bh = edge_hash(s.hashid, i1);
-        e.n = p->nr[i1];
-    } else {
-        e.ap = p->v[i1]; e.ah = edge_hash(s.hashid, i1);
-        e.bp = p->v[i2]; e.bh = edge_hash(s.hashid, i2);
-        e.n = p->nr[i2];
-    }
-    return e;
-}
-
-__device__ void contact_points(const Edge &e1, const Edge &e2, const Closest &points, Info &info)
+__device__ __forceinline__ void contact_points(const Edge &e1, const Edge &e2, const Closest &points, Info &info)
 {
     const double mindist = 0.0 + 0.0;
     if (points.d <= mindist) {
@@ -273,11 +334,12 @@ __device__ void contact_points(const Edge &e1, const Edge &e2, const Closest &po
     }
 }
 
-__device__ void collide(const Ref &a, const Ref &b, Info &info)
+template <class SA, class SB>
+__device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info)
 {
     info.count = 0;
     info.n = mk(0, 0);
-    if (!a.poly && !b.poly) { // CircleToCircle
+    if constexpr (SA::is_circle && SB::is_circle) { // CircleToCircle
         const double mindist = a.rad + b.rad;
         const V2 delta = b.c - a.c;
         const double distsq = lensq(delta);
@@ -289,7 +351,7 @@ __device__ void collide(const Ref &a, const Ref &b, Info &info)
             info.hash[0] = 0u;
             info.count = 1;
         }
-    } else if (!a.poly) { // CircleToPoly
+    } else if constexpr (SA::is_circle) { // CircleToPoly
         const Closest points = gjk(a, b);
         const double mindist = a.rad + 0.0;
         if (points.d <= mindist) {
@@ -301,53 +363,29 @@ __device__ void collide(const Ref &a, const Ref &b, Info &info)
         }
     } else { // PolyToPoly
         const Closest points = gjk(a, b);
-        if (points.d - 0.0 - 0.0 <= 0.0) contact_points(support_edge(a, points.n), support_edge(b, neg(points.n)), points, info);
+        if (points.d - 0.0 - 0.0 <= 0.0) contact_points(a.support_edge(points.n), b.support_edge(neg(points.n)), points, info);
     }
 }
 
-// SAT over both polygons' edge normals after the cpBBIntersects reject: "touching counts" (collide_ship's begin)
-__device__ bool polys_touch(const Poly &a, const Poly &b)
+// SAT over both hulls' edge normals after the cpBBIntersects reject: "touching counts" (collide_ship's begin)
+__device__ __forceinline__ bool ships_touch(const ShipShape &a, const ShipShape &b)
 {
-    if (!((a.l <= b.r) & (b.l <= a.r) & (a.b <= b.t) & (b.b <= a.t))) return false;
+    if (!bb_hit(a.bb(), b.bb())) return false;
+    bool sep = false;
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const Poly &p = pass ? b : a, &q = pass ? a : b;
-        for (int i = 0; i < p.n; ++i) {
-            const V2 n = p.nr[i];
-            const double off = dot(n, p.v[i]);
+        const ShipShape &p = pass ? b : a, &q = pass ? a : b;
+#pragma unroll
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+            const V2 n = p.normal(i);
+            const double off = dot(n, p.vert(i));
             double mn = INFINITY;
-            for (int j = 0; j < q.n; ++j) mn = fmin(mn, dot(n, q.v[j]));
-            if (mn > off) return false;
+#pragma unroll
+            for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, dot(n, q.vert(j)));
+            sep |= mn > off;
         }
     }
-    return true;
-}
-
-// cpPolyShapeCacheData for a 5-vertex ship hull
-__device__ void ship_world(Poly &out, const double *hull, const double *nrm, V2 p, double ca, double sa)
-{
-    out.n = SSG_SHIP_VERTS;
-    double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
-    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-        const double hx = hull[2 * i], hy = hull[2 * i + 1], nx = nrm[2 * i], ny = nrm[2 * i + 1];
-        const V2 v = mk(ca * hx + (-sa) * hy + p.x, sa * hx + ca * hy + p.y);
-        out.v[i] = v;
-        out.nr[i] = mk(ca * nx + (-sa) * ny, sa * nx + ca * ny);
-        l = fmin(l, v.x); r = fmax(r, v.x); b = fmin(b, v.y); t = fmax(t, v.y);
-    }
-    out.l = l; out.b = b; out.r = r; out.t = t;
-}
-
-__device__ void load_bank(Poly &out, const double *rec, int s)
-{
-    const int n = (int)rec[SSG_MAP_OFF_COUNTS + s];
-    out.n = n;
-    out.l = rec[SSG_MAP_OFF_AABB + 4 * s + 0]; out.b = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
-    out.r = rec[SSG_MAP_OFF_AABB + 4 * s + 2]; out.t = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
-    const double *pl = rec + SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES;
-    for (int j = 0; j < n; ++j) {
-        out.v[j] = mk(pl[SSG_PLANE_DOUBLES * j + 0], pl[SSG_PLANE_DOUBLES * j + 1]);
-        out.nr[j] = mk(pl[SSG_PLANE_DOUBLES * j + 2], pl[SSG_PLANE_DOUBLES * j + 3]);
-    }
+    return !sep;
 }
 
 // ---- arbiter pair ids (bits of the live mask, rows of the arbiter columns) ----
@@ -356,28 +394,6 @@ __device__ __forceinline__ int pid_tt(int j, int k) { return 6 + j + k - 1; }   
 __device__ __forceinline__ int pid_gb(int g, int s) { return 9 + 2 * g + s; }                   // [9, 21)
 __device__ __forceinline__ int pid_gt(int g, int k) { return 21 + 3 * g + k; }                  // [21, 39)
 __device__ __forceinline__ int pid_gg(int h, int g) { return 39 + g * (g - 1) / 2 + h; }        // h < g: [39, 54)
-
-__device__ __forceinline__ double k_scalar_body(const Body &b, V2 r, V2 n)
-{
-    const double rcn = cross(r, n);
-    return b.m_inv + b.i_inv * rcn * rcn;
-}
-__device__ __forceinline__ V2 relative_velocity(const Body &a, const Body &b, V2 r1, V2 r2)
-{
-    const V2 v1 = a.v + perp(r1) * a.w;
-    const V2 v2 = b.v + perp(r2) * b.w;
-    return v2 - v1;
-}
-__device__ __forceinline__ void apply_impulse(Body &b, V2 j, V2 r)
-{
-    b.v = b.v + j * b.m_inv;
-    b.w += b.i_inv * cross(r, j);
-}
-__device__ __forceinline__ void apply_bias_impulse(Body &b, V2 j, V2 r)
-{
-    b.vb = b.vb + j * b.m_inv;
-    b.wb += b.i_inv * cross(r, j);
-}
 
 struct DynCols {
     double *f64;
@@ -404,6 +420,14 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
     col.live[e] = 0ull;
 }
 
+// A field of an arbiter record: LDS column (stride 64 doubles) for the first kLdsArb records, scratch beyond.
+struct ArbRef {
+    double *p;
+    int stride;
+    __device__ __forceinline__ double &f(int i) const { return p[i * stride]; }
+    __device__ __forceinline__ double &cf(int k, int i) const { return p[(A_CON0 + k * AC_STRIDE + i) * stride]; }
+};
+
 } // namespace
 
 __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *__restrict__ mask)
@@ -422,109 +446,122 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
 
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * 64 + lane;
+    const int cbase = 64 * (B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb);
+    if (lane < kHullDoubles) { // hull constants: [0] the player, [1..3] the traffic ships; vertices then normals
+        const int i = lane % (2 * SSG_SHIP_VERTS);
+        const bool nr = lane >= 2 * SSG_SHIP_VERTS;
+        lds[cbase + lane] = nr ? c.nrm[i] : c.hull[i];
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) lds[cbase + kHullDoubles * (1 + k) + lane] = nr ? d.tnrm[k][i] : d.thull[k][i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F); // one wave per workgroup: the LDS writes above are visible to its lanes
+    __builtin_amdgcn_wave_barrier();
     if (e >= c.n_envs) return;
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
     const size_t np = col.np;
     const double dt = c.dt;
+    const int ng = c.n_goals;
     const int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
     const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
     if (col.flag[e] & 2) dyn_init(c, d, col, e, rec); // the step kernel auto-reset this env at the end of the last step
-    const unsigned gmask = (unsigned)c.mask[e] & ((1u << c.n_goals) - 1u); // goals still in the space
+    const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
     unsigned long long live = col.live[e];
 
     // deferred space.remove of goals the player reached last step (game.py:252): their cached arbiters go too
-    for (int g = 0; g < c.n_goals; ++g) {
+    for (int g = 0; g < ng; ++g) {
         if ((gmask >> g) & 1u) continue;
         for (int s = 0; s < 2; ++s) live &= ~(1ull << pid_gb(g, s));
         for (int k = 0; k < SSG_N_TRAFFIC; ++k) live &= ~(1ull << pid_gt(g, k));
-        for (int h = 0; h < c.n_goals; ++h)
+        for (int h = 0; h < ng; ++h)
             if (h != g) live &= ~(1ull << (h < g ? pid_gg(h, g) : pid_gg(g, h)));
     }
 
-    // ---- bodies -------------------------------------------------------------------------------------------
-    Body bod[kSlots];
-    for (int s = 0; s < kSlots; ++s) {
-        Body &b = bod[s];
-        b.p = mk(0, 0); b.v = mk(0, 0); b.vb = mk(0, 0); b.a = 0.0; b.w = 0.0; b.wb = 0.0; b.m_inv = 0.0; b.i_inv = 0.0;
-    }
-    for (int g = 0; g < c.n_goals; ++g) {
+    // ---- LDS columns of this lane ---------------------------------------------------------------------------
+    const int slot_ship0 = ng, slot_static = ng + SSG_N_TRAFFIC;
+    const int xbase = B_STRIDE * (slot_static + 1), abase = xbase + X_STRIDE * SSG_N_TRAFFIC;
+    auto L = [&](int f) -> double & { return lds[f * 64 + lane]; };
+    auto BF = [&](int slot, int f) -> double & { return lds[(B_STRIDE * slot + f) * 64 + lane]; };
+    for (int f = 0; f < B_STRIDE; ++f) BF(slot_static, f) = 0.0; // cpBodyNewStatic at the origin
+    auto m_inv_of = [&](int slot) -> double { return slot < slot_ship0 ? d.goal_m_inv : (slot < slot_static ? d.t_m_inv : 0.0); };
+    auto i_inv_of = [&](int slot) -> double {
+        if (slot < slot_ship0) return d.goal_i_inv;
+        const int k = slot - slot_ship0;
+        return k == 0 ? d.t_i_inv[0] : (k == 1 ? d.t_i_inv[1] : (k == 2 ? d.t_i_inv[2] : 0.0));
+    };
+
+    // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
+    for (int g = 0; g < ng; ++g) {
         if (!((gmask >> g) & 1u)) continue;
         const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
-        Body &b = bod[kSlotGoal0 + g];
-        b.p = mk(q[0 * np], q[1 * np]); b.v = mk(q[2 * np], q[3 * np]); b.vb = mk(q[4 * np], q[5 * np]);
-        b.w = q[6 * np]; b.wb = q[7 * np];
-        b.m_inv = d.goal_m_inv; b.i_inv = d.goal_i_inv;
+        const V2 p = mk(q[0 * np], q[1 * np]), v = mk(q[2 * np], q[3 * np]), vb = mk(q[4 * np], q[5 * np]);
+        const double w = q[6 * np];
+        const V2 pn = p + (v + vb) * dt; // (the angle of a circle body is never read)
+        BF(g, B_PX) = pn.x; BF(g, B_PY) = pn.y; BF(g, B_VX) = v.x; BF(g, B_VY) = v.y; BF(g, B_W) = w;
+        BF(g, B_VBX) = 0.0; BF(g, B_VBY) = 0.0; BF(g, B_WB) = 0.0;
     }
+#pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-        Body &b = bod[kSlotTraffic0 + k];
-        b.p = mk(t[0 * np], t[1 * np]); b.a = t[2 * np]; b.v = mk(t[3 * np], t[4 * np]); b.w = t[5 * np];
-        b.vb = mk(t[6 * np], t[7 * np]); b.wb = t[8 * np];
-        b.m_inv = d.t_m_inv; b.i_inv = d.t_i_inv[k];
+        const V2 p = mk(t[0 * np], t[1 * np]), v = mk(t[3 * np], t[4 * np]), vb = mk(t[6 * np], t[7 * np]);
+        const double a = t[2 * np], w = t[5 * np], wb = t[8 * np];
+        const V2 pn = p + (v + vb) * dt;
+        const double an = a + (w + wb) * dt;
+        double sa, ca;
+        sincos(an, &sa, &ca);
+        const int s = slot_ship0 + k;
+        BF(s, B_PX) = pn.x; BF(s, B_PY) = pn.y; BF(s, B_VX) = v.x; BF(s, B_VY) = v.y; BF(s, B_W) = w;
+        BF(s, B_VBX) = 0.0; BF(s, B_VBY) = 0.0; BF(s, B_WB) = 0.0;
+        L(xbase + X_STRIDE * k + X_A) = an; L(xbase + X_STRIDE * k + X_CA) = ca; L(xbase + X_STRIDE * k + X_SA) = sa;
     }
+    auto ship_shape = [&](int k) -> ShipShape {
+        ShipShape s;
+        s.hoff = cbase + kHullDoubles * (1 + k);
+        s.p = mk(BF(slot_ship0 + k, B_PX), BF(slot_ship0 + k, B_PY));
+        s.ca = L(xbase + X_STRIDE * k + X_CA); s.sa = L(xbase + X_STRIDE * k + X_SA);
+        s.hashid = (unsigned)(2 + SSG_MAX_GOALS + k);
+        return s;
+    };
+    auto bank_shape = [&](int s) -> BankShape {
+        BankShape b;
+        b.pl = rec + SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES;
+        b.n = (int)rec[SSG_MAP_OFF_COUNTS + s];
+        b.box.l = rec[SSG_MAP_OFF_AABB + 4 * s + 0]; b.box.b = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
+        b.box.r = rec[SSG_MAP_OFF_AABB + 4 * s + 2]; b.box.t = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
+        b.hashid = (unsigned)s;
+        return b;
+    };
+    auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
 
-    // ---- (1) cpBodyUpdatePosition ---------------------------------------------------------------------------
-    for (int s = kSlotGoal0; s < kSlots; ++s) {
-        Body &b = bod[s];
-        if (b.m_inv == 0.0) continue; // goal no longer in the space
-        b.p = b.p + (b.v + b.vb) * dt;
-        b.a = b.a + (b.w + b.wb) * dt;
-        b.vb = mk(0, 0);
-        b.wb = 0.0;
-    }
-    // the player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel)
-    Poly player;
+    if (d.stop_after == 1) return;
+    // the player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel) against traffic
+    bool hit = false;
     {
         const double x = c.f64cols[(size_t)COL_X * np + e], y = c.f64cols[(size_t)COL_Y * np + e];
         const double vx = c.f64cols[(size_t)COL_VX * np + e], vy = c.f64cols[(size_t)COL_VY * np + e];
         const double ang = c.f64cols[(size_t)COL_A * np + e], w = c.f64cols[(size_t)COL_W * np + e];
-        const double nx = x + vx * dt, ny = y + vy * dt, na = ang + w * dt;
-        double sa, ca;
-        sincos(na, &sa, &ca);
-        ship_world(player, c.hull, c.nrm, mk(nx, ny), ca, sa);
+        ShipShape pl;
+        pl.hoff = cbase; pl.hashid = 0;
+        pl.p = mk(x + vx * dt, y + vy * dt);
+        sincos(ang + w * dt, &pl.sa, &pl.ca);
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) hit |= ships_touch(pl, ship_shape(k)); // collide_ship: type 0 x type 1
     }
-    // ---- (2) shape caches -----------------------------------------------------------------------------------
-    Poly ship[SSG_N_TRAFFIC], bank[2];
-    bool hit = false;
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        const Body &b = bod[kSlotTraffic0 + k];
-        double sa, ca;
-        sincos(b.a, &sa, &ca);
-        ship_world(ship[k], d.thull[k], d.tnrm[k], b.p, ca, sa);
-        hit |= polys_touch(player, ship[k]); // collide_ship: player (type 0) x traffic (type 1)
-    }
-    bool bank_loaded[2] = {false, false};
 
-    auto shape_of = [&](int slot) -> Ref {
-        if (slot < kSlotGoal0) return ref_poly(&bank[slot], (unsigned)slot);
-        if (slot < kSlotTraffic0) return ref_circle(bod[slot].p, c.goal_r, (unsigned)slot);
-        return ref_poly(&ship[slot - kSlotTraffic0], (unsigned)slot);
+    if (d.stop_after == 2) return;
+    // ---- (3) collide, canonical order ---------------------------------------------------------------------------
+    double ovf[(kMaxActive - kLdsArb) * A_STRIDE]; // records beyond the LDS ones: scratch, touched only when used
+    auto arb = [&](int i) -> ArbRef {
+        ArbRef r;
+        if (i < kLdsArb) { r.p = &lds[(abase + A_STRIDE * i) * 64 + lane]; r.stride = 64; }
+        else { r.p = &ovf[(i - kLdsArb) * A_STRIDE]; r.stride = 1; }
+        return r;
     };
-    auto friction_of = [&](int slot) -> double { return slot >= kSlotTraffic0 ? d.ship_friction : 0.0; };
-
-    // ---- (3) collide, canonical order -----------------------------------------------------------------------
-    Active act[kMaxActive];
     int n_act = 0;
     unsigned long long touched = 0ull;
 
-    auto collide_pair = [&](int a, int b, int pid) {
-        if (a < kSlotGoal0 || b < kSlotGoal0) { // a bank is involved: cheap reject on the record's AABB first
-            const int s = (a < kSlotGoal0) ? a : b, o = (a < kSlotGoal0) ? b : a;
-            const double bl = rec[SSG_MAP_OFF_AABB + 4 * s + 0], bb = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
-            const double br = rec[SSG_MAP_OFF_AABB + 4 * s + 2], bt = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
-            double ol, ob, orr, ot;
-            if (o < kSlotTraffic0) { ol = bod[o].p.x - c.goal_r; ob = bod[o].p.y - c.goal_r; orr = bod[o].p.x + c.goal_r; ot = bod[o].p.y + c.goal_r; }
-            else { const Poly &q = ship[o - kSlotTraffic0]; ol = q.l; ob = q.b; orr = q.r; ot = q.t; }
-            if (!((ol <= br) & (bl <= orr) & (ob <= bt) & (bb <= ot))) return;
-            if (!bank_loaded[s]) { load_bank(bank[s], rec, s); bank_loaded[s] = true; }
-        }
-        const Ref sa = shape_of(a), sb = shape_of(b);
-        if (!bb_hit(sa, sb)) return; // queryReject
-        Info info;
-        collide(sa, sb, info);
+    // cpSpaceCollideShapes after the narrowphase found contacts: fetch / create the cached arbiter, cpArbiterUpdate
+    auto push = [&](const Info &info, int a, int b, int pid, double u) {
         if (info.count == 0 || n_act >= kMaxActive) return;
-        // cached arbiter of this pair, if any
         int state = ST_NONE, old_count = 0;
         unsigned old_hash[2] = {0u, 0u};
         double old_jn[2] = {0.0, 0.0}, old_jt[2] = {0.0, 0.0};
@@ -541,36 +578,71 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             if (state == ST_FIRST) state = ST_NORMAL; // it was on last step's solver list
         }
         if (state == ST_NONE) { state = ST_FIRST; old_count = 0; } // cpArbiterInit
-        Active &A = act[n_act++];
-        A.pid = pid; A.a = a; A.b = b; A.count = info.count; A.n = info.n;
-        A.u = friction_of(a) * friction_of(b);
+        const ArbRef A = arb(n_act++);
+        A.f(A_NX) = info.n.x; A.f(A_NY) = info.n.y; A.f(A_U) = u;
+        const V2 pa = mk(BF(a, B_PX), BF(a, B_PY)), pb = mk(BF(b, B_PX), BF(b, B_PY));
+        unsigned hh[2] = {0u, 0u};
         for (int i = 0; i < info.count; ++i) { // cpArbiterUpdate
-            A.r1[i] = info.p1[i] - bod[a].p;
-            A.r2[i] = info.p2[i] - bod[b].p;
-            A.hash[i] = info.hash[i];
-            A.jn[i] = 0.0; A.jt[i] = 0.0;
+            const V2 r1 = info.p1[i] - pa, r2 = info.p2[i] - pb;
+            double jn = 0.0, jt = 0.0;
             for (int j = 0; j < old_count; ++j)
-                if (info.hash[i] == old_hash[j]) { A.jn[i] = old_jn[j]; A.jt[i] = old_jt[j]; }
+                if (info.hash[i] == old_hash[j]) { jn = old_jn[j]; jt = old_jt[j]; }
+            A.cf(i, AC_R1X) = r1.x; A.cf(i, AC_R1Y) = r1.y; A.cf(i, AC_R2X) = r2.x; A.cf(i, AC_R2Y) = r2.y;
+            A.cf(i, AC_JN) = jn; A.cf(i, AC_JT) = jt;
+            hh[i] = info.hash[i];
         }
         if (state == ST_CACHED) state = ST_FIRST;
-        A.state = state;
+        const unsigned ints = (unsigned)pid | ((unsigned)a << 8) | ((unsigned)b << 16) | ((unsigned)info.count << 24) | ((unsigned)state << 28);
+        A.f(A_INTS) = __longlong_as_double((long long)ints);
+        A.f(A_HASH) = __longlong_as_double((long long)(((unsigned long long)hh[1] << 32) | hh[0]));
         touched |= 1ull << pid;
         live |= 1ull << pid;
     };
 
-    for (int g = 0; g < c.n_goals; ++g) {
+    Info info;
+    for (int g = 0; g < ng; ++g) {
         if (!((gmask >> g) & 1u)) continue;
-        for (int s = 0; s < 2; ++s) collide_pair(kSlotGoal0 + g, s, pid_gb(g, s));
-        for (int h = 0; h < g; ++h)
-            if ((gmask >> h) & 1u) collide_pair(kSlotGoal0 + h, kSlotGoal0 + g, pid_gg(h, g));
+        const CircleShape cg = goal_shape(g);
+        const BB gb = cg.bb();
+        for (int s = 0; s < 2; ++s) {
+            const BankShape bs = bank_shape(s);
+            if (!bb_hit(gb, bs.box)) continue; // queryReject
+            collide(cg, bs, info);
+            push(info, g, slot_static, pid_gb(g, s), 0.0);
+        }
+        for (int h = 0; h < g; ++h) {
+            if (!((gmask >> h) & 1u)) continue;
+            const CircleShape ch = goal_shape(h);
+            if (!bb_hit(ch.bb(), gb)) continue;
+            collide(ch, cg, info);
+            push(info, h, g, pid_gg(h, g), 0.0);
+        }
     }
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        for (int s = 0; s < 2; ++s) collide_pair(kSlotTraffic0 + k, s, pid_tb(k, s));
-        for (int g = 0; g < c.n_goals; ++g)
-            if ((gmask >> g) & 1u) collide_pair(kSlotGoal0 + g, kSlotTraffic0 + k, pid_gt(g, k));
-        for (int j = 0; j < k; ++j) collide_pair(kSlotTraffic0 + j, kSlotTraffic0 + k, pid_tt(j, k));
+        const ShipShape sk = ship_shape(k);
+        const BB kb = sk.bb();
+        for (int s = 0; s < 2; ++s) {
+            const BankShape bs = bank_shape(s);
+            if (!bb_hit(kb, bs.box)) continue;
+            collide(sk, bs, info);
+            push(info, slot_ship0 + k, slot_static, pid_tb(k, s), d.ship_friction * 0.0);
+        }
+        for (int g = 0; g < ng; ++g) {
+            if (!((gmask >> g) & 1u)) continue;
+            const CircleShape cg = goal_shape(g);
+            if (!bb_hit(cg.bb(), kb)) continue;
+            collide(cg, sk, info);
+            push(info, g, slot_ship0 + k, pid_gt(g, k), 0.0 * d.ship_friction);
+        }
+        for (int j = 0; j < k; ++j) {
+            const ShipShape sj = ship_shape(j);
+            if (!bb_hit(sj.bb(), kb)) continue;
+            collide(sj, sk, info);
+            push(info, slot_ship0 + j, slot_ship0 + k, pid_tt(j, k), d.ship_friction * d.ship_friction);
+        }
     }
 
+    if (d.stop_after == 3) return;
     // ---- cpSpaceArbiterSetFilter for the cached arbiters that were not touched this step -------------------------
     {
         unsigned long long rest = live & ~touched;
@@ -578,116 +650,168 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             const int pid = __ffsll((long long)rest) - 1;
             rest &= rest - 1ull;
             unsigned meta = col.u32[(size_t)(DU_META + pid) * np + e];
-            unsigned state = meta & 7u, age = (meta >> 3) & 3u;
-            if (state == ST_FIRST) state = ST_NORMAL;
-            age += 1u;
-            if (state != ST_CACHED) state = ST_CACHED; // ticks >= 1
+            unsigned age = (meta >> 3) & 3u;
+            age += 1u; // ticks >= 1: the arbiter is (now) "cached"
             if (age >= (unsigned)kPersist) {
                 live &= ~(1ull << pid);
             } else {
-                meta = (meta & ~0x1Fu) | state | (age << 3);
+                meta = (meta & ~0x1Fu) | (unsigned)ST_CACHED | (age << 3);
                 col.u32[(size_t)(DU_META + pid) * np + e] = meta;
             }
         }
     }
 
+    auto ints_of = [&](const ArbRef &A, int &pid, int &a, int &b, int &count, int &state) {
+        const unsigned v = (unsigned)__double_as_longlong(A.f(A_INTS));
+        pid = v & 0xFF; a = (v >> 8) & 0xFF; b = (v >> 16) & 0xFF; count = (v >> 24) & 0xF; state = v >> 28;
+    };
+    auto k_scalar_body = [&](int slot, V2 r, V2 n) -> double {
+        const double rcn = cross(r, n);
+        return m_inv_of(slot) + i_inv_of(slot) * rcn * rcn;
+    };
+    auto vel = [&](int slot) -> V2 { return mk(BF(slot, B_VX), BF(slot, B_VY)); };
+    auto apply_impulse = [&](int slot, V2 j, V2 r) {
+        const V2 v = vel(slot) + j * m_inv_of(slot);
+        BF(slot, B_VX) = v.x; BF(slot, B_VY) = v.y;
+        BF(slot, B_W) += i_inv_of(slot) * cross(r, j);
+    };
+    auto apply_bias_impulse = [&](int slot, V2 j, V2 r) {
+        const V2 v = mk(BF(slot, B_VBX), BF(slot, B_VBY)) + j * m_inv_of(slot);
+        BF(slot, B_VBX) = v.x; BF(slot, B_VBY) = v.y;
+        BF(slot, B_WB) += i_inv_of(slot) * cross(r, j);
+    };
+
     // ---- cpArbiterPreStep ---------------------------------------------------------------------------------------
     for (int i = 0; i < n_act; ++i) {
-        Active &A = act[i];
-        const Body &a = bod[A.a], &b = bod[A.b];
-        const V2 n = A.n;
-        const V2 body_delta = b.p - a.p;
-        for (int k = 0; k < A.count; ++k) {
-            A.nMass[k] = 1.0 / (k_scalar_body(a, A.r1[k], n) + k_scalar_body(b, A.r2[k], n));
-            A.tMass[k] = 1.0 / (k_scalar_body(a, A.r1[k], perp(n)) + k_scalar_body(b, A.r2[k], perp(n)));
-            const double dist = dot((A.r2[k] - A.r1[k]) + body_delta, n);
-            A.bias[k] = -d.bias_coef * cmin(0.0, dist + d.slop) / dt;
-            A.jBias[k] = 0.0;
-            A.bounce[k] = dot(relative_velocity(a, b, A.r1[k], A.r2[k]), n) * 0.0; // arb->e = 0 for every shape here
+        const ArbRef A = arb(i);
+        int pid, a, b, count, state;
+        ints_of(A, pid, a, b, count, state);
+        const V2 n = mk(A.f(A_NX), A.f(A_NY));
+        const V2 body_delta = mk(BF(b, B_PX), BF(b, B_PY)) - mk(BF(a, B_PX), BF(a, B_PY));
+        for (int k = 0; k < count; ++k) {
+            const V2 r1 = mk(A.cf(k, AC_R1X), A.cf(k, AC_R1Y)), r2 = mk(A.cf(k, AC_R2X), A.cf(k, AC_R2Y));
+            A.cf(k, AC_NMASS) = 1.0 / (k_scalar_body(a, r1, n) + k_scalar_body(b, r2, n));
+            A.cf(k, AC_TMASS) = 1.0 / (k_scalar_body(a, r1, perp(n)) + k_scalar_body(b, r2, perp(n)));
+            const double dist = dot((r2 - r1) + body_delta, n);
+            A.cf(k, AC_BIAS) = -d.bias_coef * cmin(0.0, dist + d.slop) / dt;
+            A.cf(k, AC_JBIAS) = 0.0;
+            // con->bounce = normal_relative_velocity * e with e = 0 for every shape on this path: +-0, carried as 0
         }
     }
+    if (d.stop_after == 4) return;
     // ---- (4) cpBodyUpdateVelocity (no forces on these bodies) -------------------------------------------------------
-    for (int s = kSlotGoal0; s < kSlots; ++s) {
-        Body &b = bod[s];
-        if (b.m_inv == 0.0) continue;
-        b.v = b.v * c.damp + (mk(0, 0) + mk(0, 0) * b.m_inv) * dt;
-        b.w = b.w * c.damp + 0.0 * b.i_inv * dt;
+    for (int s = 0; s < slot_static; ++s) {
+        if (s < ng && !((gmask >> s) & 1u)) continue; // goal no longer in the space
+        const V2 v = vel(s) * c.damp + (mk(0, 0) + mk(0, 0) * m_inv_of(s)) * dt;
+        BF(s, B_VX) = v.x; BF(s, B_VY) = v.y;
+        BF(s, B_W) = BF(s, B_W) * c.damp + 0.0 * i_inv_of(s) * dt;
     }
     // ---- (5) cached impulses (dt_coef = dt/prev_dt = 1; first contacts skip), then the solver ----------------------
     for (int i = 0; i < n_act; ++i) {
-        Active &A = act[i];
-        if (A.state == ST_FIRST) continue;
-        Body &a = bod[A.a], &b = bod[A.b];
-        for (int k = 0; k < A.count; ++k) {
-            const V2 j = rotate(A.n, mk(A.jn[k], A.jt[k])) * 1.0;
-            apply_impulse(a, neg(j), A.r1[k]);
-            apply_impulse(b, j, A.r2[k]);
+        const ArbRef A = arb(i);
+        int pid, a, b, count, state;
+        ints_of(A, pid, a, b, count, state);
+        if (state == ST_FIRST) continue;
+        const V2 n = mk(A.f(A_NX), A.f(A_NY));
+        for (int k = 0; k < count; ++k) {
+            const V2 r1 = mk(A.cf(k, AC_R1X), A.cf(k, AC_R1Y)), r2 = mk(A.cf(k, AC_R2X), A.cf(k, AC_R2Y));
+            const V2 j = rotate(n, mk(A.cf(k, AC_JN), A.cf(k, AC_JT))) * 1.0;
+            apply_impulse(a, neg(j), r1);
+            apply_impulse(b, j, r2);
         }
     }
     for (int it = 0; it < kIter; ++it) {
         for (int i = 0; i < n_act; ++i) {
-            Active &A = act[i];
-            Body &a = bod[A.a], &b = bod[A.b];
-            const V2 n = A.n;
-            for (int k = 0; k < A.count; ++k) {
-                const V2 r1 = A.r1[k], r2 = A.r2[k];
-                const V2 vb1 = a.vb + perp(r1) * a.wb;
-                const V2 vb2 = b.vb + perp(r2) * b.wb;
-                const V2 vr = relative_velocity(a, b, r1, r2) + mk(0, 0);
+            const ArbRef A = arb(i);
+            int pid, a, b, count, state;
+            ints_of(A, pid, a, b, count, state);
+            const V2 n = mk(A.f(A_NX), A.f(A_NY));
+            const double u = A.f(A_U);
+            for (int k = 0; k < count; ++k) {
+                const V2 r1 = mk(A.cf(k, AC_R1X), A.cf(k, AC_R1Y)), r2 = mk(A.cf(k, AC_R2X), A.cf(k, AC_R2Y));
+                const double nMass = A.cf(k, AC_NMASS), tMass = A.cf(k, AC_TMASS), bias = A.cf(k, AC_BIAS);
+                const V2 vb1 = mk(BF(a, B_VBX), BF(a, B_VBY)) + perp(r1) * BF(a, B_WB);
+                const V2 vb2 = mk(BF(b, B_VBX), BF(b, B_VBY)) + perp(r2) * BF(b, B_WB);
+                const V2 v1 = vel(a) + perp(r1) * BF(a, B_W);
+                const V2 v2 = vel(b) + perp(r2) * BF(b, B_W);
+                const V2 vr = (v2 - v1) + mk(0, 0);
                 const double vbn = dot(vb2 - vb1, n);
                 const double vrn = dot(vr, n);
                 const double vrt = dot(vr, perp(n));
-                const double jbn = (A.bias[k] - vbn) * A.nMass[k];
-                const double jbnOld = A.jBias[k];
-                A.jBias[k] = cmax(jbnOld + jbn, 0.0);
-                const double jn = -(A.bounce[k] + vrn) * A.nMass[k];
-                const double jnOld = A.jn[k];
-                A.jn[k] = cmax(jnOld + jn, 0.0);
-                const double jtMax = A.u * A.jn[k];
-                const double jt = -vrt * A.tMass[k];
-                const double jtOld = A.jt[k];
-                A.jt[k] = cclamp(jtOld + jt, -jtMax, jtMax);
-                const V2 jb = n * (A.jBias[k] - jbnOld);
+                const double jbn = (bias - vbn) * nMass;
+                const double jbnOld = A.cf(k, AC_JBIAS);
+                const double jBias = cmax(jbnOld + jbn, 0.0);
+                const double jn = -(0.0 + vrn) * nMass;
+                const double jnOld = A.cf(k, AC_JN);
+                const double jnAcc = cmax(jnOld + jn, 0.0);
+                const double jtMax = u * jnAcc;
+                const double jt = -vrt * tMass;
+                const double jtOld = A.cf(k, AC_JT);
+                const double jtAcc = cclamp(jtOld + jt, -jtMax, jtMax);
+                A.cf(k, AC_JBIAS) = jBias; A.cf(k, AC_JN) = jnAcc; A.cf(k, AC_JT) = jtAcc;
+                const V2 jb = n * (jBias - jbnOld);
                 apply_bias_impulse(a, neg(jb), r1);
                 apply_bias_impulse(b, jb, r2);
-                const V2 j = rotate(n, mk(A.jn[k] - jnOld, A.jt[k] - jtOld));
+                const V2 j = rotate(n, mk(jnAcc - jnOld, jtAcc - jtOld));
                 apply_impulse(a, neg(j), r1);
                 apply_impulse(b, j, r2);
             }
         }
     }
 
+    if (d.stop_after == 5) return;
     // ---- write back -----------------------------------------------------------------------------------------------
     for (int i = 0; i < n_act; ++i) {
-        const Active &A = act[i];
-        col.u32[(size_t)(DU_META + A.pid) * np + e] = (unsigned)A.state | (0u << 3) | ((unsigned)A.count << 5);
-        if (A.pid < kPolyPairs)
-            col.u32[(size_t)(DU_HASH + A.pid) * np + e] = (A.hash[0] & 0xFFFFu) | ((A.count > 1 ? A.hash[1] : 0u) << 16);
-        double *acc = col.f64 + (size_t)(DC_ARB + 4 * A.pid) * np + e;
-        acc[0 * np] = A.jn[0]; acc[1 * np] = A.count > 1 ? A.jn[1] : 0.0;
-        acc[2 * np] = A.jt[0]; acc[3 * np] = A.count > 1 ? A.jt[1] : 0.0;
+        const ArbRef A = arb(i);
+        int pid, a, b, count, state;
+        ints_of(A, pid, a, b, count, state);
+        col.u32[(size_t)(DU_META + pid) * np + e] = (unsigned)state | (0u << 3) | ((unsigned)count << 5);
+        if (pid < kPolyPairs) {
+            const unsigned long long hh = (unsigned long long)__double_as_longlong(A.f(A_HASH));
+            col.u32[(size_t)(DU_HASH + pid) * np + e] = ((unsigned)hh & 0xFFFFu) | ((count > 1 ? (unsigned)(hh >> 32) : 0u) << 16);
+        }
+        double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
+        acc[0 * np] = A.cf(0, AC_JN); acc[1 * np] = count > 1 ? A.cf(1, AC_JN) : 0.0;
+        acc[2 * np] = A.cf(0, AC_JT); acc[3 * np] = count > 1 ? A.cf(1, AC_JT) : 0.0;
     }
-    for (int g = 0; g < c.n_goals; ++g) {
+    for (int g = 0; g < ng; ++g) {
         if (!((gmask >> g) & 1u)) continue;
         double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
-        const Body &b = bod[kSlotGoal0 + g];
-        q[0 * np] = b.p.x; q[1 * np] = b.p.y; q[2 * np] = b.v.x; q[3 * np] = b.v.y; q[4 * np] = b.vb.x; q[5 * np] = b.vb.y;
-        q[6 * np] = b.w; q[7 * np] = b.wb;
+        q[0 * np] = BF(g, B_PX); q[1 * np] = BF(g, B_PY); q[2 * np] = BF(g, B_VX); q[3 * np] = BF(g, B_VY);
+        q[4 * np] = BF(g, B_VBX); q[5 * np] = BF(g, B_VBY); q[6 * np] = BF(g, B_W); q[7 * np] = BF(g, B_WB);
     }
+#pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-        const Body &b = bod[kSlotTraffic0 + k];
-        t[0 * np] = b.p.x; t[1 * np] = b.p.y; t[2 * np] = b.a; t[3 * np] = b.v.x; t[4 * np] = b.v.y; t[5 * np] = b.w;
-        t[6 * np] = b.vb.x; t[7 * np] = b.vb.y; t[8 * np] = b.wb;
+        const int s = slot_ship0 + k;
+        t[0 * np] = BF(s, B_PX); t[1 * np] = BF(s, B_PY); t[2 * np] = L(xbase + X_STRIDE * k + X_A);
+        t[3 * np] = BF(s, B_VX); t[4 * np] = BF(s, B_VY); t[5 * np] = BF(s, B_W);
+        t[6 * np] = BF(s, B_VBX); t[7 * np] = BF(s, B_VBY); t[8 * np] = BF(s, B_WB);
     }
     col.live[e] = live;
     col.flag[e] = hit ? 1 : 0;
 }
 
+size_t dyn_lds_bytes(int n_goals)
+{
+    const int doubles = B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb;
+    return ((size_t)doubles * 64 + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
+}
+
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
 {
     const int block = 64;
-    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), 0, stream, c, d);
+    const size_t lds = dyn_lds_bytes(c.n_goals);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    DynCfg dd = d;
+    if (const char *sv = getenv("SSG_DYN_STOP")) dd.stop_after = atoi(sv);
+    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), lds, stream, c, dd);
     return hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ struct DynCfg {
     double goal_m_inv, goal_i_inv;
     double ship_friction;  // 0.7 (models.py:98); banks and goals keep Chipmunk's default 0
     double bias_coef, slop; // 1 - pow(collisionBias, dt), collisionSlop
+    int stop_after;         // development aid (SSG_DYN_STOP): leave the dyn kernel after phase n; 0 = run it all
 };
 
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions_kn, int K, double *obs,

@@ -1035,7 +1035,7 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
 // (this file compiled with -DSSG_NB_GROUP=0..3, four beam counts each) so the library builds in parallel.
 // ---------------------------------------------------------------------------------------------------------
 using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *, int);
-// variant: 0 = default, 1 = SSG_FLAG_EXACT_LIDAR (beam counts 8 and 10), 2 = config 4 / DYN (64 envs per workgroup)
+// variant: 0 = default, 1 = SSG_FLAG_EXACT_LIDAR (beam counts 8 and 10), 2 = config 4 / DYN (64 or 256 envs per workgroup)
 
 #ifdef SSG_NB_GROUP
 template <int NB, int EPW>
@@ -1048,7 +1048,7 @@ static step_fn_t step_fn_nb(bool lds, int variant)
         else return nullptr;
     }
     if (variant == 2) {
-        if constexpr (EPW == 64) return lds ? step_kernel<NB, EPW, true, false, true> : step_kernel<NB, EPW, false, false, true>;
+        if constexpr (EPW != 128) return lds ? step_kernel<NB, EPW, true, false, true> : step_kernel<NB, EPW, false, false, true>;
         else return nullptr;
     }
     return lds ? step_kernel<NB, EPW, true, false, false> : step_kernel<NB, EPW, false, false, false>;

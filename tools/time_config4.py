@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Timing of BASELINE configs[3] (65 536 envs x 4 ships, 10 beams): dyn kernel + DYN step kernel per step."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from ship_sim_gym_amd.vec_env import ShipVecEnv
+
+n = int(os.environ.get("N", "65536"))
+K, W = int(os.environ.get("K", "300")), 50
+vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
+acts = vec.random_actions(12345, 0, K + W)
+vec.reset_tensor()
+vec.rollout_tensor(acts[:W])
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+vec.rollout_tensor(acts[W:])
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+B = 96 * 4 + 8 + 8 + 2 + 80 + 4 + 4 + 16 * 10 + 8 * 16 + 8 * 2 * 16 + 9   # SURVEY 8(d), S=4, nb=10, H=2 = 1043
+print(json.dumps({"config": "C4 %d envs x 4 ships, 10 beams" % n, "us_per_step": ms * 1e3 / K,
+                  "env_steps_per_s": n * K / (ms * 1e-3), "algorithmic_GBps": B * n * K / (ms * 1e-3) / 1e9,
+                  "stats": vec.stats()}))
