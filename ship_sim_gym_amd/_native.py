@@ -16,7 +16,7 @@ MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES,
 FLAG_AUTO_RESET, FLAG_FIX_COLLISION_REWARD, FLAG_BANK_IN_GLOBAL, FLAG_EXACT_LIDAR = 0x1, 0x2, 0x4, 0x8
 EV_COLLIDING, EV_GOAL_REACHED, EV_OUT_OF_BOUNDS, EV_MAX_STEPS, EV_NO_GOALS_LEFT = 0x1, 0x2, 0x4, 0x8, 0x10
 (F_X, F_Y, F_VX, F_VY, F_ANGLE, F_W, F_CUM_REWARD, F_LIDAR, F_RUDDER, F_STEP_COUNT, F_MAP_ID, F_GOAL_MASK,
- F_STATS, F_TRAFFIC, F_GOAL_BODIES) = range(15)
+ F_STATS, F_TRAFFIC, F_GOAL_BODIES, F_DYN_FLAGS) = range(16)
 
 # every symbol include/shipsim.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = (

@@ -19,6 +19,7 @@ struct ssg_handle {
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
+    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0;
     ssg::DynCfg dyn{};
     void *state = nullptr;
     const double *bank = nullptr;
@@ -321,6 +322,9 @@ void refresh_dev(ssg_handle *h)
     d.dyn_live = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_live) : nullptr;
     d.dyn_u32 = dyn ? reinterpret_cast<uint32_t *>(base + h->off_dyn_u32) : nullptr;
     d.dyn_flag = dyn ? reinterpret_cast<uint8_t *>(base + h->off_dyn_flag) : nullptr;
+    d.dyn_hash = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_hash) : nullptr;
+    d.dyn_queue = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_queue) : nullptr;
+    d.dyn_count = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_count) : nullptr;
 }
 
 
@@ -449,7 +453,10 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_live = h->off_dyn_f64 + (size_t)ssg::DC_COUNT * np * sizeof(double);
         h->off_dyn_u32 = h->off_dyn_live + np * sizeof(unsigned long long);
         h->off_dyn_flag = h->off_dyn_u32 + (size_t)ssg::DU_COUNT * np * sizeof(uint32_t);
-        h->nbytes = h->off_dyn_flag + np;
+        h->off_dyn_hash = h->off_dyn_flag + np;
+        h->off_dyn_queue = h->off_dyn_hash + np * sizeof(unsigned long long);
+        h->off_dyn_count = h->off_dyn_queue + np * sizeof(int32_t);
+        h->nbytes = h->off_dyn_count + 256;
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -493,6 +500,9 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
         const int c0 = field == SSG_F_TRAFFIC ? ssg::DC_TRAFFIC : ssg::DC_GOALS;
         off = h->off_dyn_f64 + (size_t)c0 * np * 8; es = 8;
         nc = field == SSG_F_TRAFFIC ? 9 * SSG_N_TRAFFIC : ssg::DC_GOAL_COLS * SSG_MAX_GOALS;
+    } else if (field == SSG_F_DYN_FLAGS) {
+        if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
+        off = h->off_dyn_flag; es = 1; nc = 1;
     } else if (field == SSG_F_STATS) {
         // kStatsSlots rows of 4 int64 counters; sum over rows: [0] sum_return*100 [1] sum_length [2] episodes [3] goals
         off = h->off_stats; es = 8; nc = 4 * ssg::kStatsSlots;
@@ -528,6 +538,7 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64; // the config-4 step kernel is built for 64 and 256
     h->bank = dev_bank;
     h->n_maps = n_maps;
+    h->dyn.bank_epoch++; // resting traffic must be re-collided against the new banks
     // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch
     h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
              ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) <= 160u * 1024u;
@@ -635,6 +646,7 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
     hipError_t e = ssg::launch_generate_bank(seed, n_maps, h->cfg.n_goals, h->cfg.width, h->cfg.height, width_frac,
                                              h->cfg.spawn_x, h->cfg.spawn_y, dev_bank, dev_raw, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("generate_bank launch: ") + hipGetErrorString(e));
+    if (dev_bank == h->bank) h->dyn.bank_epoch++; // regenerated in place
     return SSG_OK;
 }
 

@@ -42,7 +42,7 @@ extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-unif
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
 constexpr int kMaxGjk = 30, kMaxEpa = 30;
-constexpr int kLdsArb = 3;         // arbiter records per env held in LDS; further ones (rare) go to scratch
+constexpr int kLdsArb = 5;         // arbiter records per env held in LDS; further ones (rare) go to scratch
 constexpr int kMaxActive = 8;      // arbiters on one env's solver list
 enum { ST_NONE = 0, ST_FIRST = 1, ST_NORMAL = 2, ST_IGNORE = 3, ST_CACHED = 4 };
 
@@ -152,15 +152,18 @@ struct ShipShape {
     }
 };
 
-// A river bank: static body at the origin, planes straight from the map record (v0x v0y nx ny ... per plane).
+// A river bank: static body at the origin.  Its planes (v0, n per vertex) are staged from the map record into this
+// lane's LDS columns right before the narrowphase that needs them (all 48 loads in flight at once): GJK / EPA call
+// support() a dozen times in a dependent chain, and each call straight from L2 was a round trip.
+constexpr int kBankDoubles = 4 * SSG_MAX_HULL;
 struct BankShape {
-    const double *pl; // plane j at pl + SSG_PLANE_DOUBLES * j
+    int base; // index in lds[] of this lane's staged plane 0 (field stride 64)
     int n;
     BB box;
     unsigned hashid;
     static constexpr bool is_circle = false;
-    __device__ __forceinline__ V2 vert(int i) const { return mk(pl[SSG_PLANE_DOUBLES * i], pl[SSG_PLANE_DOUBLES * i + 1]); }
-    __device__ __forceinline__ V2 normal(int i) const { return mk(pl[SSG_PLANE_DOUBLES * i + 2], pl[SSG_PLANE_DOUBLES * i + 3]); }
+    __device__ __forceinline__ V2 vert(int i) const { return mk(lds[base + (4 * i) * 64], lds[base + (4 * i + 1) * 64]); }
+    __device__ __forceinline__ V2 normal(int i) const { return mk(lds[base + (4 * i + 2) * 64], lds[base + (4 * i + 3) * 64]); }
     __device__ __forceinline__ BB bb() const { return box; }
     __device__ __forceinline__ Sup support(V2 nn) const
     {
@@ -242,34 +245,68 @@ __device__ __forceinline__ Closest closest_new(const Mink &v0, const Mink &v1)
     return r;
 }
 
+// EPA's growing hull: two buffers of kEpaLds entries {a, b} per lane in LDS columns (ab = b - a is recomputed: the same
+// expression that produced it), entries beyond that (practically never) in scratch.
+constexpr int kEpaLds = 7;
+constexpr int kEpaDoubles = 2 * kEpaLds * 4;
+struct EpaMem {
+    int base; // index in lds[] of this lane's buffer 0 entry 0 field 0 (field stride 64)
+    Mink *ov; // [2][kMaxEpa + 4 - kEpaLds]
+    __device__ __forceinline__ Mink get(int buf, int i) const
+    {
+        if (i < kEpaLds) {
+            const int o = base + ((buf * kEpaLds + i) * 4) * 64;
+            Mink m;
+            m.a = mk(lds[o], lds[o + 64]); m.b = mk(lds[o + 128], lds[o + 192]);
+            m.ab = m.b - m.a;
+            return m;
+        }
+        return ov[buf * (kMaxEpa + 4 - kEpaLds) + i - kEpaLds];
+    }
+    __device__ __forceinline__ void set(int buf, int i, const Mink &m) const
+    {
+        if (i < kEpaLds) {
+            const int o = base + ((buf * kEpaLds + i) * 4) * 64;
+            lds[o] = m.a.x; lds[o + 64] = m.a.y; lds[o + 128] = m.b.x; lds[o + 192] = m.b.y;
+        } else {
+            ov[buf * (kMaxEpa + 4 - kEpaLds) + i - kEpaLds] = m;
+        }
+    }
+};
+
 template <class SA, class SB>
-__device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v0, const Mink &v1, const Mink &v2)
+__device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v0, const Mink &v1, const Mink &v2, const EpaMem &mem)
 {
-    Mink bufa[kMaxEpa + 4], bufb[kMaxEpa + 4]; // scratch; only the entries a query touches ever reach memory
-    Mink *hull = bufa, *hull2 = bufb;
+    int cur = 0; // buffer holding the hull; the other one receives the rebuilt hull
     int count = 3;
-    hull[0] = v0; hull[1] = v1; hull[2] = v2;
+    mem.set(0, 0, v0); mem.set(0, 1, v1); mem.set(0, 2, v2);
     for (int iteration = 1;; ++iteration) {
         int mini = 0;
         double min_dist = INFINITY;
-        for (int j = 0, i = count - 1; j < count; i = j, ++j) {
-            const double d = closest_dist(hull[i].ab, hull[j].ab);
-            if (d < min_dist) { min_dist = d; mini = i; }
+        {
+            V2 hi = mem.get(cur, count - 1).ab;
+            for (int j = 0, i = count - 1; j < count; i = j, ++j) {
+                const V2 hj = mem.get(cur, j).ab;
+                const double d = closest_dist(hi, hj);
+                if (d < min_dist) { min_dist = d; mini = i; }
+                hi = hj;
+            }
         }
-        const Mink e0 = hull[mini], e1 = hull[(mini + 1) % count];
+        const Mink e0 = mem.get(cur, mini), e1 = mem.get(cur, (mini + 1) % count);
         const Mink p = support(s1, s2, perp(e1.ab - e0.ab));
         const double area2x = cross(e1.ab - e0.ab, (p.ab - e0.ab) + (p.ab - e1.ab));
         if (area2x > 0.0 && iteration < kMaxEpa) {
             int count2 = 1;
-            hull2[0] = p;
+            mem.set(cur ^ 1, 0, p);
+            V2 h0 = p.ab; // ab of the last entry written to the new hull
             for (int i = 0; i < count; ++i) {
                 const int index = (mini + 1 + i) % count;
-                const V2 h0 = hull2[count2 - 1].ab;
-                const V2 h1 = hull[index].ab;
-                const V2 h2 = (i + 1 < count) ? hull[(index + 1) % count].ab : p.ab;
-                if (cross(h2 - h0, h1 - h0) > 0.0) hull2[count2++] = hull[index];
+                const Mink hm = mem.get(cur, index);
+                const V2 h1 = hm.ab;
+                const V2 h2 = (i + 1 < count) ? mem.get(cur, (index + 1) % count).ab : p.ab;
+                if (cross(h2 - h0, h1 - h0) > 0.0) { mem.set(cur ^ 1, count2++, hm); h0 = h1; }
             }
-            Mink *tmp = hull; hull = hull2; hull2 = tmp;
+            cur ^= 1;
             count = count2;
         } else {
             return closest_new(e0, e1);
@@ -278,7 +315,7 @@ __device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v
 }
 
 template <class SA, class SB>
-__device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2)
+__device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2, const EpaMem &mem)
 {
     const V2 axis = perp(bb_center(s1.bb()) - bb_center(s2.bb())); // cold start (no cached collision id)
     Mink v0 = support(s1, s2, axis);
@@ -295,7 +332,7 @@ __device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2)
         const V2 n = (-1.0 < t && t < 1.0) ? perp(delta) : neg(lerp_t(v0.ab, v1.ab, t));
         const Mink p = support(s1, s2, n);
         if (cross(v1.ab - p.ab, v1.ab + p.ab) > 0.0 && cross(v0.ab - p.ab, v0.ab + p.ab) < 0.0)
-            return epa(s1, s2, v0, p, v1);
+            return epa(s1, s2, v0, p, v1, mem);
         if (dot(p.ab, n) <= cmax(dot(v0.ab, n), dot(v1.ab, n))) return closest_new(v0, v1);
         if (closest_dist(v0.ab, p.ab) < closest_dist(p.ab, v1.ab)) v1 = p; else v0 = p;
         ++iteration;
@@ -335,7 +372,7 @@ __device__ __forceinline__ void contact_points(const Edge &e1, const Edge &e2, c
 }
 
 template <class SA, class SB>
-__device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info)
+__device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info, const EpaMem &mem)
 {
     info.count = 0;
     info.n = mk(0, 0);
@@ -352,7 +389,7 @@ __device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info)
             info.count = 1;
         }
     } else if constexpr (SA::is_circle) { // CircleToPoly
-        const Closest points = gjk(a, b);
+        const Closest points = gjk(a, b, mem);
         const double mindist = a.rad + 0.0;
         if (points.d <= mindist) {
             const V2 n = info.n = points.n;
@@ -362,7 +399,7 @@ __device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info)
             info.count = 1;
         }
     } else { // PolyToPoly
-        const Closest points = gjk(a, b);
+        const Closest points = gjk(a, b, mem);
         if (points.d - 0.0 - 0.0 <= 0.0) contact_points(a.support_edge(points.n), b.support_edge(neg(points.n)), points, info);
     }
 }
@@ -420,12 +457,15 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
     col.live[e] = 0ull;
 }
 
-// A field of an arbiter record: LDS column (stride 64 doubles) for the first kLdsArb records, scratch beyond.
+// An arbiter record: LDS columns of this lane (stride 64 doubles) for the first kLdsArb records of an env, scratch
+// beyond (rare; never touched otherwise).  No generic pointers: FLAT accesses to LDS stall on both counters.
 struct ArbRef {
-    double *p;
-    int stride;
-    __device__ __forceinline__ double &f(int i) const { return p[i * stride]; }
-    __device__ __forceinline__ double &cf(int k, int i) const { return p[(A_CON0 + k * AC_STRIDE + i) * stride]; }
+    int base;   // index of field 0 in lds[] for this lane, or -1
+    double *ov; // scratch record otherwise
+    __device__ __forceinline__ double get(int f) const { return base >= 0 ? lds[base + f * 64] : ov[f]; }
+    __device__ __forceinline__ void set(int f, double v) const { if (base >= 0) lds[base + f * 64] = v; else ov[f] = v; }
+    __device__ __forceinline__ double cget(int k, int f) const { return get(A_CON0 + k * AC_STRIDE + f); }
+    __device__ __forceinline__ void cset(int k, int f, double v) const { set(A_CON0 + k * AC_STRIDE + f, v); }
 };
 
 } // namespace
@@ -444,38 +484,161 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
     col.flag[e] = 0;
 }
 
+// Hash of everything a resting env's next step depends on besides its arbiter columns: the cpBody fields of the ships
+// and goals, which goals are in the space, which pairs have cached arbiters, the map and the bank generation.
+// Guards the rest bit against callers that write the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns or swap the bank.
+__device__ __forceinline__ unsigned long long mix(unsigned long long h, unsigned long long v)
+{
+    h = (h ^ v) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+__device__ __forceinline__ unsigned long long mixd(unsigned long long h, double v)
+{
+    return mix(h, (unsigned long long)__double_as_longlong(v));
+}
+
+// Stage the hull constants ([0] the player, [1..3] the traffic ships; vertices then normals) at lds[cbase ..].
+__device__ __forceinline__ void stage_hulls(const DevCfg &c, const DynCfg &d, int cbase, int tid)
+{
+    if (tid < kHullDoubles) {
+        const int i = tid % (2 * SSG_SHIP_VERTS);
+        const bool nr = tid >= 2 * SSG_SHIP_VERTS;
+        lds[cbase + tid] = nr ? c.nrm[i] : c.hull[i];
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) lds[cbase + kHullDoubles * (1 + k) + tid] = nr ? d.tnrm[k][i] : d.thull[k][i];
+    }
+}
+
+// The player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel).
+__device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int hoff)
+{
+    const size_t np = (size_t)c.n_pad;
+    const double x = c.f64cols[(size_t)COL_X * np + e], y = c.f64cols[(size_t)COL_Y * np + e];
+    const double vx = c.f64cols[(size_t)COL_VX * np + e], vy = c.f64cols[(size_t)COL_VY * np + e];
+    const double ang = c.f64cols[(size_t)COL_A * np + e], w = c.f64cols[(size_t)COL_W * np + e];
+    ShipShape pl;
+    pl.hoff = hoff; pl.hashid = 0;
+    pl.p = mk(x + vx * c.dt, y + vy * c.dt);
+    sincos(ang + w * c.dt, &pl.sa, &pl.ca);
+    return pl;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pass 1, every env.  cpSpaceStep is a deterministic function of the bodies' cpBody fields, the cached arbiters and
+// the static banks (the player never pushes anything: PLAYER assumption).  When a full step wrote back exactly the
+// bits it had read -- every body field, every arbiter's state / age / contact hashes / accumulated impulses, the live
+// mask -- the space is at a fixed point: the next step is the identity.  (That is how a ship resting against a bank
+// ends up: the penetration left beyond the slop shrinks by 99.8 % per step until position + bias*dt rounds to the
+// position.)  The full step records that as the rest bit plus a hash of the body fields; as long as both still
+// hold, these bodies are skipped and only the player's collide_ship test against the parked traffic is left.
+// Everything else is appended to the queue of pass 2.  In steady state that is the few steps after each reset in
+// which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dyn_classify_kernel(const DevCfg c, const DynCfg d)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    stage_hulls(c, d, 0, threadIdx.x);
+    __syncthreads();
+    const bool valid = e < c.n_envs;
+    bool need_full = false;
+    if (valid) {
+        DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
+        const size_t np = col.np;
+        const int ng = c.n_goals;
+        const int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
+        const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
+        const unsigned flag = col.flag[e];
+        if (flag & 2u) dyn_init(c, d, col, e, rec); // the step kernel auto-reset this env at the end of the last step
+        const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
+        // deferred space.remove of goals the player reached last step (game.py:252): their cached arbiters go too
+        const unsigned long long live0 = col.live[e];
+        unsigned long long live = live0;
+        for (int g = 0; g < ng; ++g) {
+            if ((gmask >> g) & 1u) continue;
+            for (int s = 0; s < 2; ++s) live &= ~(1ull << pid_gb(g, s));
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) live &= ~(1ull << pid_gt(g, k));
+            for (int h = 0; h < ng; ++h)
+                if (h != g) live &= ~(1ull << (h < g ? pid_gg(h, g) : pid_gg(g, h)));
+        }
+        if (live != live0) col.live[e] = live;
+        bool rest = ((flag & 6u) == 4u);
+        bool hit = false;
+        if (rest) { // wave-divergent, but the loads below are what the check costs
+            unsigned long long hsh = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live);
+            const ShipShape pl = player_shape(c, e, 0);
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+                ShipShape sk;
+                sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
+                sk.p = mk(t[0 * np], t[1 * np]);
+                const double a = t[2 * np];
+                for (int f = 0; f < 9; ++f) hsh = mixd(hsh, t[(size_t)f * np]);
+                sincos(a, &sk.sa, &sk.ca);
+                hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
+            }
+            for (int g = 0; g < ng; ++g) {
+                if (!((gmask >> g) & 1u)) continue;
+                const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
+                unsigned long long go = 0ull; // same field order as the full step writes: p, v, v_bias, w, w_bias
+                const int ford[DC_GOAL_COLS] = {0, 1, 2, 3, 4, 5, 6, 7};
+                for (int f = 0; f < DC_GOAL_COLS; ++f) go = mixd(go, q[(size_t)ford[f] * np]);
+                hsh = mix(hsh, go);
+            }
+            rest &= (hsh == c.dyn_hash[e]);
+        }
+        if (rest) col.flag[e] = (uint8_t)(4u | (hit ? 1u : 0u));
+        need_full = !rest;
+    }
+    // compact the envs that need the full step (wave-aggregated append)
+    const unsigned long long m = __ballot(need_full);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(c.dyn_count, (unsigned)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (need_full) c.dyn_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pass 2: the full cpSpaceStep of the queued envs, one lane per env, one wave per workgroup.
+// ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * 64 + lane;
-    const int cbase = 64 * (B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb);
-    if (lane < kHullDoubles) { // hull constants: [0] the player, [1..3] the traffic ships; vertices then normals
-        const int i = lane % (2 * SSG_SHIP_VERTS);
-        const bool nr = lane >= 2 * SSG_SHIP_VERTS;
-        lds[cbase + lane] = nr ? c.nrm[i] : c.hull[i];
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) lds[cbase + kHullDoubles * (1 + k) + lane] = nr ? d.tnrm[k][i] : d.thull[k][i];
-    }
+    const unsigned n_queued = *c.dyn_count;
+    if ((unsigned)blockIdx.x * 64u >= n_queued) return; // wave-uniform: nothing queued for this workgroup
+    const bool queued = (unsigned)blockIdx.x * 64u + (unsigned)lane < n_queued;
+    const int e = queued ? c.dyn_queue[blockIdx.x * 64 + lane] : 0;
+    const int lane_doubles = B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
+                             kBankDoubles + kEpaDoubles;
+    const int cbase = 64 * lane_doubles;
+    stage_hulls(c, d, cbase, lane);
     __builtin_amdgcn_s_waitcnt(0xC07F); // one wave per workgroup: the LDS writes above are visible to its lanes
     __builtin_amdgcn_wave_barrier();
-    if (e >= c.n_envs) return;
+    if (!queued) return;
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
     const size_t np = col.np;
     const double dt = c.dt;
     const int ng = c.n_goals;
     const int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
     const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
-    if (col.flag[e] & 2) dyn_init(c, d, col, e, rec); // the step kernel auto-reset this env at the end of the last step
+    // development aid (SSG_DYN_STOP=-1): phase stamps of this lane's wave into the unused arbiter rows of pair 50..53
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int i) {
+        if (d.stop_after == -1)
+            col.f64[(size_t)(DC_ARB + 4 * 50 + i) * np + e] = (double)(__builtin_amdgcn_s_memtime() - t_start);
+    };
     const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
-    unsigned long long live = col.live[e];
-
-    // deferred space.remove of goals the player reached last step (game.py:252): their cached arbiters go too
-    for (int g = 0; g < ng; ++g) {
-        if ((gmask >> g) & 1u) continue;
-        for (int s = 0; s < 2; ++s) live &= ~(1ull << pid_gb(g, s));
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) live &= ~(1ull << pid_gt(g, k));
-        for (int h = 0; h < ng; ++h)
-            if (h != g) live &= ~(1ull << (h < g ? pid_gg(h, g) : pid_gg(g, h)));
-    }
+    unsigned long long live = col.live[e]; // (pass 1 rebuilt the bodies after a reset and dropped removed goals' arbiters)
+    const unsigned long long live0 = live;
+    // Did this step write back anything but the bits it read?  Compared through 64-bit hashes of what is read and of
+    // what is written (re-reading the columns at write-back would put ~80 dependent round trips on the chain).
+    bool changed = false;
+    unsigned long long hin = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live0);
+    unsigned long long ain = 0ull, aout = 0ull; // order-independent (xor) over the touched arbiters
+    auto arb_hash = [&](int pid, unsigned meta, unsigned hh, double j0, double j1, double t0, double t1) -> unsigned long long {
+        return mixd(mixd(mixd(mixd(mix(mix(mix(0x7F4A7C15ull, (unsigned)pid), meta), hh), j0), j1), t0), t1);
+    };
 
     // ---- LDS columns of this lane ---------------------------------------------------------------------------
     const int slot_ship0 = ng, slot_static = ng + SSG_N_TRAFFIC;
@@ -491,11 +654,15 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     };
 
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
-    for (int g = 0; g < ng; ++g) {
+    unsigned long long gin[SSG_MAX_GOALS] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // per-goal input hashes (unrolled: registers)
+#pragma unroll
+    for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+        if (g >= ng) continue;
         if (!((gmask >> g) & 1u)) continue;
         const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
         const V2 p = mk(q[0 * np], q[1 * np]), v = mk(q[2 * np], q[3 * np]), vb = mk(q[4 * np], q[5 * np]);
-        const double w = q[6 * np];
+        const double w = q[6 * np], wb = q[7 * np];
+        gin[g] = mixd(mixd(mixd(mixd(mixd(mixd(mixd(mixd(0ull, p.x), p.y), v.x), v.y), vb.x), vb.y), w), wb);
         const V2 pn = p + (v + vb) * dt; // (the angle of a circle body is never read)
         BF(g, B_PX) = pn.x; BF(g, B_PY) = pn.y; BF(g, B_VX) = v.x; BF(g, B_VY) = v.y; BF(g, B_W) = w;
         BF(g, B_VBX) = 0.0; BF(g, B_VBY) = 0.0; BF(g, B_WB) = 0.0;
@@ -505,6 +672,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
         const V2 p = mk(t[0 * np], t[1 * np]), v = mk(t[3 * np], t[4 * np]), vb = mk(t[6 * np], t[7 * np]);
         const double a = t[2 * np], w = t[5 * np], wb = t[8 * np];
+        { const double v9[9] = {p.x, p.y, a, v.x, v.y, w, vb.x, vb.y, wb};
+#pragma unroll
+          for (int f = 0; f < 9; ++f) hin = mixd(hin, v9[f]); }
         const V2 pn = p + (v + vb) * dt;
         const double an = a + (w + wb) * dt;
         double sa, ca;
@@ -522,38 +692,62 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         s.hashid = (unsigned)(2 + SSG_MAX_GOALS + k);
         return s;
     };
-    auto bank_shape = [&](int s) -> BankShape {
+    // both banks' vertex counts and AABBs up front (one round trip); planes are staged on demand
+    double bk[2][5];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bk[s][0] = rec[SSG_MAP_OFF_COUNTS + s];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bk[s][1 + f] = rec[SSG_MAP_OFF_AABB + 4 * s + f];
+    }
+    const int bbase = (abase + A_STRIDE * kLdsArb) * 64 + lane, ebase = bbase + kBankDoubles * 64;
+    int staged = -1;
+    auto bank_box = [&](int s) -> BB {
+        BB o;
+        o.l = s ? bk[1][1] : bk[0][1]; o.b = s ? bk[1][2] : bk[0][2]; o.r = s ? bk[1][3] : bk[0][3]; o.t = s ? bk[1][4] : bk[0][4];
+        return o;
+    };
+    auto bank_shape = [&](int s) -> BankShape { // stages bank s's planes if they are not the ones in LDS
+        if (staged != s) {
+            const double *pl = rec + SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES;
+            double tmp[kBankDoubles];
+#pragma unroll
+            for (int j = 0; j < SSG_MAX_HULL; ++j)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) tmp[4 * j + f] = pl[SSG_PLANE_DOUBLES * j + f]; // all 12 slots exist in the record
+#pragma unroll
+            for (int q = 0; q < kBankDoubles; ++q) lds[bbase + q * 64] = tmp[q];
+            staged = s;
+        }
         BankShape b;
-        b.pl = rec + SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES;
-        b.n = (int)rec[SSG_MAP_OFF_COUNTS + s];
-        b.box.l = rec[SSG_MAP_OFF_AABB + 4 * s + 0]; b.box.b = rec[SSG_MAP_OFF_AABB + 4 * s + 1];
-        b.box.r = rec[SSG_MAP_OFF_AABB + 4 * s + 2]; b.box.t = rec[SSG_MAP_OFF_AABB + 4 * s + 3];
+        b.base = bbase;
+        b.n = (int)(s ? bk[1][0] : bk[0][0]);
+        b.box = bank_box(s);
         b.hashid = (unsigned)s;
         return b;
     };
+    Mink epa_ov[2 * (kMaxEpa + 4 - kEpaLds)];
+    EpaMem emem;
+    emem.base = ebase; emem.ov = epa_ov;
     auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
 
+    stamp(0);
     if (d.stop_after == 1) return;
     // the player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel) against traffic
     bool hit = false;
     {
-        const double x = c.f64cols[(size_t)COL_X * np + e], y = c.f64cols[(size_t)COL_Y * np + e];
-        const double vx = c.f64cols[(size_t)COL_VX * np + e], vy = c.f64cols[(size_t)COL_VY * np + e];
-        const double ang = c.f64cols[(size_t)COL_A * np + e], w = c.f64cols[(size_t)COL_W * np + e];
-        ShipShape pl;
-        pl.hoff = cbase; pl.hashid = 0;
-        pl.p = mk(x + vx * dt, y + vy * dt);
-        sincos(ang + w * dt, &pl.sa, &pl.ca);
+        const ShipShape pl = player_shape(c, e, cbase);
         for (int k = 0; k < SSG_N_TRAFFIC; ++k) hit |= ships_touch(pl, ship_shape(k)); // collide_ship: type 0 x type 1
     }
 
+    stamp(1);
     if (d.stop_after == 2) return;
     // ---- (3) collide, canonical order ---------------------------------------------------------------------------
     double ovf[(kMaxActive - kLdsArb) * A_STRIDE]; // records beyond the LDS ones: scratch, touched only when used
     auto arb = [&](int i) -> ArbRef {
         ArbRef r;
-        if (i < kLdsArb) { r.p = &lds[(abase + A_STRIDE * i) * 64 + lane]; r.stride = 64; }
-        else { r.p = &ovf[(i - kLdsArb) * A_STRIDE]; r.stride = 1; }
+        r.base = (i < kLdsArb) ? (abase + A_STRIDE * i) * 64 + lane : -1;
+        r.ov = &ovf[(i < kLdsArb ? 0 : i - kLdsArb) * A_STRIDE];
         return r;
     };
     int n_act = 0;
@@ -575,11 +769,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             }
             const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
             old_jn[0] = acc[0 * np]; old_jn[1] = acc[1 * np]; old_jt[0] = acc[2 * np]; old_jt[1] = acc[3 * np];
+            ain ^= arb_hash(pid, meta & ~0x18u, (pid < kPolyPairs) ? (old_hash[0] | old_hash[1] << 16) : 0u, old_jn[0], old_jn[1],
+                            old_jt[0], old_jt[1]); // (age bits are 0 for an arbiter touched every step; a cached one changes anyway)
+            if ((meta >> 3) & 3u) changed = true;
             if (state == ST_FIRST) state = ST_NORMAL; // it was on last step's solver list
         }
         if (state == ST_NONE) { state = ST_FIRST; old_count = 0; } // cpArbiterInit
         const ArbRef A = arb(n_act++);
-        A.f(A_NX) = info.n.x; A.f(A_NY) = info.n.y; A.f(A_U) = u;
+        A.set(A_NX, info.n.x); A.set(A_NY, info.n.y); A.set(A_U, u);
         const V2 pa = mk(BF(a, B_PX), BF(a, B_PY)), pb = mk(BF(b, B_PX), BF(b, B_PY));
         unsigned hh[2] = {0u, 0u};
         for (int i = 0; i < info.count; ++i) { // cpArbiterUpdate
@@ -587,14 +784,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             double jn = 0.0, jt = 0.0;
             for (int j = 0; j < old_count; ++j)
                 if (info.hash[i] == old_hash[j]) { jn = old_jn[j]; jt = old_jt[j]; }
-            A.cf(i, AC_R1X) = r1.x; A.cf(i, AC_R1Y) = r1.y; A.cf(i, AC_R2X) = r2.x; A.cf(i, AC_R2Y) = r2.y;
-            A.cf(i, AC_JN) = jn; A.cf(i, AC_JT) = jt;
+            A.cset(i, AC_R1X, r1.x); A.cset(i, AC_R1Y, r1.y); A.cset(i, AC_R2X, r2.x); A.cset(i, AC_R2Y, r2.y);
+            A.cset(i, AC_JN, jn); A.cset(i, AC_JT, jt);
             hh[i] = info.hash[i];
         }
         if (state == ST_CACHED) state = ST_FIRST;
         const unsigned ints = (unsigned)pid | ((unsigned)a << 8) | ((unsigned)b << 16) | ((unsigned)info.count << 24) | ((unsigned)state << 28);
-        A.f(A_INTS) = __longlong_as_double((long long)ints);
-        A.f(A_HASH) = __longlong_as_double((long long)(((unsigned long long)hh[1] << 32) | hh[0]));
+        A.set(A_INTS, __longlong_as_double((long long)ints));
+        A.set(A_HASH, __longlong_as_double((long long)(((unsigned long long)hh[1] << 32) | hh[0])));
         touched |= 1ull << pid;
         live |= 1ull << pid;
     };
@@ -605,16 +802,16 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const CircleShape cg = goal_shape(g);
         const BB gb = cg.bb();
         for (int s = 0; s < 2; ++s) {
+            if (!bb_hit(gb, bank_box(s))) continue; // queryReject
             const BankShape bs = bank_shape(s);
-            if (!bb_hit(gb, bs.box)) continue; // queryReject
-            collide(cg, bs, info);
+            collide(cg, bs, info, emem);
             push(info, g, slot_static, pid_gb(g, s), 0.0);
         }
         for (int h = 0; h < g; ++h) {
             if (!((gmask >> h) & 1u)) continue;
             const CircleShape ch = goal_shape(h);
             if (!bb_hit(ch.bb(), gb)) continue;
-            collide(ch, cg, info);
+            collide(ch, cg, info, emem);
             push(info, h, g, pid_gg(h, g), 0.0);
         }
     }
@@ -622,26 +819,27 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const ShipShape sk = ship_shape(k);
         const BB kb = sk.bb();
         for (int s = 0; s < 2; ++s) {
+            if (!bb_hit(kb, bank_box(s))) continue;
             const BankShape bs = bank_shape(s);
-            if (!bb_hit(kb, bs.box)) continue;
-            collide(sk, bs, info);
+            collide(sk, bs, info, emem);
             push(info, slot_ship0 + k, slot_static, pid_tb(k, s), d.ship_friction * 0.0);
         }
         for (int g = 0; g < ng; ++g) {
             if (!((gmask >> g) & 1u)) continue;
             const CircleShape cg = goal_shape(g);
             if (!bb_hit(cg.bb(), kb)) continue;
-            collide(cg, sk, info);
+            collide(cg, sk, info, emem);
             push(info, g, slot_ship0 + k, pid_gt(g, k), 0.0 * d.ship_friction);
         }
         for (int j = 0; j < k; ++j) {
             const ShipShape sj = ship_shape(j);
             if (!bb_hit(sj.bb(), kb)) continue;
-            collide(sj, sk, info);
+            collide(sj, sk, info, emem);
             push(info, slot_ship0 + j, slot_ship0 + k, pid_tt(j, k), d.ship_friction * d.ship_friction);
         }
     }
 
+    stamp(2);
     if (d.stop_after == 3) return;
     // ---- cpSpaceArbiterSetFilter for the cached arbiters that were not touched this step -------------------------
     {
@@ -652,6 +850,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             unsigned meta = col.u32[(size_t)(DU_META + pid) * np + e];
             unsigned age = (meta >> 3) & 3u;
             age += 1u; // ticks >= 1: the arbiter is (now) "cached"
+            changed = true; // an ageing arbiter is a state change by itself
             if (age >= (unsigned)kPersist) {
                 live &= ~(1ull << pid);
             } else {
@@ -662,7 +861,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     }
 
     auto ints_of = [&](const ArbRef &A, int &pid, int &a, int &b, int &count, int &state) {
-        const unsigned v = (unsigned)__double_as_longlong(A.f(A_INTS));
+        const unsigned v = (unsigned)__double_as_longlong(A.get(A_INTS));
         pid = v & 0xFF; a = (v >> 8) & 0xFF; b = (v >> 16) & 0xFF; count = (v >> 24) & 0xF; state = v >> 28;
     };
     auto k_scalar_body = [&](int slot, V2 r, V2 n) -> double {
@@ -686,18 +885,19 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const ArbRef A = arb(i);
         int pid, a, b, count, state;
         ints_of(A, pid, a, b, count, state);
-        const V2 n = mk(A.f(A_NX), A.f(A_NY));
+        const V2 n = mk(A.get(A_NX), A.get(A_NY));
         const V2 body_delta = mk(BF(b, B_PX), BF(b, B_PY)) - mk(BF(a, B_PX), BF(a, B_PY));
         for (int k = 0; k < count; ++k) {
-            const V2 r1 = mk(A.cf(k, AC_R1X), A.cf(k, AC_R1Y)), r2 = mk(A.cf(k, AC_R2X), A.cf(k, AC_R2Y));
-            A.cf(k, AC_NMASS) = 1.0 / (k_scalar_body(a, r1, n) + k_scalar_body(b, r2, n));
-            A.cf(k, AC_TMASS) = 1.0 / (k_scalar_body(a, r1, perp(n)) + k_scalar_body(b, r2, perp(n)));
+            const V2 r1 = mk(A.cget(k, AC_R1X), A.cget(k, AC_R1Y)), r2 = mk(A.cget(k, AC_R2X), A.cget(k, AC_R2Y));
+            A.cset(k, AC_NMASS, 1.0 / (k_scalar_body(a, r1, n) + k_scalar_body(b, r2, n)));
+            A.cset(k, AC_TMASS, 1.0 / (k_scalar_body(a, r1, perp(n)) + k_scalar_body(b, r2, perp(n))));
             const double dist = dot((r2 - r1) + body_delta, n);
-            A.cf(k, AC_BIAS) = -d.bias_coef * cmin(0.0, dist + d.slop) / dt;
-            A.cf(k, AC_JBIAS) = 0.0;
+            A.cset(k, AC_BIAS, -d.bias_coef * cmin(0.0, dist + d.slop) / dt);
+            A.cset(k, AC_JBIAS, 0.0);
             // con->bounce = normal_relative_velocity * e with e = 0 for every shape on this path: +-0, carried as 0
         }
     }
+    stamp(3);
     if (d.stop_after == 4) return;
     // ---- (4) cpBodyUpdateVelocity (no forces on these bodies) -------------------------------------------------------
     for (int s = 0; s < slot_static; ++s) {
@@ -712,10 +912,10 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         int pid, a, b, count, state;
         ints_of(A, pid, a, b, count, state);
         if (state == ST_FIRST) continue;
-        const V2 n = mk(A.f(A_NX), A.f(A_NY));
+        const V2 n = mk(A.get(A_NX), A.get(A_NY));
         for (int k = 0; k < count; ++k) {
-            const V2 r1 = mk(A.cf(k, AC_R1X), A.cf(k, AC_R1Y)), r2 = mk(A.cf(k, AC_R2X), A.cf(k, AC_R2Y));
-            const V2 j = rotate(n, mk(A.cf(k, AC_JN), A.cf(k, AC_JT))) * 1.0;
+            const V2 r1 = mk(A.cget(k, AC_R1X), A.cget(k, AC_R1Y)), r2 = mk(A.cget(k, AC_R2X), A.cget(k, AC_R2Y));
+            const V2 j = rotate(n, mk(A.cget(k, AC_JN), A.cget(k, AC_JT))) * 1.0;
             apply_impulse(a, neg(j), r1);
             apply_impulse(b, j, r2);
         }
@@ -725,81 +925,110 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             const ArbRef A = arb(i);
             int pid, a, b, count, state;
             ints_of(A, pid, a, b, count, state);
-            const V2 n = mk(A.f(A_NX), A.f(A_NY));
-            const double u = A.f(A_U);
+            const V2 n = mk(A.get(A_NX), A.get(A_NY));
+            const double u = A.get(A_U);
+            const double ma = m_inv_of(a), ia = i_inv_of(a), mb = m_inv_of(b), ib = i_inv_of(b);
             for (int k = 0; k < count; ++k) {
-                const V2 r1 = mk(A.cf(k, AC_R1X), A.cf(k, AC_R1Y)), r2 = mk(A.cf(k, AC_R2X), A.cf(k, AC_R2Y));
-                const double nMass = A.cf(k, AC_NMASS), tMass = A.cf(k, AC_TMASS), bias = A.cf(k, AC_BIAS);
-                const V2 vb1 = mk(BF(a, B_VBX), BF(a, B_VBY)) + perp(r1) * BF(a, B_WB);
-                const V2 vb2 = mk(BF(b, B_VBX), BF(b, B_VBY)) + perp(r2) * BF(b, B_WB);
-                const V2 v1 = vel(a) + perp(r1) * BF(a, B_W);
-                const V2 v2 = vel(b) + perp(r2) * BF(b, B_W);
+                // one batch of LDS reads (the record's contact fields, both bodies' velocity fields), the arithmetic of
+                // cpArbiterApplyImpulse, one batch of writes: a and b are different bodies, so the four apply_*impulse
+                // updates need not re-read what the previous one wrote
+                const V2 r1 = mk(A.cget(k, AC_R1X), A.cget(k, AC_R1Y)), r2 = mk(A.cget(k, AC_R2X), A.cget(k, AC_R2Y));
+                const double nMass = A.cget(k, AC_NMASS), tMass = A.cget(k, AC_TMASS), bias = A.cget(k, AC_BIAS);
+                const double jbnOld = A.cget(k, AC_JBIAS), jnOld = A.cget(k, AC_JN), jtOld = A.cget(k, AC_JT);
+                const V2 a_v = vel(a), b_v = vel(b), a_vb = mk(BF(a, B_VBX), BF(a, B_VBY)), b_vb = mk(BF(b, B_VBX), BF(b, B_VBY));
+                const double a_w = BF(a, B_W), b_w = BF(b, B_W), a_wb = BF(a, B_WB), b_wb = BF(b, B_WB);
+                const V2 vb1 = a_vb + perp(r1) * a_wb;
+                const V2 vb2 = b_vb + perp(r2) * b_wb;
+                const V2 v1 = a_v + perp(r1) * a_w;
+                const V2 v2 = b_v + perp(r2) * b_w;
                 const V2 vr = (v2 - v1) + mk(0, 0);
                 const double vbn = dot(vb2 - vb1, n);
                 const double vrn = dot(vr, n);
                 const double vrt = dot(vr, perp(n));
                 const double jbn = (bias - vbn) * nMass;
-                const double jbnOld = A.cf(k, AC_JBIAS);
                 const double jBias = cmax(jbnOld + jbn, 0.0);
                 const double jn = -(0.0 + vrn) * nMass;
-                const double jnOld = A.cf(k, AC_JN);
                 const double jnAcc = cmax(jnOld + jn, 0.0);
                 const double jtMax = u * jnAcc;
                 const double jt = -vrt * tMass;
-                const double jtOld = A.cf(k, AC_JT);
                 const double jtAcc = cclamp(jtOld + jt, -jtMax, jtMax);
-                A.cf(k, AC_JBIAS) = jBias; A.cf(k, AC_JN) = jnAcc; A.cf(k, AC_JT) = jtAcc;
+                A.cset(k, AC_JBIAS, jBias); A.cset(k, AC_JN, jnAcc); A.cset(k, AC_JT, jtAcc);
                 const V2 jb = n * (jBias - jbnOld);
-                apply_bias_impulse(a, neg(jb), r1);
-                apply_bias_impulse(b, jb, r2);
                 const V2 j = rotate(n, mk(jnAcc - jnOld, jtAcc - jtOld));
-                apply_impulse(a, neg(j), r1);
-                apply_impulse(b, j, r2);
+                const V2 njb = neg(jb), nj = neg(j);
+                const V2 a_vb2 = a_vb + njb * ma, b_vb2 = b_vb + jb * mb; // apply_bias_impulses
+                const double a_wb2 = a_wb + ia * cross(r1, njb), b_wb2 = b_wb + ib * cross(r2, jb);
+                const V2 a_v2 = a_v + nj * ma, b_v2 = b_v + j * mb;       // apply_impulses
+                const double a_w2 = a_w + ia * cross(r1, nj), b_w2 = b_w + ib * cross(r2, j);
+                BF(a, B_VBX) = a_vb2.x; BF(a, B_VBY) = a_vb2.y; BF(a, B_WB) = a_wb2;
+                BF(a, B_VX) = a_v2.x; BF(a, B_VY) = a_v2.y; BF(a, B_W) = a_w2;
+                BF(b, B_VBX) = b_vb2.x; BF(b, B_VBY) = b_vb2.y; BF(b, B_WB) = b_wb2;
+                BF(b, B_VX) = b_v2.x; BF(b, B_VY) = b_v2.y; BF(b, B_W) = b_w2;
             }
         }
     }
 
+    stamp(4);
     if (d.stop_after == 5) return;
-    // ---- write back -----------------------------------------------------------------------------------------------
+    // ---- write back, hashing what is written --------------------------------------------------------------------------
     for (int i = 0; i < n_act; ++i) {
         const ArbRef A = arb(i);
         int pid, a, b, count, state;
         ints_of(A, pid, a, b, count, state);
-        col.u32[(size_t)(DU_META + pid) * np + e] = (unsigned)state | (0u << 3) | ((unsigned)count << 5);
-        if (pid < kPolyPairs) {
-            const unsigned long long hh = (unsigned long long)__double_as_longlong(A.f(A_HASH));
-            col.u32[(size_t)(DU_HASH + pid) * np + e] = ((unsigned)hh & 0xFFFFu) | ((count > 1 ? (unsigned)(hh >> 32) : 0u) << 16);
-        }
+        if (!((live0 >> pid) & 1ull)) changed = true; // a new arbiter
+        const unsigned meta = (unsigned)state | (0u << 3) | ((unsigned)count << 5);
+        const unsigned long long hh64 = (unsigned long long)__double_as_longlong(A.get(A_HASH));
+        const unsigned hh = (pid < kPolyPairs) ? (((unsigned)hh64 & 0xFFFFu) | ((count > 1 ? (unsigned)(hh64 >> 32) : 0u) << 16)) : 0u;
+        const double j0 = A.cget(0, AC_JN), j1 = count > 1 ? A.cget(1, AC_JN) : 0.0;
+        const double t0 = A.cget(0, AC_JT), t1 = count > 1 ? A.cget(1, AC_JT) : 0.0;
+        aout ^= arb_hash(pid, meta, hh, j0, j1, t0, t1);
+        col.u32[(size_t)(DU_META + pid) * np + e] = meta;
+        if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + e] = hh;
         double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
-        acc[0 * np] = A.cf(0, AC_JN); acc[1 * np] = count > 1 ? A.cf(1, AC_JN) : 0.0;
-        acc[2 * np] = A.cf(0, AC_JT); acc[3 * np] = count > 1 ? A.cf(1, AC_JT) : 0.0;
+        acc[0 * np] = j0; acc[1 * np] = j1; acc[2 * np] = t0; acc[3 * np] = t1;
     }
-    for (int g = 0; g < ng; ++g) {
-        if (!((gmask >> g) & 1u)) continue;
-        double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
-        q[0 * np] = BF(g, B_PX); q[1 * np] = BF(g, B_PY); q[2 * np] = BF(g, B_VX); q[3 * np] = BF(g, B_VY);
-        q[4 * np] = BF(g, B_VBX); q[5 * np] = BF(g, B_VBY); q[6 * np] = BF(g, B_W); q[7 * np] = BF(g, B_WB);
-    }
-#pragma unroll
+    unsigned long long hsh = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live);
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
         const int s = slot_ship0 + k;
-        t[0 * np] = BF(s, B_PX); t[1 * np] = BF(s, B_PY); t[2 * np] = L(xbase + X_STRIDE * k + X_A);
-        t[3 * np] = BF(s, B_VX); t[4 * np] = BF(s, B_VY); t[5 * np] = BF(s, B_W);
-        t[6 * np] = BF(s, B_VBX); t[7 * np] = BF(s, B_VBY); t[8 * np] = BF(s, B_WB);
+        const double v[9] = {BF(s, B_PX), BF(s, B_PY), L(xbase + X_STRIDE * k + X_A), BF(s, B_VX), BF(s, B_VY), BF(s, B_W),
+                             BF(s, B_VBX), BF(s, B_VBY), BF(s, B_WB)};
+#pragma unroll
+        for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; hsh = mixd(hsh, v[f]); }
     }
+#pragma unroll
+    for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+        if (g >= ng || !((gmask >> g) & 1u)) continue;
+        double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
+        const double v[DC_GOAL_COLS] = {BF(g, B_PX), BF(g, B_PY), BF(g, B_VX), BF(g, B_VY), BF(g, B_VBX), BF(g, B_VBY),
+                                        BF(g, B_W), BF(g, B_WB)};
+        unsigned long long go = 0ull;
+#pragma unroll
+        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; go = mixd(go, v[f]); }
+        hin = mix(hin, gin[g]);
+        hsh = mix(hsh, go);
+    }
+    changed |= (hin != hsh) | (ain != aout);
+    stamp(5);
+    if (d.stop_after == -1) col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + e] = (double)n_act;
     col.live[e] = live;
-    col.flag[e] = hit ? 1 : 0;
+    c.dyn_hash[e] = hsh;
+    col.flag[e] = (uint8_t)((hit ? 1u : 0u) | (changed ? 0u : 4u)); // unchanged = a fixed point of cpSpaceStep: at rest
 }
 
 size_t dyn_lds_bytes(int n_goals)
 {
-    const int doubles = B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb;
+    const int doubles = B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
+                        kBankDoubles + kEpaDoubles;
     return ((size_t)doubles * 64 + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
 }
 
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
 {
+    // pass 1 over every env, then pass 2 over the queue it built (grid sized for the worst case; workgroups past the
+    // queue's end leave at once).  The step kernel that follows empties the queue counter.
+    hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256),
+                       (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, d);
     const int block = 64;
     const size_t lds = dyn_lds_bytes(c.n_goals);
     static bool attr_set = false;

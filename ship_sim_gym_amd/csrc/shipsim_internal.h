@@ -62,6 +62,10 @@ struct DevCfg {
     unsigned long long *dyn_live; // bit p: pair p has a cached arbiter
     uint8_t *dyn_flag;            // bit 0: player touches a traffic ship this step (dyn -> step kernel);
                                   // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
+                                  // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
+    unsigned long long *dyn_hash; // pose hash the rest bit was established for
+    int32_t *dyn_queue;           // envs that need the full dyn step this step (compacted by dyn_classify_kernel)
+    unsigned *dyn_count;          // length of dyn_queue; zeroed by the step kernel
 };
 
 // Constants of the traffic ships and of Chipmunk's solver, by value to the dyn kernels only.
@@ -71,6 +75,7 @@ struct DynCfg {
     double goal_m_inv, goal_i_inv;
     double ship_friction;  // 0.7 (models.py:98); banks and goals keep Chipmunk's default 0
     double bias_coef, slop; // 1 - pow(collisionBias, dt), collisionSlop
+    unsigned bank_epoch;    // bumped whenever the map bank changes: part of the pose hash
     int stop_after;         // development aid (SSG_DYN_STOP): leave the dyn kernel after phase n; 0 = run it all
 };
 
@@ -79,7 +84,7 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
-hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream);
+hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream); // classify + full step of the queue
 hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
 hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);

@@ -764,7 +764,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         for (int i = 0; i < NB; ++i) lid[i] = ld_f64(colLid + (size_t)i * np + el2, fresh);
     }
     bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
-    if constexpr (DYN) colliding |= (c.dyn_flag[el_] & 1) != 0; // ... and against the traffic ships (dyn kernel)
+    unsigned dflag = 0;
+    if constexpr (DYN) {
+        dflag = c.dyn_flag[el_];
+        colliding |= (dflag & 1u) != 0; // ... and against the traffic ships (dyn kernels)
+        if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
+    }
 
     // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role 0 accumulated; forces are
     //      cleared afterwards.  (The narrowphase reads positions only, so doing this last changes nothing.) ----
@@ -904,7 +909,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     if constexpr (DYN) {
         if (live) {
-            c.dyn_flag[el_] = do_reset ? 2 : 0; // tells the dyn kernel to rebuild this env's traffic / goal bodies
+            // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
+            c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
             c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = do_reset ? rs_gx : nf_gx;
             c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = do_reset ? rs_gy : nf_gy;
         }

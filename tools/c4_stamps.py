@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Development aid: per-phase s_memtime stamps of the config-4 full dyn step (run with SSG_DYN_STOP=-1)."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import numpy as np
+from ship_sim_gym_amd.vec_env import ShipVecEnv
+from ship_sim_gym_amd import _native as N
+n = int(os.environ.get("N", "4096"))
+vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
+acts = vec.random_actions(12345, 0, 120)
+vec.reset_tensor()
+vec.rollout_tensor(acts)
+off, es, nc, stride = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t()
+N.check(N.lib().ssg_state_field(vec._h, N.F_TRAFFIC, C.byref(off), C.byref(es), C.byref(nc), C.byref(stride)), vec._h, "f")
+npad = stride.value // 8
+DC_ARB = 27 + 8 * 6
+cols = vec.state[off.value: off.value + (DC_ARB + 4 * 54 + 2) * npad * 8].view(torch.float64).view(-1, npad)
+st = cols[DC_ARB + 200: DC_ARB + 207, :n].cpu().numpy()
+fl = vec.field(N.F_DYN_FLAGS).cpu().numpy()
+sel = st[5] > 0
+print("envs with stamps", sel.sum(), "of", n)
+names = ["load+pos", "player hit", "collide", "prestep", "vel+solver", "writeback"]
+prev = np.zeros(sel.sum())
+for i, nm in enumerate(names):
+    cur = st[i][sel]
+    print("%-12s median %8.0f  p90 %8.0f  max %8.0f cycles" % (nm, np.median(cur - prev), np.percentile(cur - prev, 90), (cur - prev).max()))
+    prev = cur
+print("total median %8.0f max %8.0f ; n_act hist" % (np.median(st[5][sel]), st[5][sel].max()), np.bincount(st[6][sel].astype(int)))

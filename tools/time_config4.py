@@ -22,6 +22,12 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 B = 96 * 4 + 8 + 8 + 2 + 80 + 4 + 4 + 16 * 10 + 8 * 16 + 8 * 2 * 16 + 9   # SURVEY 8(d), S=4, nb=10, H=2 = 1043
+from ship_sim_gym_amd import _native as N
+fl = vec.field(N.F_DYN_FLAGS)
+rest_frac = float(((fl & 4) != 0).double().mean())
+steps = vec.field(N.F_STEP_COUNT)
+print("rest fraction %.3f; mean step_count %.1f; rest among step_count>=6: %.3f" % (
+    rest_frac, float(steps.double().mean()), float(((fl & 4) != 0)[steps >= 6].double().mean())))
 print(json.dumps({"config": "C4 %d envs x 4 ships, 10 beams" % n, "us_per_step": ms * 1e3 / K,
                   "env_steps_per_s": n * K / (ms * 1e-3), "algorithmic_GBps": B * n * K / (ms * 1e-3) / 1e9,
                   "stats": vec.stats()}))
