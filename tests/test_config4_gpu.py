@@ -149,3 +149,40 @@ def test_config4_full_size_properties():
     st = vec.stats()
     assert st["episodes"] > n // 2
     vec.close()
+
+
+def test_config4_rest_bit_and_poke_at_rest():
+    """The dyn step skips envs whose bodies are at a fixed point of cpSpaceStep (rest bit).  The skip must be invisible:
+    parity continues while most envs rest, and writing the traffic columns of a resting env wakes it up."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    n = 512
+    vec = ShipVecEnv(n, n_maps=32, n_ships=4, auto_reset=True)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    vec.reset_tensor(); ob.reset()
+    ones = torch.ones(n, dtype=torch.int32, device=vec.device)   # rudder only: nobody dies, everything settles
+    for k in range(14):
+        obs, rew, done, flags = vec.step_tensor(ones)
+        r_obs, r_rew, r_done = ob.step(np.ones(n, dtype=np.int32))
+        np.testing.assert_array_equal(obs.cpu().numpy(), r_obs) if k < 2 else None
+    fl = vec.field(N.F_DYN_FLAGS).cpu().numpy()
+    assert ((fl & 4) != 0).mean() > 0.8                           # most spaces have reached their fixed point
+    _compare_dyn(N, vec, ob, atol=1e-9)
+    # throw ship 2 of every 3rd env at ship 3 while the env rests: the hash of the body columns no longer matches
+    T = vec.field(N.F_TRAFFIC)
+    cols = T.clone()
+    idx = np.arange(0, n, 3)
+    cols[9 + 0, idx] = 372.0; cols[9 + 1, idx] = 360.0; cols[9 + 3, idx] = 11.0; cols[9 + 5, idx] = 0.03
+    T.copy_(cols)
+    for e in idx:
+        cur = ob.peek_dyn(int(e))["traffic"][1]
+        ob.poke_traffic(int(e), 1, 372.0, 360.0, cur[2], 11.0, cur[4], 0.03)
+    for k in range(25):
+        obs, rew, done, flags = vec.step_tensor(ones)
+        r_obs, r_rew, r_done = ob.step(np.ones(n, dtype=np.int32))
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done)
+        assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
+        _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
+    t, _ = _dyn_state(N, vec)
+    assert (np.abs(t[idx, 2, 0] - 400.0) > 1e-3).mean() > 0.9     # ship 3 was really pushed in the poked envs
+    vec.close()
