@@ -42,6 +42,11 @@ class _Goal(object):
         return "Goal(%s, %s)" % (self.x, self.y)
 
 
+class _Traffic(object):
+    def __init__(self, x, y, angle):
+        self.x, self.y, self.angle = float(x), float(y), float(angle)
+
+
 class _Player(object):
     def __init__(self, env):
         self._env = env
@@ -70,9 +75,29 @@ class _GameView(object):
 
     @property
     def goals(self):
-        mask = int(self._env._vec.field(N.F_GOAL_MASK)[0].item())
-        g = self._env._vec.worlds[0][1]
+        v = self._env._vec
+        mask = int(v.field(N.F_GOAL_MASK)[0].item())
+        g = v.worlds[0][1]
+        if v.n_ships > 1:  # config 4: goals are dynamic bodies, their position is body.position (game.py:343)
+            b = v.field(N.F_GOAL_BODIES)[:, 0].cpu().numpy().reshape(N.MAX_GOALS, 8)
+            return [_Goal(b[i, 0], b[i, 1]) for i in range(len(g)) if mask & (1 << i)]
         return [_Goal(g[i, 0], g[i, 1]) for i in range(len(g)) if mask & (1 << i)]
+
+    @property
+    def ships(self):
+        """ShipGame.ships (game.py:284-286): the traffic ships of a config-4 env as (x, y, angle) views."""
+        v = self._env._vec
+        if v.n_ships <= 1:
+            return []
+        t = v.field(N.F_TRAFFIC)[:, 0].cpu().numpy().reshape(N.N_TRAFFIC, 9)
+        return [_Traffic(*t[k, :3]) for k in range(N.N_TRAFFIC)]
+
+    def add_default_traffic(self):
+        """ShipGame.add_default_traffic (game.py:279-286).  The state layout of the HIP path is fixed at construction:
+        build the env with ``n_ships=4`` and the three traffic ships are (re-)added by every reset, which is what a
+        caller of the reference does by hand after each ``reset()``; this call is then a no-op."""
+        if self._env._vec.n_ships <= 1:
+            raise N.ShipSimError("add_default_traffic: construct ShipEnv / ShipVecEnv with n_ships=4")
 
     @property
     def colliding(self):
