@@ -874,11 +874,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         BF(slot, B_VX) = v.x; BF(slot, B_VY) = v.y;
         BF(slot, B_W) += i_inv_of(slot) * cross(r, j);
     };
-    auto apply_bias_impulse = [&](int slot, V2 j, V2 r) {
-        const V2 v = mk(BF(slot, B_VBX), BF(slot, B_VBY)) + j * m_inv_of(slot);
-        BF(slot, B_VBX) = v.x; BF(slot, B_VBY) = v.y;
-        BF(slot, B_WB) += i_inv_of(slot) * cross(r, j);
-    };
 
     // ---- cpArbiterPreStep ---------------------------------------------------------------------------------------
     for (int i = 0; i < n_act; ++i) {
