@@ -514,6 +514,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         rudder = colRud[el];
     }
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
+    double cg_x = 0.0, cg_y = 0.0; // role 3: the newest frame's nearest goal, i.e. the next step's older-frame goal
 
     for (int k = 0; k < K; ++k) {
     const bool fresh = k > 0;
@@ -746,7 +747,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         pf_gx = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_];
         pf_gy = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_];
     } else {
-        if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, goff, gm0, pf_x, pf_y, pf_gx, pf_gy);
+        // = the nearest goal the previous step put into its new frame; only the first step of a launch computes it
+        if (k == 0) { if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, goff, gm0, pf_x, pf_y, pf_gx, pf_gy); }
+        else { pf_gx = cg_x; pf_gy = cg_y; }
     }
 
     SSG_STAMP(4);
@@ -915,6 +918,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = do_reset ? rs_gy : nf_gy;
         }
     }
+    if constexpr (!DYN) { cg_x = do_reset ? rs_gx : nf_gx; cg_y = do_reset ? rs_gy : nf_gy; }
     if (do_reset) {
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
         rudder = 0; steps = 0;
