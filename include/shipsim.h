@@ -215,6 +215,13 @@ int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_
 int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *dev_bank, int n_maps, double *dev_raw,
                       void *stream);
 
+/* Replaces: ShipGame.render + ShipGame.get_screen (game.py:133-138,197-229) for ONE env: an RGB frame of `width` x
+ * `height` pixels covering the env's bounds, laid out like pygame.surfarray.array3d ([x][y][3], screen y down).
+ * flags bit 0 = GameConfig.DEBUG drawing (shapes in their colours + one circle per lidar beam end); the yellow
+ * player marker is always drawn.  Debugging / video aid (`metadata['render.modes']` lists 'rgb_array',
+ * ship_env.py:18); not a hot path. */
+int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream);
+
 /* Measurement aid (no reference counterpart): coalesced 8-byte-per-lane device copy of n_doubles doubles, the
  * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);

@@ -650,6 +650,17 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
     return SSG_OK;
 }
 
+int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream)
+{
+    int rc = check_ready(h, true);
+    if (rc != SSG_OK) return rc;
+    if (!dev_rgb || env_index < 0 || env_index >= h->cfg.n_envs || width < 1 || height < 1 || width > 8192 || height > 8192)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_render: bad argument");
+    hipError_t e = ssg::launch_render(h->dev, h->dyn, env_index, width, height, dev_rgb, flags, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("render launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream)
 {
     if (!dev_src || !dev_dst) return SSG_ERR_BAD_ARG;

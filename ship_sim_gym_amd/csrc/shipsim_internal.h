@@ -86,6 +86,8 @@ hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream); // classify + full step of the queue
 hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
+hipError_t launch_render(const DevCfg &c, const DynCfg &d, int e, int width, int height, uint8_t *rgb, unsigned flags,
+                         hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
 hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);
 hipError_t launch_generate_bank(uint64_t seed, int n_maps, int n_goals, double width, double height, double width_frac,

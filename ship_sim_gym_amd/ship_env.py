@@ -194,6 +194,8 @@ class ShipEnv(_GymEnv):
 
     def render(self, mode='human', close=False):
         import sys
+        if mode == 'rgb_array':  # metadata['render.modes'] (ship_env.py:18); the reference leaves it unimplemented
+            return self._vec.render(mode='rgb_array', env=0)
         if self.last_action is not None:  # ship_env.py:165-168
             sys.stdout.write('action=%s, cumm_reward=%s' % (self.last_action, self.cumulative_reward))
 

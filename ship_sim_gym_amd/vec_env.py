@@ -286,8 +286,24 @@ class ShipVecEnv(object):
         np.random.seed(seed)
         return [seed]
 
-    def render(self, mode='human', close=False):
-        return None  # pygame rendering is out of scope
+    def get_screen(self, env=0, width=None, height=None, debug=True):
+        """ShipGame.render + get_screen (game.py:133-138,197-229) for one env: uint8 [width, height, 3] like
+        pygame.surfarray.array3d (x first, screen y down), rasterised on the GPU (csrc/shipsim_render.hip)."""
+        torch = _torch()
+        width = int(width or self.bounds[0])
+        height = int(height or self.bounds[1])
+        with torch.cuda.device(self.device):
+            img = torch.empty((width, height, 3), dtype=torch.uint8, device=self.device)
+            N.check(N.lib().ssg_render(self._h, int(env), width, height, C.c_void_p(img.data_ptr()), 1 if debug else 0,
+                                       self._stream()), self._h, "ssg_render")
+        return img
+
+    def render(self, mode='human', close=False, env=0):
+        """ShipEnv.render (ship_env.py:158-168) only writes a text line (done by the ShipEnv facade); 'rgb_array'
+        returns the frame the reference's screen would hold, as a numpy array [H, W, 3]."""
+        if mode == 'rgb_array':
+            return self.get_screen(env).permute(1, 0, 2).cpu().numpy()
+        return None
 
     def get_attr(self, name, indices=None):
         return [getattr(self, name)] * self.num_envs

@@ -435,3 +435,35 @@ def test_two_handles_with_different_bank_sizes_interleave(torch_cuda, native):
         big.step_tensor(acts[k])
     torch_cuda.cuda.synchronize()
     assert torch_cuda.equal(big.obs, ref.obs)
+
+
+@pytest.mark.gpu
+def test_rgb_array_frames():
+    """ShipGame.render / get_screen (game.py:133-138,197-229) rasterised on the GPU: colours at known world points."""
+    import torch
+    from ship_sim_gym_amd import _native as N
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    vec = ShipVecEnv(8, n_maps=8, n_ships=4)
+    vec.reset_tensor()
+    img = vec.get_screen(3).cpu().numpy()                       # [x][y][rgb], screen y down (pygame.surfarray.array3d)
+    assert img.shape == (600, 600, 3) and img.dtype == np.uint8
+
+    def at(x, y):
+        return tuple(int(v) for v in img[int(x), int(600 - y)])
+
+    assert at(300, 25) == (255, 255, 0)                          # yellow marker at the player's position (game.py:229)
+    assert at(305, 60) == (255, 255, 255)                        # the player's hull, white (game.py:275)
+    assert at(405, 370) == (0, 0, 0) and at(307, 210) == (0, 0, 0)   # traffic ships, black (game.py:284-286)
+    assert at(2, 300) == (139, 69, 19) and at(598, 300) == (139, 69, 19)   # banks (models.py:181)
+    assert at(250, 140) in ((0, 0, 200), (0, 255, 0))            # open water (or a goal / a free beam's end marker)
+    g = vec.bank_goals[3 % 8]
+    seen_green = sum(at(gx, gy) == (0, 255, 0) for gx, gy in g)
+    assert seen_green >= 3                                       # goals are green discs (game.py:88)
+    plain = vec.get_screen(3, debug=False).cpu().numpy()         # GameConfig.DEBUG off: blue screen + the yellow marker
+    cols = {tuple(c) for c in plain.reshape(-1, 3)}
+    assert cols == {(0, 0, 200), (255, 255, 0)}
+    small = vec.render(mode='rgb_array', env=3)
+    assert small.shape == (600, 600, 3) and tuple(small[600 - 25, 300]) == (255, 255, 0)   # [row = y][col = x]
+    half = vec.get_screen(3, width=300, height=300).cpu().numpy()
+    assert tuple(half[150, 300 - 13]) == (255, 255, 0)
+    vec.close()
