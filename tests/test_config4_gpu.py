@@ -186,3 +186,35 @@ def test_config4_rest_bit_and_poke_at_rest():
     t, _ = _dyn_state(N, vec)
     assert (np.abs(t[idx, 2, 0] - 400.0) > 1e-3).mean() > 0.9     # ship 3 was really pushed in the poked envs
     vec.close()
+
+
+def test_config4_curriculum_maps():
+    """BASELINE configs[3] in full: 4 ships AND curriculum maps — a lesson change installs the next river width's bank
+    (wider banks: traffic ship 1 starts deeper inside the left one) and resets; parity on the new bank."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    from ship_sim_gym_amd.curriculum import CurriculumMaps
+    n = 1024
+    vec = ShipVecEnv(n, n_maps=16, n_ships=4)
+    cm = CurriculumMaps(vec, widths=(0.5, 0.8), conditions=(0.0,), repeat_condition=0, n_maps=16)
+    vec.reset_tensor()
+    acts = vec.random_actions(7, 0, 130)
+    for k in range(12):                                           # lesson 0 runs long enough for spaces to come to rest
+        vec.step_tensor(acts[k])
+    assert ((vec.field(N.F_DYN_FLAGS) & 4) != 0).double().mean() > 0.3
+    assert cm.progress(1.0) is not None and cm.width_frac == 0.8
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    acts_h = acts.cpu().numpy()
+    moved3 = False
+    for k in range(12, 130):
+        obs, rew, done, flags = vec.step_tensor(acts[k])
+        r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
+        assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
+        if k % 10 == 0:
+            _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
+            moved3 |= bool((_dyn_state(N, vec)[0][:, 0, 0] > 170.0).any())
+    assert moved3                                                 # ship 1 is pushed out of a left bank wider than lesson 0's 150
+    vec.close()
