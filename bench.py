@@ -190,7 +190,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
-                         "kernel": "ssg::step_kernel<8, 256, true, false>", "algorithmic_bytes_per_env_step": B,
+                         "kernel": "ssg::step_kernel<8, 256, true, false, false>", "algorithmic_bytes_per_env_step": B,
                          "steps_per_launch": K / n_launch, "avg_launch_us": launch_s * 1e6,
                          "us_per_step_in_launch": launch_s * 1e6 * n_launch / K},
             "single_step_launch_us": single_us,
