@@ -564,6 +564,10 @@ static int prepare(ssg_handle *h)
     if (h->prepared) return SSG_OK;
     hipError_t e = ssg::prepare_step(h->dev, h->block, h->lds, h->lds_bytes);
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("prepare_step: ") + hipGetErrorString(e));
+    if (h->cfg.n_ships > 1) {
+        e = ssg::prepare_dyn(h->dev);
+        if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("prepare_dyn: ") + hipGetErrorString(e));
+    }
     h->prepared = true;
     return SSG_OK;
 }

@@ -1018,24 +1018,24 @@ size_t dyn_lds_bytes(int n_goals)
     return ((size_t)doubles * 64 + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
 }
 
+// Raise the dynamic-LDS cap of the full-step kernel to the CU's whole 160 KiB (once per handle, like prepare_step).
+hipError_t prepare_dyn(const DevCfg &c)
+{
+    if (dyn_lds_bytes(c.n_goals) > 160u * 1024u) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024);
+}
+
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
 {
     // pass 1 over every env, then pass 2 over the queue it built (grid sized for the worst case; workgroups past the
     // queue's end leave at once).  The step kernel that follows empties the queue counter.
     hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256),
                        (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, d);
-    const int block = 64;
-    const size_t lds = dyn_lds_bytes(c.n_goals);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
-    if (const char *sv = getenv("SSG_DYN_STOP")) dd.stop_after = atoi(sv);
-    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), lds, stream, c, dd);
+    dd.stop_after = stop_after;
+    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + 63) / 64)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
     return hipGetLastError();
 }
 

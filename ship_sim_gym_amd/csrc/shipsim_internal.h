@@ -85,6 +85,7 @@ size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream); // classify + full step of the queue
+hipError_t prepare_dyn(const DevCfg &c);
 hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_render(const DevCfg &c, const DynCfg &d, int e, int width, int height, uint8_t *rgb, unsigned flags,
                          hipStream_t stream);
