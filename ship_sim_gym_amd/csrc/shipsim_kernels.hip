@@ -687,6 +687,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         unsigned *gw = reinterpret_cast<unsigned *>(gq + 64 * SSG_MAX_GOALS);
         gw[lane] = 0u;
         int n_pairs = 0;
+        SSG_STAMP(10);
         for (int g = 0; g < c.n_goals; ++g) {
             const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
             const double gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (near) gq[pos] = (unsigned short)(lane | (g << 6));
             n_pairs += __popcll(m);
         }
+        SSG_STAMP(11);
         for (int base = 0; base < n_pairs; base += 12) {
             const int p = base + wq;
             const bool valid = (lane < 60) & (p < n_pairs);
@@ -731,6 +733,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const double sd = outside ? md : -md;
             if (valid & (wi == 0) & (sd <= c.goal_r)) atomicOr(&gw[src], 1u << g); // goal g of env src consumed
         }
+        SSG_STAMP(12);
         const unsigned gotmask = gw[lane];
         goal_reached = gotmask != 0u;
         gm &= ~gotmask;
@@ -895,6 +898,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (p0 + RP < 64) __builtin_amdgcn_s_waitcnt(0xC07F); // reads done before the next pass overwrites the tile
         }
     }
+    SSG_STAMP(13);
 #pragma unroll
     for (int i = 0; i < NB; ++i) lid[i] = do_reset ? -1.0 : ((nl[i] >= 0.0) ? nl[i] : lid[i]);
     if (live) {
@@ -931,12 +935,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         colRud[el] = rudder; colStep[el] = steps; colMap[el] = map_id;
         c.mask[el] = (uint8_t)gm;
     }
+    SSG_STAMP(14);
     if (k + 1 < K) {
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wave's state stores have reached the L2
+        SSG_STAMP(15);
         __syncthreads();               // barrier 3: the other roles may now read the next step's state
     }
     } // k
-    SSG_STAMP_FLUSH(7);
+    SSG_STAMP_FLUSH(16);
 }
 
 #ifndef SSG_NB_GROUP

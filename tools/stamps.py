@@ -38,6 +38,8 @@ for k in range(200, 300):
 b3 = b[:, 3, :, :]
 print("role 3 goals fine: 2->10 bb+consts %.0f | 10->11 near tests+queue %.0f | 11->12 pair passes %.0f | 12->3 gw read+nearest goal %.0f" % (
     (b3[..., 10] - b3[..., 2]).mean(), (b3[..., 11] - b3[..., 10]).mean(), (b3[..., 12] - b3[..., 11]).mean(), (b3[..., 3] - b3[..., 12]).mean()))
+print("role 3 post: 6->13 lidar results + obs tile + obs stores %.0f | 13->14 outputs + state stores issued %.0f | 14->15 store drain (vmcnt 0) %.0f" % (
+    (b3[..., 13] - b3[..., 6]).mean(), (b3[..., 14] - b3[..., 13]).mean(), (b3[..., 15] - b3[..., 14]).mean()))
 for r in range(4):
     print("role %d" % r)
     for nme, v in zip(names[r], acc[r] / 100):
