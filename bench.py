@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true", help="skip the informational one-launch-per-step timing")
+    ap.add_argument("--workload", choices=("c3", "c4"), default="c3",
+                    help="c3 (default, the BASELINE metric's config): 1 ship, 8 beams; c4: BASELINE configs[3], 4 ships "
+                         "(traffic + dynamic goals + contact solver), 10 beams — informational, not the headline line")
     args = ap.parse_args()
 
     import torch
@@ -114,8 +117,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     n = args.envs_per_gpu
-    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=N_BEAMS,
-                     env_id_base=rank * n, exact_lidar=bool(int(os.environ.get("SSG_EXACT_LIDAR", "0"))))
+    c4 = args.workload == "c4"
+    n_beams = 10 if c4 else N_BEAMS
+    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams,
+                     env_id_base=rank * n, exact_lidar=bool(int(os.environ.get("SSG_EXACT_LIDAR", "0"))),
+                     n_ships=4 if c4 else 1)
     if os.environ.get("SSG_ABLATE"):  # timing-only development aid (needs a -DSSG_ABLATION build)
         import ctypes as C
         vec.cfg.flags |= int(os.environ["SSG_ABLATE"], 0) << 16
@@ -164,16 +170,17 @@ def main():
 
     if rank == 0:
         total_steps = float(n) * world * K
-        B = algorithmic_bytes(1, N_BEAMS, 2)
+        B = algorithmic_bytes(4 if c4 else 1, n_beams, 2)
         # ssg_rollout fuses SSG_ROLLOUT_STEPS_PER_LAUNCH (100) steps into each launch of the step kernel:
         # algorithmic bytes per launch = B * n * steps_per_launch, launch duration = HIP-event time / launches
-        spl = int(os.environ.get("SSG_FUSE", "100"))
+        # (config 4 has no fused rollout: one "launch" below is one step = dyn classify + dyn step + step kernel)
+        spl = 1 if c4 else int(os.environ.get("SSG_FUSE", "100"))
         n_launch = (K + spl - 1) // spl
         launch_s = ev_ms * 1e-3 / n_launch
         achieved = B * n * (K / n_launch) / launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not c4:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")  # rocprofv3 PMC, same command (profiles/)
             except Exception:
@@ -183,19 +190,24 @@ def main():
             "metric": "env steps/sec (batched ShipEnv)", "value": total_steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 65536 parallel envs per GPU, 1 ship, 8-beam lidar, 64-map "
-                                   "bank (600x600, SPEED 10), random Philox actions, auto-reset in-kernel",
-                       "envs_per_gpu": n, "total_envs": n * world, "n_beams": N_BEAMS, "history": 2,
+            "config": {"workload": ("BASELINE configs[3]: 65536 parallel envs per GPU x 4 ships (3 traffic ships, dynamic "
+                                    "goal bodies, Chipmunk contact solver), 10-beam lidar, 64-map bank, random Philox "
+                                    "actions, auto-reset in-kernel") if c4 else
+                                   ("BASELINE configs[2]: 65536 parallel envs per GPU, 1 ship, 8-beam lidar, 64-map "
+                                    "bank (600x600, SPEED 10), random Philox actions, auto-reset in-kernel"),
+                       "envs_per_gpu": n, "total_envs": n * world, "n_beams": n_beams, "history": 2,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
-                         "kernel": "ssg::step_kernel<8, 256, true, false, false>", "algorithmic_bytes_per_env_step": B,
+                         "kernel": ("ssg::dyn_classify_kernel + ssg::dyn_step_kernel + ssg::step_kernel<10, 256, true, false, true>"
+                                    if c4 else "ssg::step_kernel<8, 256, true, false, false>"),
+                         "algorithmic_bytes_per_env_step": B,
                          "steps_per_launch": K / n_launch, "avg_launch_us": launch_s * 1e6,
                          "us_per_step_in_launch": launch_s * 1e6 * n_launch / K},
             "single_step_launch_us": single_us,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not c4:
             out["cpu_baseline"] = cpu_baseline(vec)
         else:
             out["cpu_baseline"] = None
