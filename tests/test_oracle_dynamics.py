@@ -159,3 +159,90 @@ def test_traffic_off_is_the_old_path():
         if da or db:
             break
         np.testing.assert_array_equal(oa, ob)      # until something touches, traffic changes nothing the player sees
+
+
+def _rand_convex(rng, n, r, cx, cy):
+    ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+    rad = rng.uniform(0.6 * r, r, n)
+    return np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], axis=1)
+
+
+def _seg_dist(p, a, b):
+    d = b - a
+    t = np.clip(np.dot(p - a, d) / np.dot(d, d), 0.0, 1.0)
+    return float(np.linalg.norm(p - (a + t * d)))
+
+
+def _brute_separation(A, B):
+    """Distance between two disjoint convex polygons (vertex-edge minimum), and SAT minimum-translation depth if they
+    overlap: an independent, brute-force statement of what GJK / EPA must return."""
+    def axes(P):
+        e = np.roll(P, -1, axis=0) - P
+        n = np.stack([e[:, 1], -e[:, 0]], axis=1)
+        return n / np.linalg.norm(n, axis=1, keepdims=True)
+    best_overlap = np.inf
+    separated = False
+    for n in np.concatenate([axes(A), axes(B)]):
+        a0, a1 = (A @ n).min(), (A @ n).max()
+        b0, b1 = (B @ n).min(), (B @ n).max()
+        o = min(a1 - b0, b1 - a0)           # translation along n that separates the projections (not their overlap
+        if o < 0:                           #  length: one interval may contain the other)
+            separated = True
+        best_overlap = min(best_overlap, o)
+    if not separated:
+        return -best_overlap
+    d = np.inf
+    for P, Q in ((A, B), (B, A)):
+        for p in P:
+            for i in range(len(Q)):
+                d = min(d, _seg_dist(p, Q[i], Q[(i + 1) % len(Q)]))
+    return d
+
+
+def test_gjk_epa_against_brute_force_geometry():
+    """The restated GJK / EPA (cpCollision.c) on 600 random convex polygon pairs: separation distance, penetration depth
+    (the SAT minimum translation), unit normal pointing from a to b, and contact points that lie on the shapes."""
+    rng = np.random.RandomState(11)
+    n_sep = n_pen = 0
+    for trial in range(600):
+        A = O.convex_hull(_rand_convex(rng, rng.randint(3, 9), rng.uniform(5, 30), 0.0, 0.0))
+        off = rng.uniform(-45, 45, 2)
+        B = O.convex_hull(_rand_convex(rng, rng.randint(3, 9), rng.uniform(5, 30), off[0], off[1]))
+        if len(A) < 3 or len(B) < 3:
+            continue
+        pa, pb = O.make_poly(A), O.make_poly(B)
+        cnt, n, p1, p2, h, d = O.collide_poly_poly(pa, pb)
+        want = _brute_separation(np.asarray(A), np.asarray(B))
+        # (random polygons: the bounding-box reject that precedes cpCollide in the space step is not applied here)
+        assert d == pytest.approx(want, abs=1e-9 * max(1.0, abs(want))), (trial, d, want)
+        if want > 0:
+            n_sep += 1
+            assert cnt == 0
+        else:
+            n_pen += 1
+            assert cnt >= 1 and np.hypot(*n) == pytest.approx(1.0, abs=1e-12)
+            # n points from a towards b: moving b by depth along n separates them
+            moved = O.make_poly(np.asarray(B) + np.asarray(n) * (-want + 1e-6))
+            assert O.collide_poly_poly(pa, moved)[0] == 0
+            for q1, q2 in zip(p1, p2):
+                assert abs(O.point_query(pa, q1)) < 1e-7 and abs(O.point_query(pb, q2)) < 1e-7   # on the boundaries
+                assert np.dot(np.subtract(q2, q1), n) <= 1e-9                                      # penetrating
+    assert n_sep > 100 and n_pen > 100
+
+
+def test_circle_poly_against_point_query():
+    """CircleToPoly's GJK distance is the signed point-query distance of the centre (cpPolyShapePointQuery)."""
+    rng = np.random.RandomState(12)
+    for trial in range(300):
+        P = O.convex_hull(_rand_convex(rng, rng.randint(3, 10), rng.uniform(5, 40), 0.0, 0.0))
+        if len(P) < 3:
+            continue
+        poly = O.make_poly(P)
+        c = rng.uniform(-60, 60, 2)
+        cnt, n, p1, p2, d = O.collide_circle_poly(tuple(c), 5.0, poly)
+        want = O.point_query(poly, tuple(c))
+        assert d == pytest.approx(want, abs=1e-9)
+        assert (cnt == 1) == (want <= 5.0)
+        if cnt:
+            assert abs(O.point_query(poly, p2)) < 1e-7                  # contact point on the polygon's boundary
+            assert np.hypot(p1[0] - c[0], p1[1] - c[1]) == pytest.approx(5.0, abs=1e-9)   # ... and on the circle
