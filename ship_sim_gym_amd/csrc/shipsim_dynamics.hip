@@ -564,16 +564,34 @@ __global__ __launch_bounds__(256) void dyn_classify_kernel(const DevCfg c, const
         bool hit = false;
         if (rest) { // wave-divergent, but the loads below are what the check costs
             unsigned long long hsh = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live);
-            const ShipShape pl = player_shape(c, e, 0);
+            // the player's position after its own cpBodyUpdatePosition; its rotation only if some ship is in reach
+            const double ppx = c.f64cols[(size_t)COL_X * np + e] + c.f64cols[(size_t)COL_VX * np + e] * c.dt;
+            const double ppy = c.f64cols[(size_t)COL_Y * np + e] + c.f64cols[(size_t)COL_VY * np + e] * c.dt;
+            bool reach = false;
+            double tp[SSG_N_TRAFFIC][3];
+#pragma unroll
             for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
                 const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-                ShipShape sk;
-                sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
-                sk.p = mk(t[0 * np], t[1 * np]);
-                const double a = t[2 * np];
-                for (int f = 0; f < 9; ++f) hsh = mixd(hsh, t[(size_t)f * np]);
-                sincos(a, &sk.sa, &sk.ca);
-                hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
+#pragma unroll
+                for (int f = 0; f < 9; ++f) {
+                    const double v = t[(size_t)f * np];
+                    if (f < 3) tp[k][f] = v;
+                    hsh = mixd(hsh, v);
+                }
+                // No vertex of either hull is further than d.reach from its body position: beyond the sum the AABBs
+                // cannot meet, whatever the rotations (a conservative pre-reject of cpBBIntersects' exact one)
+                const double dx = tp[k][0] - ppx, dy = tp[k][1] - ppy;
+                reach |= (dx * dx + dy * dy) <= d.reach2[k];
+            }
+            if (reach) {
+                const ShipShape pl = player_shape(c, e, 0);
+                for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                    ShipShape sk;
+                    sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
+                    sk.p = mk(tp[k][0], tp[k][1]);
+                    sincos(tp[k][2], &sk.sa, &sk.ca);
+                    hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
+                }
             }
             for (int g = 0; g < ng; ++g) {
                 if (!((gmask >> g) & 1u)) continue;
