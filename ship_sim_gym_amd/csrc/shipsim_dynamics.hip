@@ -933,50 +933,148 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             apply_impulse(b, j, r2);
         }
     }
-    for (int it = 0; it < kIter; ++it) {
-        for (int i = 0; i < n_act; ++i) {
-            const ArbRef A = arb(i);
-            int pid, a, b, count, state;
-            ints_of(A, pid, a, b, count, state);
-            const V2 n = mk(A.get(A_NX), A.get(A_NY));
-            const double u = A.get(A_U);
-            const double ma = m_inv_of(a), ia = i_inv_of(a), mb = m_inv_of(b), ib = i_inv_of(b);
-            for (int k = 0; k < count; ++k) {
-                // one batch of LDS reads (the record's contact fields, both bodies' velocity fields), the arithmetic of
-                // cpArbiterApplyImpulse, one batch of writes: a and b are different bodies, so the four apply_*impulse
-                // updates need not re-read what the previous one wrote
-                const V2 r1 = mk(A.cget(k, AC_R1X), A.cget(k, AC_R1Y)), r2 = mk(A.cget(k, AC_R2X), A.cget(k, AC_R2Y));
-                const double nMass = A.cget(k, AC_NMASS), tMass = A.cget(k, AC_TMASS), bias = A.cget(k, AC_BIAS);
-                const double jbnOld = A.cget(k, AC_JBIAS), jnOld = A.cget(k, AC_JN), jtOld = A.cget(k, AC_JT);
-                const V2 a_v = vel(a), b_v = vel(b), a_vb = mk(BF(a, B_VBX), BF(a, B_VBY)), b_vb = mk(BF(b, B_VBX), BF(b, B_VBY));
-                const double a_w = BF(a, B_W), b_w = BF(b, B_W), a_wb = BF(a, B_WB), b_wb = BF(b, B_WB);
-                const V2 vb1 = a_vb + perp(r1) * a_wb;
-                const V2 vb2 = b_vb + perp(r2) * b_wb;
-                const V2 v1 = a_v + perp(r1) * a_w;
-                const V2 v2 = b_v + perp(r2) * b_w;
-                const V2 vr = (v2 - v1) + mk(0, 0);
-                const double vbn = dot(vb2 - vb1, n);
-                const double vrn = dot(vr, n);
-                const double vrt = dot(vr, perp(n));
-                const double jbn = (bias - vbn) * nMass;
-                const double jBias = cmax(jbnOld + jbn, 0.0);
-                const double jn = -(0.0 + vrn) * nMass;
-                const double jnAcc = cmax(jnOld + jn, 0.0);
-                const double jtMax = u * jnAcc;
-                const double jt = -vrt * tMass;
-                const double jtAcc = cclamp(jtOld + jt, -jtMax, jtMax);
-                A.cset(k, AC_JBIAS, jBias); A.cset(k, AC_JN, jnAcc); A.cset(k, AC_JT, jtAcc);
-                const V2 jb = n * (jBias - jbnOld);
-                const V2 j = rotate(n, mk(jnAcc - jnOld, jtAcc - jtOld));
-                const V2 njb = neg(jb), nj = neg(j);
-                const V2 a_vb2 = a_vb + njb * ma, b_vb2 = b_vb + jb * mb; // apply_bias_impulses
-                const double a_wb2 = a_wb + ia * cross(r1, njb), b_wb2 = b_wb + ib * cross(r2, jb);
-                const V2 a_v2 = a_v + nj * ma, b_v2 = b_v + j * mb;       // apply_impulses
-                const double a_w2 = a_w + ia * cross(r1, nj), b_w2 = b_w + ib * cross(r2, j);
-                BF(a, B_VBX) = a_vb2.x; BF(a, B_VBY) = a_vb2.y; BF(a, B_WB) = a_wb2;
-                BF(a, B_VX) = a_v2.x; BF(a, B_VY) = a_v2.y; BF(a, B_W) = a_w2;
-                BF(b, B_VBX) = b_vb2.x; BF(b, B_VBY) = b_vb2.y; BF(b, B_WB) = b_wb2;
-                BF(b, B_VX) = b_v2.x; BF(b, B_VY) = b_v2.y; BF(b, B_W) = b_w2;
+    // cpSpaceStep's 10 solver iterations.  Almost every env has one or two arbiters on its list: those run entirely in
+    // registers (the records' constants, the accumulated impulses and both bodies' velocity fields are loaded once, the
+    // two arbiters hand a shared body's fields to each other after each update, everything is written back once); an
+    // iteration is then ~60 dependent FP64 operations instead of that plus ~40 LDS round trips with computed addresses.
+    // Longer lists take the generic LDS-resident loop below.
+    struct RegArb {
+        int a, b, count;
+        V2 n;
+        double u, ma, ia, mb, ib;
+        V2 r1[2], r2[2];
+        double nM[2], tM[2], bias[2], jB[2], jn[2], jt[2];
+        V2 av, avb, bv, bvb;
+        double aw, awb, bw, bwb;
+    };
+    auto reg_load = [&](RegArb &R, int i) {
+        const ArbRef A = arb(i);
+        int pid, state;
+        ints_of(A, pid, R.a, R.b, R.count, state);
+        R.n = mk(A.get(A_NX), A.get(A_NY));
+        R.u = A.get(A_U);
+        R.ma = m_inv_of(R.a); R.ia = i_inv_of(R.a); R.mb = m_inv_of(R.b); R.ib = i_inv_of(R.b);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            R.r1[k] = mk(A.cget(k, AC_R1X), A.cget(k, AC_R1Y)); R.r2[k] = mk(A.cget(k, AC_R2X), A.cget(k, AC_R2Y));
+            R.nM[k] = A.cget(k, AC_NMASS); R.tM[k] = A.cget(k, AC_TMASS); R.bias[k] = A.cget(k, AC_BIAS);
+            R.jB[k] = A.cget(k, AC_JBIAS); R.jn[k] = A.cget(k, AC_JN); R.jt[k] = A.cget(k, AC_JT);
+        }
+        R.av = vel(R.a); R.avb = mk(BF(R.a, B_VBX), BF(R.a, B_VBY)); R.aw = BF(R.a, B_W); R.awb = BF(R.a, B_WB);
+        R.bv = vel(R.b); R.bvb = mk(BF(R.b, B_VBX), BF(R.b, B_VBY)); R.bw = BF(R.b, B_W); R.bwb = BF(R.b, B_WB);
+    };
+    auto reg_step = [&](RegArb &R) { // cpArbiterApplyImpulse
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= R.count) break;
+            const V2 r1 = R.r1[k], r2 = R.r2[k], n = R.n;
+            const V2 vb1 = R.avb + perp(r1) * R.awb;
+            const V2 vb2 = R.bvb + perp(r2) * R.bwb;
+            const V2 v1 = R.av + perp(r1) * R.aw;
+            const V2 v2 = R.bv + perp(r2) * R.bw;
+            const V2 vr = (v2 - v1) + mk(0, 0);
+            const double vbn = dot(vb2 - vb1, n);
+            const double vrn = dot(vr, n);
+            const double vrt = dot(vr, perp(n));
+            const double jbn = (R.bias[k] - vbn) * R.nM[k];
+            const double jbnOld = R.jB[k];
+            const double jBias = cmax(jbnOld + jbn, 0.0);
+            const double jn = -(0.0 + vrn) * R.nM[k];
+            const double jnOld = R.jn[k];
+            const double jnAcc = cmax(jnOld + jn, 0.0);
+            const double jtMax = R.u * jnAcc;
+            const double jt = -vrt * R.tM[k];
+            const double jtOld = R.jt[k];
+            const double jtAcc = cclamp(jtOld + jt, -jtMax, jtMax);
+            R.jB[k] = jBias; R.jn[k] = jnAcc; R.jt[k] = jtAcc;
+            const V2 jb = n * (jBias - jbnOld);
+            const V2 j = rotate(n, mk(jnAcc - jnOld, jtAcc - jtOld));
+            const V2 njb = neg(jb), nj = neg(j);
+            R.avb = R.avb + njb * R.ma; R.bvb = R.bvb + jb * R.mb;         // apply_bias_impulses
+            R.awb = R.awb + R.ia * cross(r1, njb); R.bwb = R.bwb + R.ib * cross(r2, jb);
+            R.av = R.av + nj * R.ma; R.bv = R.bv + j * R.mb;               // apply_impulses
+            R.aw = R.aw + R.ia * cross(r1, nj); R.bw = R.bw + R.ib * cross(r2, j);
+        }
+    };
+    auto reg_sync = [&](const RegArb &F, RegArb &T) { // T's copy of a body F has just updated
+        if (T.a == F.a) { T.av = F.av; T.avb = F.avb; T.aw = F.aw; T.awb = F.awb; }
+        if (T.a == F.b) { T.av = F.bv; T.avb = F.bvb; T.aw = F.bw; T.awb = F.bwb; }
+        if (T.b == F.a) { T.bv = F.av; T.bvb = F.avb; T.bw = F.aw; T.bwb = F.awb; }
+        if (T.b == F.b) { T.bv = F.bv; T.bvb = F.bvb; T.bw = F.bw; T.bwb = F.bwb; }
+    };
+    auto reg_store = [&](const RegArb &R, int i) {
+        const ArbRef A = arb(i);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= R.count) break;
+            A.cset(k, AC_JBIAS, R.jB[k]); A.cset(k, AC_JN, R.jn[k]); A.cset(k, AC_JT, R.jt[k]);
+        }
+        BF(R.a, B_VX) = R.av.x; BF(R.a, B_VY) = R.av.y; BF(R.a, B_W) = R.aw;
+        BF(R.a, B_VBX) = R.avb.x; BF(R.a, B_VBY) = R.avb.y; BF(R.a, B_WB) = R.awb;
+        BF(R.b, B_VX) = R.bv.x; BF(R.b, B_VY) = R.bv.y; BF(R.b, B_W) = R.bw;
+        BF(R.b, B_VBX) = R.bvb.x; BF(R.b, B_VBY) = R.bvb.y; BF(R.b, B_WB) = R.bwb;
+    };
+    if (n_act >= 1 && n_act <= 2) {
+        RegArb R0, R1;
+        reg_load(R0, 0);
+        reg_load(R1, n_act > 1 ? 1 : 0);
+        const bool two = n_act > 1;
+        for (int it = 0; it < kIter; ++it) {
+            reg_step(R0);
+            if (two) {
+                reg_sync(R0, R1);
+                reg_step(R1);
+                reg_sync(R1, R0);
+            }
+        }
+        reg_store(R0, 0);
+        if (two) reg_store(R1, 1); // (a body the two arbiters share holds the same, latest fields in both after the last sync)
+    } else {
+        for (int it = 0; it < kIter; ++it) {
+            for (int i = 0; i < n_act; ++i) {
+                const ArbRef A = arb(i);
+                int pid, a, b, count, state;
+                ints_of(A, pid, a, b, count, state);
+                const V2 n = mk(A.get(A_NX), A.get(A_NY));
+                const double u = A.get(A_U);
+                const double ma = m_inv_of(a), ia = i_inv_of(a), mb = m_inv_of(b), ib = i_inv_of(b);
+                for (int k = 0; k < count; ++k) {
+                    // one batch of LDS reads (the record's contact fields, both bodies' velocity fields), the arithmetic of
+                    // cpArbiterApplyImpulse, one batch of writes: a and b are different bodies, so the four apply_*impulse
+                    // updates need not re-read what the previous one wrote
+                    const V2 r1 = mk(A.cget(k, AC_R1X), A.cget(k, AC_R1Y)), r2 = mk(A.cget(k, AC_R2X), A.cget(k, AC_R2Y));
+                    const double nMass = A.cget(k, AC_NMASS), tMass = A.cget(k, AC_TMASS), bias = A.cget(k, AC_BIAS);
+                    const double jbnOld = A.cget(k, AC_JBIAS), jnOld = A.cget(k, AC_JN), jtOld = A.cget(k, AC_JT);
+                    const V2 a_v = vel(a), b_v = vel(b), a_vb = mk(BF(a, B_VBX), BF(a, B_VBY)), b_vb = mk(BF(b, B_VBX), BF(b, B_VBY));
+                    const double a_w = BF(a, B_W), b_w = BF(b, B_W), a_wb = BF(a, B_WB), b_wb = BF(b, B_WB);
+                    const V2 vb1 = a_vb + perp(r1) * a_wb;
+                    const V2 vb2 = b_vb + perp(r2) * b_wb;
+                    const V2 v1 = a_v + perp(r1) * a_w;
+                    const V2 v2 = b_v + perp(r2) * b_w;
+                    const V2 vr = (v2 - v1) + mk(0, 0);
+                    const double vbn = dot(vb2 - vb1, n);
+                    const double vrn = dot(vr, n);
+                    const double vrt = dot(vr, perp(n));
+                    const double jbn = (bias - vbn) * nMass;
+                    const double jBias = cmax(jbnOld + jbn, 0.0);
+                    const double jn = -(0.0 + vrn) * nMass;
+                    const double jnAcc = cmax(jnOld + jn, 0.0);
+                    const double jtMax = u * jnAcc;
+                    const double jt = -vrt * tMass;
+                    const double jtAcc = cclamp(jtOld + jt, -jtMax, jtMax);
+                    A.cset(k, AC_JBIAS, jBias); A.cset(k, AC_JN, jnAcc); A.cset(k, AC_JT, jtAcc);
+                    const V2 jb = n * (jBias - jbnOld);
+                    const V2 j = rotate(n, mk(jnAcc - jnOld, jtAcc - jtOld));
+                    const V2 njb = neg(jb), nj = neg(j);
+                    const V2 a_vb2 = a_vb + njb * ma, b_vb2 = b_vb + jb * mb; // apply_bias_impulses
+                    const double a_wb2 = a_wb + ia * cross(r1, njb), b_wb2 = b_wb + ib * cross(r2, jb);
+                    const V2 a_v2 = a_v + nj * ma, b_v2 = b_v + j * mb;       // apply_impulses
+                    const double a_w2 = a_w + ia * cross(r1, nj), b_w2 = b_w + ib * cross(r2, j);
+                    BF(a, B_VBX) = a_vb2.x; BF(a, B_VBY) = a_vb2.y; BF(a, B_WB) = a_wb2;
+                    BF(a, B_VX) = a_v2.x; BF(a, B_VY) = a_v2.y; BF(a, B_W) = a_w2;
+                    BF(b, B_VBX) = b_vb2.x; BF(b, B_VBY) = b_vb2.y; BF(b, B_WB) = b_wb2;
+                    BF(b, B_VX) = b_v2.x; BF(b, B_VY) = b_v2.y; BF(b, B_W) = b_w2;
+                }
             }
         }
     }
