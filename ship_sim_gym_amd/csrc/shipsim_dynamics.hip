@@ -13,7 +13,7 @@
 // sequential chain (Gauss-Seidel over at most a handful of contacts), so the kernel is bound by the latency of that
 // chain, not by HBM: what matters is that nothing on the chain goes to memory.
 //  * Body state and the solver's arbiter records live in LDS, one column per field, lane-contiguous
-//    (`lds[field*64 + lane]`): a lane's dynamic slot index changes the field, never the LDS bank, so the per-lane
+//    (`lds[field*kGrp + lane]`, kGrp = 64): a lane's dynamic slot index changes the field, never the LDS bank, so the per-lane
 //    gathers of the solver are conflict-free.  (A first version kept them in per-lane arrays: 8.7 KB of scratch per
 //    lane, 1 GB of HBM traffic per step, 420 us.)
 //  * Shapes are never materialised: a ship's world vertices are its pose applied on the fly to the hull constants
@@ -39,6 +39,13 @@ namespace {
 
 extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-uniform hull constants
 
+// Envs per workgroup of the full step (lanes kGrp..63 of its one wave would idle).  Measured at 65 536 envs: 64 ->
+// 146 us per step, 32 -> 149, 16 -> 155, 8 -> 314: a queued env costs ~5 k FP64 VALU instructions per narrowphase
+// query whatever its neighbours do, so smaller groups only add workgroups.  Kept as a build-time knob.
+#ifndef SSG_DYN_GRP
+#define SSG_DYN_GRP 64
+#endif
+constexpr int kGrp = SSG_DYN_GRP;
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
 constexpr int kMaxGjk = 30, kMaxEpa = 30;
@@ -162,8 +169,8 @@ struct BankShape {
     BB box;
     unsigned hashid;
     static constexpr bool is_circle = false;
-    __device__ __forceinline__ V2 vert(int i) const { return mk(lds[base + (4 * i) * 64], lds[base + (4 * i + 1) * 64]); }
-    __device__ __forceinline__ V2 normal(int i) const { return mk(lds[base + (4 * i + 2) * 64], lds[base + (4 * i + 3) * 64]); }
+    __device__ __forceinline__ V2 vert(int i) const { return mk(lds[base + (4 * i) * kGrp], lds[base + (4 * i + 1) * kGrp]); }
+    __device__ __forceinline__ V2 normal(int i) const { return mk(lds[base + (4 * i + 2) * kGrp], lds[base + (4 * i + 3) * kGrp]); }
     __device__ __forceinline__ BB bb() const { return box; }
     __device__ __forceinline__ Sup support(V2 nn) const
     {
@@ -252,12 +259,13 @@ constexpr int kEpaDoubles = 2 * kEpaLds * 4;
 struct EpaMem {
     int base; // index in lds[] of this lane's buffer 0 entry 0 field 0 (field stride 64)
     Mink *ov; // [2][kMaxEpa + 4 - kEpaLds]
+    int *cnt; // development counters: [0] gjk iterations [1] epa iterations [2] queries
     __device__ __forceinline__ Mink get(int buf, int i) const
     {
         if (i < kEpaLds) {
-            const int o = base + ((buf * kEpaLds + i) * 4) * 64;
+            const int o = base + ((buf * kEpaLds + i) * 4) * kGrp;
             Mink m;
-            m.a = mk(lds[o], lds[o + 64]); m.b = mk(lds[o + 128], lds[o + 192]);
+            m.a = mk(lds[o], lds[o + kGrp]); m.b = mk(lds[o + 2 * kGrp], lds[o + 3 * kGrp]);
             m.ab = m.b - m.a;
             return m;
         }
@@ -266,8 +274,8 @@ struct EpaMem {
     __device__ __forceinline__ void set(int buf, int i, const Mink &m) const
     {
         if (i < kEpaLds) {
-            const int o = base + ((buf * kEpaLds + i) * 4) * 64;
-            lds[o] = m.a.x; lds[o + 64] = m.a.y; lds[o + 128] = m.b.x; lds[o + 192] = m.b.y;
+            const int o = base + ((buf * kEpaLds + i) * 4) * kGrp;
+            lds[o] = m.a.x; lds[o + kGrp] = m.a.y; lds[o + 2 * kGrp] = m.b.x; lds[o + 3 * kGrp] = m.b.y;
         } else {
             ov[buf * (kMaxEpa + 4 - kEpaLds) + i - kEpaLds] = m;
         }
@@ -281,6 +289,7 @@ __device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v
     int count = 3;
     mem.set(0, 0, v0); mem.set(0, 1, v1); mem.set(0, 2, v2);
     for (int iteration = 1;; ++iteration) {
+        mem.cnt[1]++;
         int mini = 0;
         double min_dist = INFINITY;
         {
@@ -321,7 +330,9 @@ __device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2, const EpaMem 
     Mink v0 = support(s1, s2, axis);
     Mink v1 = support(s1, s2, neg(axis));
     int iteration = 1;
+    mem.cnt[2]++;
     for (;;) {
+        mem.cnt[0]++;
         if (iteration > kMaxGjk) return closest_new(v0, v1);
         const V2 delta = v1.ab - v0.ab;
         if (cross(delta, v0.ab + v1.ab) > 0.0) {
@@ -462,8 +473,8 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
 struct ArbRef {
     int base;   // index of field 0 in lds[] for this lane, or -1
     double *ov; // scratch record otherwise
-    __device__ __forceinline__ double get(int f) const { return base >= 0 ? lds[base + f * 64] : ov[f]; }
-    __device__ __forceinline__ void set(int f, double v) const { if (base >= 0) lds[base + f * 64] = v; else ov[f] = v; }
+    __device__ __forceinline__ double get(int f) const { return base >= 0 ? lds[base + f * kGrp] : ov[f]; }
+    __device__ __forceinline__ void set(int f, double v) const { if (base >= 0) lds[base + f * kGrp] = v; else ov[f] = v; }
     __device__ __forceinline__ double cget(int k, int f) const { return get(A_CON0 + k * AC_STRIDE + f); }
     __device__ __forceinline__ void cset(int k, int f, double v) const { set(A_CON0 + k * AC_STRIDE + f, v); }
 };
@@ -624,12 +635,12 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 {
     const int lane = threadIdx.x;
     const unsigned n_queued = *c.dyn_count;
-    if ((unsigned)blockIdx.x * 64u >= n_queued) return; // wave-uniform: nothing queued for this workgroup
-    const bool queued = (unsigned)blockIdx.x * 64u + (unsigned)lane < n_queued;
-    const int e = queued ? c.dyn_queue[blockIdx.x * 64 + lane] : 0;
+    if ((unsigned)blockIdx.x * (unsigned)kGrp >= n_queued) return; // wave-uniform: nothing queued for this workgroup
+    const bool queued = (lane < kGrp) & ((unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane < n_queued);
+    const int e = queued ? c.dyn_queue[blockIdx.x * kGrp + lane] : 0;
     const int lane_doubles = B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
                              kBankDoubles + kEpaDoubles;
-    const int cbase = 64 * lane_doubles;
+    const int cbase = kGrp * lane_doubles;
     stage_hulls(c, d, cbase, lane);
     __builtin_amdgcn_s_waitcnt(0xC07F); // one wave per workgroup: the LDS writes above are visible to its lanes
     __builtin_amdgcn_wave_barrier();
@@ -661,8 +672,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // ---- LDS columns of this lane ---------------------------------------------------------------------------
     const int slot_ship0 = ng, slot_static = ng + SSG_N_TRAFFIC;
     const int xbase = B_STRIDE * (slot_static + 1), abase = xbase + X_STRIDE * SSG_N_TRAFFIC;
-    auto L = [&](int f) -> double & { return lds[f * 64 + lane]; };
-    auto BF = [&](int slot, int f) -> double & { return lds[(B_STRIDE * slot + f) * 64 + lane]; };
+    auto L = [&](int f) -> double & { return lds[f * kGrp + lane]; };
+    auto BF = [&](int slot, int f) -> double & { return lds[(B_STRIDE * slot + f) * kGrp + lane]; };
     for (int f = 0; f < B_STRIDE; ++f) BF(slot_static, f) = 0.0; // cpBodyNewStatic at the origin
     auto m_inv_of = [&](int slot) -> double { return slot < slot_ship0 ? d.goal_m_inv : (slot < slot_static ? d.t_m_inv : 0.0); };
     auto i_inv_of = [&](int slot) -> double {
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
         for (int f = 0; f < 4; ++f) bk[s][1 + f] = rec[SSG_MAP_OFF_AABB + 4 * s + f];
     }
-    const int bbase = (abase + A_STRIDE * kLdsArb) * 64 + lane, ebase = bbase + kBankDoubles * 64;
+    const int bbase = (abase + A_STRIDE * kLdsArb) * kGrp + lane, ebase = bbase + kBankDoubles * kGrp;
     int staged = -1;
     auto bank_box = [&](int s) -> BB {
         BB o;
@@ -734,7 +745,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
                 for (int f = 0; f < 4; ++f) tmp[4 * j + f] = pl[SSG_PLANE_DOUBLES * j + f]; // all 12 slots exist in the record
 #pragma unroll
-            for (int q = 0; q < kBankDoubles; ++q) lds[bbase + q * 64] = tmp[q];
+            for (int q = 0; q < kBankDoubles; ++q) lds[bbase + q * kGrp] = tmp[q];
             staged = s;
         }
         BankShape b;
@@ -746,7 +757,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     };
     Mink epa_ov[2 * (kMaxEpa + 4 - kEpaLds)];
     EpaMem emem;
-    emem.base = ebase; emem.ov = epa_ov;
+    int dbg_cnt[3] = {0, 0, 0};
+    emem.base = ebase; emem.ov = epa_ov; emem.cnt = dbg_cnt;
     auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
 
     stamp(0);
@@ -764,7 +776,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     double ovf[(kMaxActive - kLdsArb) * A_STRIDE]; // records beyond the LDS ones: scratch, touched only when used
     auto arb = [&](int i) -> ArbRef {
         ArbRef r;
-        r.base = (i < kLdsArb) ? (abase + A_STRIDE * i) * 64 + lane : -1;
+        r.base = (i < kLdsArb) ? (abase + A_STRIDE * i) * kGrp + lane : -1;
         r.ov = &ovf[(i < kLdsArb ? 0 : i - kLdsArb) * A_STRIDE];
         return r;
     };
@@ -1121,7 +1133,12 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     }
     changed |= (hin != hsh) | (ain != aout);
     stamp(5);
-    if (d.stop_after == -1) col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + e] = (double)n_act;
+    if (d.stop_after == -1) {
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + e] = (double)n_act;
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 7) * np + e] = (double)dbg_cnt[0];
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 8) * np + e] = (double)dbg_cnt[1];
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 9) * np + e] = (double)dbg_cnt[2];
+    }
     col.live[e] = live;
     c.dyn_hash[e] = hsh;
     col.flag[e] = (uint8_t)((hit ? 1u : 0u) | (changed ? 0u : 4u)); // unchanged = a fixed point of cpSpaceStep: at rest
@@ -1131,7 +1148,7 @@ size_t dyn_lds_bytes(int n_goals)
 {
     const int doubles = B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
                         kBankDoubles + kEpaDoubles;
-    return ((size_t)doubles * 64 + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
+    return ((size_t)doubles * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
 }
 
 // Raise the dynamic-LDS cap of the full-step kernel to the CU's whole 160 KiB (once per handle, like prepare_step).
@@ -1151,7 +1168,7 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
     static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
     dd.stop_after = stop_after;
-    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + 63) / 64)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
+    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + kGrp - 1) / kGrp)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
     return hipGetLastError();
 }
 

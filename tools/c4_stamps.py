@@ -16,7 +16,7 @@ N.check(N.lib().ssg_state_field(vec._h, N.F_TRAFFIC, C.byref(off), C.byref(es), 
 npad = stride.value // 8
 DC_ARB = 27 + 8 * 6
 cols = vec.state[off.value: off.value + (DC_ARB + 4 * 54 + 2) * npad * 8].view(torch.float64).view(-1, npad)
-st = cols[DC_ARB + 200: DC_ARB + 207, :n].cpu().numpy()
+st = cols[DC_ARB + 200: DC_ARB + 210, :n].cpu().numpy()
 fl = vec.field(N.F_DYN_FLAGS).cpu().numpy()
 sel = st[5] > 0
 print("envs with stamps", sel.sum(), "of", n)
@@ -27,3 +27,8 @@ for i, nm in enumerate(names):
     print("%-12s median %8.0f  p90 %8.0f  max %8.0f cycles" % (nm, np.median(cur - prev), np.percentile(cur - prev, 90), (cur - prev).max()))
     prev = cur
 print("total median %8.0f max %8.0f ; n_act hist" % (np.median(st[5][sel]), st[5][sel].max()), np.bincount(st[6][sel].astype(int)))
+print("per env: gjk iterations mean %.2f max %d | epa iterations mean %.2f max %d | narrowphase queries mean %.2f max %d" % (
+    st[7][sel].mean(), st[7][sel].max(), st[8][sel].mean(), st[8][sel].max(), st[9][sel].mean(), st[9][sel].max()))
+w = st[7:10, :n].reshape(3, -1, 64)
+print("per wave (sum over the sites a wave enters is what it pays): max-lane gjk it %.1f, epa it %.1f, queries %.1f" % (
+    w[0].max(axis=1).mean(), w[1].max(axis=1).mean(), w[2].max(axis=1).mean()))
