@@ -218,3 +218,19 @@ def test_config4_curriculum_maps():
             moved3 |= bool((_dyn_state(N, vec)[0][:, 0, 0] > 170.0).any())
     assert moved3                                                 # ship 1 is pushed out of a left bank wider than lesson 0's 150
     vec.close()
+
+
+@pytest.mark.parametrize("hist", [1, 3])
+def test_config4_history_sizes(hist):
+    """Config 4 with EnvConfig.HISTORY_SIZE other than 2 (per-step launches + the frame-shift kernel for H > 2)."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import run_pair
+    from ship_sim_gym_amd.config import EnvConfig
+
+    class E(EnvConfig):
+        HISTORY_SIZE = hist
+    vec = ShipVecEnv(300, env_config=E, n_maps=8, n_ships=4)
+    assert vec.observation_space.shape == (16 * hist,)
+    err, n_done = run_pair(O, N, vec, K=80)
+    assert err <= 1e-9 and n_done > 30
+    vec.close()
