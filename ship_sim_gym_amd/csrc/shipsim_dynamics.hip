@@ -106,12 +106,17 @@ struct ShipShape {
     V2 p;
     double ca, sa;
     unsigned hashid;
+    V2 wv[SSG_SHIP_VERTS]; // world vertices, computed once per shape (cache()): GJK / EPA ask for them a dozen times
     static constexpr bool is_circle = false;
-    __device__ __forceinline__ V2 vert(int i) const
+    __device__ __forceinline__ void cache()
     {
-        const double hx = lds[hoff + 2 * i], hy = lds[hoff + 2 * i + 1];
-        return mk(ca * hx + (-sa) * hy + p.x, sa * hx + ca * hy + p.y);
+#pragma unroll
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+            const double hx = lds[hoff + 2 * i], hy = lds[hoff + 2 * i + 1];
+            wv[i] = mk(ca * hx + (-sa) * hy + p.x, sa * hx + ca * hy + p.y);
+        }
     }
+    __device__ __forceinline__ V2 vert(int i) const { return wv[i]; } // i is a compile-time constant at every use
     __device__ __forceinline__ V2 normal(int i) const
     {
         const double nx = lds[hoff + 2 * SSG_SHIP_VERTS + 2 * i], ny = lds[hoff + 2 * SSG_SHIP_VERTS + 2 * i + 1];
@@ -530,6 +535,7 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
     pl.hoff = hoff; pl.hashid = 0;
     pl.p = mk(x + vx * c.dt, y + vy * c.dt);
     sincos(ang + w * c.dt, &pl.sa, &pl.ca);
+    pl.cache();
     return pl;
 }
 
@@ -601,6 +607,7 @@ __global__ __launch_bounds__(256) void dyn_classify_kernel(const DevCfg c, const
                     sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
                     sk.p = mk(tp[k][0], tp[k][1]);
                     sincos(tp[k][2], &sk.sa, &sk.ca);
+                    sk.cache();
                     hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
                 }
             }
@@ -719,6 +726,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         s.p = mk(BF(slot_ship0 + k, B_PX), BF(slot_ship0 + k, B_PY));
         s.ca = L(xbase + X_STRIDE * k + X_CA); s.sa = L(xbase + X_STRIDE * k + X_SA);
         s.hashid = (unsigned)(2 + SSG_MAX_GOALS + k);
+        s.cache();
         return s;
     };
     // both banks' vertex counts and AABBs up front (one round trip); planes are staged on demand
