@@ -181,10 +181,16 @@ struct BankShape {
     {
         double mx = -INFINITY;
         Sup s; s.p = mk(0, 0); s.i = 0;
-        for (int i = 0; i < n; ++i) {
-            const V2 v = vert(i);
-            const double d = dot(v, nn);
-            if (d > mx) { mx = d; s.p = v; s.i = i; }
+        // all 12 staged slots are fetched at once (one LDS round trip instead of one per vertex); the comparisons run
+        // in vertex order over the first n, exactly as PolySupportPointIndex does
+        V2 v[SSG_MAX_HULL];
+#pragma unroll
+        for (int i = 0; i < SSG_MAX_HULL; ++i) v[i] = vert(i);
+#pragma unroll
+        for (int i = 0; i < SSG_MAX_HULL; ++i) {
+            const double d = dot(v[i], nn);
+            const bool take = (i < n) & (d > mx);
+            mx = take ? d : mx; s.p.x = take ? v[i].x : s.p.x; s.p.y = take ? v[i].y : s.p.y; s.i = take ? i : s.i;
         }
         return s;
     }
