@@ -215,6 +215,12 @@ int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_
 int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *dev_bank, int n_maps, double *dev_raw,
                       void *stream);
 
+/* Config 4 only.  The traffic ships and goal bodies of an env whose space has reached a fixed point of cpSpaceStep are
+ * not stepped again until something changes (SSG_F_DYN_FLAGS bit 2).  The library sees resets, goal removals and bank
+ * changes itself; a caller that WRITES the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns (tests, scenario set-up) tells it
+ * with this call.  dev_mask: u8[n_envs], non-zero = invalidate; NULL = all envs. */
+int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
+
 /* Replaces: ShipGame.render + ShipGame.get_screen (game.py:133-138,197-229) for ONE env: an RGB frame of `width` x
  * `height` pixels covering the env's bounds, laid out like pygame.surfarray.array3d ([x][y][3], screen y down).
  * flags bit 0 = GameConfig.DEBUG drawing (shapes in their colours + one circle per lidar beam end); the yellow

@@ -664,6 +664,16 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
     return SSG_OK;
 }
 
+int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream)
+{
+    int rc = check_ready(h, false);
+    if (rc != SSG_OK) return rc;
+    if (h->cfg.n_ships <= 1) return SSG_OK; // nothing to wake
+    hipError_t e = ssg::launch_dyn_invalidate(h->dev, dev_mask, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn_invalidate launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
 int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream)
 {
     int rc = check_ready(h, true);

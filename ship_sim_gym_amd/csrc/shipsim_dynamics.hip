@@ -470,10 +470,17 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
         t[0 * col.np] = d.tx[k]; t[1 * col.np] = d.ty[k];
         for (int f = 2; f < 9; ++f) t[(size_t)f * col.np] = 0.0;
     }
-    for (int g = 0; g < c.n_goals; ++g) {
+    // all goal centres first, then the stores: a load issued after a store it might alias waits for nothing, but the
+    // compiler keeps program order, and one L2 round trip per goal coordinate made this the slowest part of pass 1
+    double gxy[2 * SSG_MAX_GOALS];
+#pragma unroll
+    for (int i = 0; i < 2 * SSG_MAX_GOALS; ++i) gxy[i] = rec[SSG_MAP_OFF_GOALS + i];
+#pragma unroll
+    for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+        if (g >= c.n_goals) break;
         double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * col.np + e;
-        q[0 * col.np] = rec[SSG_MAP_OFF_GOALS + 2 * g];
-        q[1 * col.np] = rec[SSG_MAP_OFF_GOALS + 2 * g + 1];
+        q[0 * col.np] = gxy[2 * g];
+        q[1 * col.np] = gxy[2 * g + 1];
         for (int f = 2; f < DC_GOAL_COLS; ++f) q[(size_t)f * col.np] = 0.0;
     }
     col.live[e] = 0ull;
@@ -506,9 +513,7 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
     col.flag[e] = 0;
 }
 
-// Hash of everything a resting env's next step depends on besides its arbiter columns: the cpBody fields of the ships
-// and goals, which goals are in the space, which pairs have cached arbiters, the map and the bank generation.
-// Guards the rest bit against callers that write the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns or swap the bank.
+// 64-bit mixing for the "did this step change anything" test of the full step (inputs vs outputs, no re-reads).
 __device__ __forceinline__ unsigned long long mix(unsigned long long h, unsigned long long v)
 {
     h = (h ^ v) * 0x9E3779B97F4A7C15ull;
@@ -551,15 +556,19 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
 // bits it had read -- every body field, every arbiter's state / age / contact hashes / accumulated impulses, the live
 // mask -- the space is at a fixed point: the next step is the identity.  (That is how a ship resting against a bank
 // ends up: the penetration left beyond the slop shrinks by 99.8 % per step until position + bias*dt rounds to the
-// position.)  The full step records that as the rest bit plus a hash of the body fields; as long as both still
-// hold, these bodies are skipped and only the player's collide_ship test against the parked traffic is left.
+// position.)  The full step records that as the rest bit (with the bank generation it holds for); while it stands,
+// these bodies are skipped and only the player's collide_ship test against the parked traffic is left.  A caller
+// that writes the body columns itself must clear the bit with ssg_dyn_invalidate.
 // Everything else is appended to the queue of pass 2.  In steady state that is the few steps after each reset in
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dyn_classify_kernel(const DevCfg c, const DynCfg d)
+constexpr int kClassifyThreads = 1024;
+__global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const DevCfg c, const DynCfg d)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned wg_cnt, wg_base;
+    const int e = blockIdx.x * kClassifyThreads + threadIdx.x;
     stage_hulls(c, d, 0, threadIdx.x);
+    if (threadIdx.x == 0) wg_cnt = 0u;
     __syncthreads();
     const bool valid = e < c.n_envs;
     bool need_full = false;
@@ -583,26 +592,22 @@ __global__ __launch_bounds__(256) void dyn_classify_kernel(const DevCfg c, const
                 if (h != g) live &= ~(1ull << (h < g ? pid_gg(h, g) : pid_gg(g, h)));
         }
         if (live != live0) col.live[e] = live;
-        bool rest = ((flag & 6u) == 4u);
+        // rest bit still valid?  It was established for this bank generation; callers that write the body columns
+        // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).
+        bool rest = ((flag & 6u) == 4u) && (c.dyn_hash[e] == (unsigned long long)d.bank_epoch);
         bool hit = false;
-        if (rest) { // wave-divergent, but the loads below are what the check costs
-            unsigned long long hsh = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live);
+        if (rest) {
             // the player's position after its own cpBodyUpdatePosition; its rotation only if some ship is in reach
             const double ppx = c.f64cols[(size_t)COL_X * np + e] + c.f64cols[(size_t)COL_VX * np + e] * c.dt;
             const double ppy = c.f64cols[(size_t)COL_Y * np + e] + c.f64cols[(size_t)COL_VY * np + e] * c.dt;
             bool reach = false;
-            double tp[SSG_N_TRAFFIC][3];
+            double tp[SSG_N_TRAFFIC][2];
 #pragma unroll
             for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
                 const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-#pragma unroll
-                for (int f = 0; f < 9; ++f) {
-                    const double v = t[(size_t)f * np];
-                    if (f < 3) tp[k][f] = v;
-                    hsh = mixd(hsh, v);
-                }
-                // No vertex of either hull is further than d.reach from its body position: beyond the sum the AABBs
-                // cannot meet, whatever the rotations (a conservative pre-reject of cpBBIntersects' exact one)
+                tp[k][0] = t[0]; tp[k][1] = t[np];
+                // No vertex of either hull is further than its hull radius from its body position: beyond the sum the
+                // AABBs cannot meet, whatever the rotations (a conservative pre-reject of cpBBIntersects' exact one)
                 const double dx = tp[k][0] - ppx, dy = tp[k][1] - ppy;
                 reach |= (dx * dx + dy * dy) <= d.reach2[k];
             }
@@ -612,33 +617,26 @@ __global__ __launch_bounds__(256) void dyn_classify_kernel(const DevCfg c, const
                     ShipShape sk;
                     sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
                     sk.p = mk(tp[k][0], tp[k][1]);
-                    sincos(tp[k][2], &sk.sa, &sk.ca);
+                    sincos(col.f64[(size_t)(DC_TRAFFIC + 9 * k + 2) * np + e], &sk.sa, &sk.ca);
                     sk.cache();
                     hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
                 }
             }
-            for (int g = 0; g < ng; ++g) {
-                if (!((gmask >> g) & 1u)) continue;
-                const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
-                unsigned long long go = 0ull; // same field order as the full step writes: p, v, v_bias, w, w_bias
-                const int ford[DC_GOAL_COLS] = {0, 1, 2, 3, 4, 5, 6, 7};
-                for (int f = 0; f < DC_GOAL_COLS; ++f) go = mixd(go, q[(size_t)ford[f] * np]);
-                hsh = mix(hsh, go);
-            }
-            rest &= (hsh == c.dyn_hash[e]);
         }
         if (rest) col.flag[e] = (uint8_t)(4u | (hit ? 1u : 0u));
         need_full = !rest;
     }
-    // compact the envs that need the full step (wave-aggregated append)
+    // Compact the envs that need the full step.  One global atomic per WORKGROUP: with one per wave, the 1024
+    // same-address atomics of a step were serialised in the L2 and cost the kernel ~15 of its 20 us.
     const unsigned long long m = __ballot(need_full);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        unsigned base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(c.dyn_count, (unsigned)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (need_full) c.dyn_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
-    }
+    const int lane = threadIdx.x & 63;
+    unsigned wave_base = 0;
+    if (m && lane == 0) wave_base = atomicAdd(&wg_cnt, (unsigned)__popcll(m)); // LDS
+    wave_base = __shfl(wave_base, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_base = wg_cnt ? atomicAdd(c.dyn_count, wg_cnt) : 0u;
+    __syncthreads();
+    if (need_full) c.dyn_queue[wg_base + wave_base + __popcll(m & ((1ull << lane) - 1ull))] = e;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1154,7 +1152,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         col.f64[(size_t)(DC_ARB + 4 * 50 + 9) * np + e] = (double)dbg_cnt[2];
     }
     col.live[e] = live;
-    c.dyn_hash[e] = hsh;
+    c.dyn_hash[e] = (unsigned long long)d.bank_epoch; // the bank generation this (possible) rest state belongs to
     col.flag[e] = (uint8_t)((hit ? 1u : 0u) | (changed ? 0u : 4u)); // unchanged = a fixed point of cpSpaceStep: at rest
 }
 
@@ -1177,12 +1175,25 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
 {
     // pass 1 over every env, then pass 2 over the queue it built (grid sized for the worst case; workgroups past the
     // queue's end leave at once).  The step kernel that follows empties the queue counter.
-    hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256),
-                       (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, d);
     static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
     dd.stop_after = stop_after;
+    hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + kClassifyThreads - 1) / kClassifyThreads)),
+                       dim3(kClassifyThreads), (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, dd);
     hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + kGrp - 1) / kGrp)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
+    return hipGetLastError();
+}
+
+__global__ void dyn_invalidate_kernel(const DevCfg c, const uint8_t *__restrict__ mask)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.n_envs || (mask && !mask[e])) return;
+    c.dyn_flag[e] &= (uint8_t)~4u;
+}
+
+hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dyn_invalidate_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256), 0, stream, c, mask);
     return hipGetLastError();
 }
 

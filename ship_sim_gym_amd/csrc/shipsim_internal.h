@@ -63,7 +63,7 @@ struct DevCfg {
     uint8_t *dyn_flag;            // bit 0: player touches a traffic ship this step (dyn -> step kernel);
                                   // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
                                   // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
-    unsigned long long *dyn_hash; // pose hash the rest bit was established for
+    unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
     int32_t *dyn_queue;           // envs that need the full dyn step this step (compacted by dyn_classify_kernel)
     unsigned *dyn_count;          // length of dyn_queue; zeroed by the step kernel
 };
@@ -87,6 +87,7 @@ hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream); // classify + full step of the queue
 hipError_t prepare_dyn(const DevCfg &c);
+hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_render(const DevCfg &c, const DynCfg &d, int e, int width, int height, uint8_t *rgb, unsigned flags,
                          hipStream_t stream);

@@ -188,6 +188,13 @@ class ShipVecEnv(object):
         v = self.state[off.value: off.value + nc.value * stride.value].view(dt).view(nc.value, n_pad)[:, :self.num_envs]
         return v[0] if nc.value == 1 else v
 
+    def wake_dynamics(self, mask=None):
+        """Config 4: call after writing the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns through field() — envs whose bodies
+        had come to rest are otherwise not stepped (ssg_dyn_invalidate).  mask: uint8 device tensor [num_envs] or None."""
+        with _torch().cuda.device(self.device):
+            mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
+            N.check(N.lib().ssg_dyn_invalidate(self._h, mp, self._stream()), self._h, "ssg_dyn_invalidate")
+
     def stats(self):
         """Per-handle episode counters accumulated in-kernel: sum_return, sum_length, episodes, goals_hit."""
         s = self.field(N.F_STATS).sum(dim=0).cpu().numpy()

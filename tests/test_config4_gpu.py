@@ -109,6 +109,7 @@ def test_config4_solver_scenarios():
     for k in range(3):
         cols[9 * k: 9 * k + 6] = poke[:, k].T
     T.copy_(torch.from_numpy(cols).to(vec.device))
+    vec.wake_dynamics()
     # the live arbiters of ship 1 (resting on the left bank) refer to its old pose in both implementations alike
     K = 60
     acts = (np.arange(n)[None, :] % 4 == 3) * 0 + np.where(np.arange(n)[None, :] % 4 == 3, 0, 1) * np.ones((K, 1), dtype=np.int64)
@@ -153,7 +154,7 @@ def test_config4_full_size_properties():
 
 def test_config4_rest_bit_and_poke_at_rest():
     """The dyn step skips envs whose bodies are at a fixed point of cpSpaceStep (rest bit).  The skip must be invisible:
-    parity continues while most envs rest, and writing the traffic columns of a resting env wakes it up."""
+    parity continues while most envs rest, and a caller that writes the traffic columns wakes the env (wake_dynamics)."""
     torch, O, N, ShipVecEnv = _mods()
     from helpers import oracle_cfg
     n = 512
@@ -174,6 +175,7 @@ def test_config4_rest_bit_and_poke_at_rest():
     idx = np.arange(0, n, 3)
     cols[9 + 0, idx] = 372.0; cols[9 + 1, idx] = 360.0; cols[9 + 3, idx] = 11.0; cols[9 + 5, idx] = 0.03
     T.copy_(cols)
+    vec.wake_dynamics()                                        # the contract for writing body columns (ssg_dyn_invalidate)
     for e in idx:
         cur = ob.peek_dyn(int(e))["traffic"][1]
         ob.poke_traffic(int(e), 1, 372.0, 360.0, cur[2], 11.0, cur[4], 0.03)
