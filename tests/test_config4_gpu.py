@@ -236,3 +236,44 @@ def test_config4_history_sizes(hist):
     err, n_done = run_pair(O, N, vec, K=80)
     assert err <= 1e-9 and n_done > 30
     vec.close()
+
+
+def test_config4_single_env_facade_fresh_mode():
+    """The reference's usage pattern for config 4 — `env = ShipEnv(...); env.reset(); env.game.add_default_traffic()` —
+    on the facade (fresh map mode, one brand-new world per reset from the global RNG streams) against an oracle World."""
+    import random
+    torch, O, N, ShipVecEnv = _mods()
+    from ship_sim_gym_amd.ship_env import ShipEnv
+    from ship_sim_gym_amd import worldgen
+    for seed in (3, 4):
+        random.seed(seed); np.random.seed(seed)
+        env = ShipEnv(n_ships=4)
+        o = env.reset()
+        env.game.add_default_traffic()                           # a no-op here: every reset of an n_ships=4 env adds them
+        random.seed(seed); np.random.seed(seed)
+        worldgen.generate_world((600, 600))                      # construction consumes one world (game.py:58)
+        _, polys, goals = worldgen.generate_world((600, 600))
+        w = O.World(O.default_config(n_traffic=3))
+        np.testing.assert_array_equal(o, w.reset(polys[0], polys[1], goals))
+        assert [(s.x, s.y) for s in env.game.ships] == [(100.0, 200.0), (300.0, 200.0), (400.0, 350.0)]
+        rng = np.random.RandomState(seed + 100)
+        for t in range(300):
+            a = int(rng.randint(3))
+            o, r, d, info = env.step(a)
+            ro, rr, rd = w.step(a)
+            assert r == rr and d == rd
+            np.testing.assert_allclose(o, ro, rtol=0, atol=1e-9)
+            pd = w.peek_dyn()
+            got = np.array([(s.x, s.y, s.angle) for s in env.game.ships])
+            np.testing.assert_allclose(got, pd["traffic"][:, :3], rtol=0, atol=1e-8)
+            if d:
+                break
+        g = env.game.goals                                       # moving goal bodies are reported from body.position
+        assert len(g) == bin(int(w.peek()["alive_mask"])).count("1")
+        env.close()
+    with pytest.raises(N.ShipSimError):
+        e1 = ShipEnv()
+        try:
+            e1.game.add_default_traffic()                        # a 1-ship env cannot grow traffic after the fact
+        finally:
+            e1.close()
