@@ -277,3 +277,27 @@ def test_config4_single_env_facade_fresh_mode():
             e1.game.add_default_traffic()                        # a 1-ship env cannot grow traffic after the fact
         finally:
             e1.close()
+
+
+def test_config4_shard_equivalence():
+    """SURVEY §8e for config 4: stepping N envs on one handle == the same envs split over two handles (per-env action
+    stream and map assignment are keyed by the GLOBAL env id), bit for bit, bodies included."""
+    torch, O, N, ShipVecEnv = _mods()
+    n, K = 640, 60
+    whole = ShipVecEnv(n, n_maps=16, n_ships=4)
+    a = ShipVecEnv(256, n_maps=16, n_ships=4, env_id_base=0)
+    b = ShipVecEnv(n - 256, n_maps=16, n_ships=4, env_id_base=256)
+    ow = whole.reset_tensor().clone()
+    assert torch.equal(ow[:256], a.reset_tensor()) and torch.equal(ow[256:], b.reset_tensor())
+    aw, aa, ab = whole.random_actions(5, 0, K), a.random_actions(5, 0, K), b.random_actions(5, 0, K)
+    assert torch.equal(aw[:, :256], aa) and torch.equal(aw[:, 256:], ab)
+    for k in range(K):
+        o, r, d, f = whole.step_tensor(aw[k])
+        o1, r1, d1, f1 = a.step_tensor(aa[k])
+        o2, r2, d2, f2 = b.step_tensor(ab[k])
+        assert torch.equal(o[:256], o1) and torch.equal(o[256:], o2)
+        assert torch.equal(r[:256], r1) and torch.equal(r[256:], r2) and torch.equal(d[:256], d1) and torch.equal(d[256:], d2)
+    tw = whole.field(N.F_TRAFFIC)
+    assert torch.equal(tw[:, :256], a.field(N.F_TRAFFIC)) and torch.equal(tw[:, 256:], b.field(N.F_TRAFFIC))
+    for v in (whole, a, b):
+        v.close()
