@@ -196,7 +196,8 @@ int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double 
  * train/random.py:14-27, batched), enqueued on `stream` as ceil(K / SSG_ROLLOUT_STEPS_PER_LAUNCH) launches of the step
  * kernel: inside a launch the map bank stays in LDS and the body state in registers from step to step.
  * obs/reward/done/flags are overwritten by every step and the state blob is updated every step; the final contents of
- * every buffer are bit for bit those of K separate ssg_step calls. */
+ * every buffer are bit for bit those of K separate ssg_step calls.  With history > 2 or n_ships = 4 every step is its own
+ * launch sequence (frame shift / the two dyn kernels before the step kernel): same results, no fusion. */
 #define SSG_ROLLOUT_STEPS_PER_LAUNCH 100 /* steps fused into one launch of the step kernel by ssg_rollout */
 int ssg_rollout(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev_obs, double *dev_reward,
                 uint8_t *dev_done, uint8_t *dev_flags /* nullable */, void *stream);
