@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Long randomized parity soak on the GPU box (not part of the test suite): the HIP path against the oracle over
+millions of env-steps with auto-reset, configs 3 and 4.  Round 1: 12 M + 20 M env-steps, 780 k episode ends, rewards /
+done flags identical, max |obs - oracle| 1.1e-10."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from oracle import oracle as O
+from ship_sim_gym_amd.vec_env import ShipVecEnv
+from helpers import oracle_cfg
+
+
+def soak(n, K, seed=777, **kw):
+    vec = ShipVecEnv(n, n_maps=64, **kw)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    acts = vec.random_actions(seed, 0, K)
+    ah = acts.cpu().numpy()
+    worst, t0, ndone = 0.0, time.time(), 0
+    for k in range(K):
+        obs, rew, done, flags = vec.step_tensor(acts[k])
+        r_obs, r_rew, r_done = ob.step(ah[k], auto_reset=True, n_threads=O.max_threads())
+        assert np.array_equal(done.cpu().numpy(), r_done), ("done", k)
+        assert np.array_equal(rew.cpu().numpy(), r_rew), ("reward", k)
+        worst = max(worst, float(np.abs(obs.cpu().numpy() - r_obs).max()))
+        ndone += int(r_done.sum())
+    print(kw, "n=%d K=%d: max |obs-oracle| %.3e, %d episode ends, %.1f s" % (n, K, worst, ndone, time.time() - t0), flush=True)
+    assert worst <= 1e-9
+    vec.close()
+
+
+if __name__ == "__main__":
+    soak(8192, 1500, n_beams=8)
+    soak(8192, 1200, n_beams=10, n_ships=4)
+    soak(16384, 600, seed=4, n_beams=10, n_ships=4)
