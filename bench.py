@@ -3,23 +3,39 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed / RCCL when N > 1, launched by torch.distributed.run); every rank steps
-its own shard of envs with NO data-path collective (envs are independent) after one RCCL broadcast
-of the map bank from rank 0.  A "step" is one ssg_step pass (one kernel launch) over the rank's whole env batch
-with a pre-generated random action vector already resident in HBM; obs / reward / done are written to HBM every
-step and done envs are auto-reset in-kernel.  Workload at N=1: BASELINE.json configs[2] — 65 536 parallel envs,
-1 ship, 8-beam lidar, default 600x600 map bank (64 maps), SPEED 10 — the configuration the ">= 10 M env-steps/s
-on one MI355X" target is quoted on.  Weak scaling: every rank owns 65 536 envs.
+One process per GPU.  With N > 1 and no torch.distributed environment (RANK unset) this process is only a
+LAUNCHER: it touches no GPU, starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+(the same command line the driver uses) and exits with the child's code.  A rank started by torch.distributed.run
+initialises RCCL (backend "nccl"), refuses to run when WORLD_SIZE != --gpus or when the node shows fewer devices
+than ranks, and steps its own shard of envs with NO data-path collective (envs are independent)
+after one RCCL broadcast of the map bank from rank 0.  Weak scaling: every rank owns 65 536 envs; `n_gpus` in the
+JSON line is the RCCL world size the ranks saw.
 
-Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
-  roofline     — algorithmic HBM bytes per launch (675 B/env-step at S=1, nb=8, H=2) divided by the
-                 kernel's average launch duration measured with HIP events on the launch stream, against 8 TB/s.
-  cpu_baseline — the CPU oracle ("port": our C restatement of the reference path, NOT pymunk) timed on this box's
-                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+A "step" is one pass of the hot path over the rank's whole env batch (ssg_rollout: fused launches of
+ssg::step_kernel) with a pre-generated random action tensor already resident in HBM; obs / reward / done are
+written to HBM every step and done envs are auto-reset in-kernel.  Workload at N=1: BASELINE.json configs[2] —
+65 536 parallel envs, 1 ship, 8-beam lidar, default 600x600 map bank (64 maps), SPEED 10 — the configuration
+the ">= 10 M env-steps/s on one MI355X" target is quoted on.
+
+Timing: W untimed warm-up steps, then the K-step rollout is timed `--repeats` (default 5) times, every repeat
+bracketed by barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` is the
+MEDIAN repeat, all repeats are listed in `repeats_ms`.
+
+Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
+  roofline      — algorithmic HBM bytes per launch (675 B/env-step at S=1, nb=8, H=2) divided by
+                  the step kernel's average launch duration in the median repeat, measured with HIP events on the
+                  launch stream, against 8 TB/s.  `traffic` is the PMC-measured HBM bytes per env-step of the
+                  committed rocprofv3 run (`traffic_source`) scaled to the launch that was timed here.
+  other_configs — informational (N=1 only, outside the timed region): BASELINE configs[1] (4 096 envs, 10 beams),
+                  configs[3] (65 536 envs x 4 ships) and the one-launch-per-step (policy-in-the-loop) path.
+  cpu_baseline  — the CPU oracle ("port": our C restatement of the reference path, NOT pymunk) timed on this box's
+                  host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,7 +54,11 @@ def algorithmic_bytes(n_ships, nb, hist):
     return 96 * n_ships + 8 + 8 + 2 + 80 + 4 + 4 + 16 * nb + 8 * (6 + nb) + 8 * hist * (6 + nb) + 9
 
 
-def cpu_baseline(vec, seconds_target=6.0):
+def steps_per_launch_cfg():
+    return max(1, int(os.environ.get("SSG_FUSE", "100")))  # SSG_ROLLOUT_STEPS_PER_LAUNCH (include/shipsim.h)
+
+
+def cpu_baseline(vec, seconds_target=10.0):
     """Time the CPU oracle on a bounded sample of the same workload: same bank, same Philox action stream."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -61,7 +81,7 @@ def cpu_baseline(vec, seconds_target=6.0):
                       "%.1f s" % (n, K, dt)}
 
 
-def measured_copy_gbps(dev, stream_ptr=None):
+def measured_copy_gbps(dev):
     """SURVEY.md §8(d) "measured roofline": our own 8-byte-per-lane device-to-device copy (the step kernel's access
     width) over 2 x 1 GiB on the same GPU in the same run; returns (read + write) GB/s, best of 5."""
     import ctypes as C
@@ -85,36 +105,102 @@ def measured_copy_gbps(dev, stream_ptr=None):
     return best
 
 
+def event_time_rollout(vec, acts, reps=3):
+    """HIP-event time (ms, median of `reps`) of one ssg_rollout over `acts` on torch's current stream."""
+    import torch
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        vec.rollout_tensor(acts)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
+
+
+def side_config(dev, n, n_beams, n_ships, K, W):
+    """Informational timing of another BASELINE config on this GPU (outside the headline's timed region)."""
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships)
+    acts = vec.random_actions(12345, 0, K + W)
+    vec.reset_tensor()
+    vec.rollout_tensor(acts[:W])
+    ms = event_time_rollout(vec, acts[W:])
+    B = algorithmic_bytes(n_ships, n_beams, 2)
+    us = ms * 1e3 / K
+    sps = n * K / (ms * 1e-3)
+    vec.close()
+    return {"envs": n, "n_beams": n_beams, "n_ships": n_ships, "steps": K, "us_per_step": us, "env_steps_per_s": sps,
+            "algorithmic_bytes_per_env_step": B, "achieved_GBps": sps * B / 1e9, "frac": sps * B / 1e9 / HBM_PEAK_GBPS}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a torch.distributed environment: start N ranks as a CHILD job and return its exit code.
+    This process never touches a GPU (no HIP call, no torch.cuda query), so nothing GPU-initialised is re-executed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step rollout; value = the median")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true", help="skip the informational one-launch-per-step timing")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C4 timings")
     ap.add_argument("--workload", choices=("c3", "c4"), default="c3",
                     help="c3 (default, the BASELINE metric's config): 1 ship, 8 beams; c4: BASELINE configs[3], 4 ships "
                          "(traffic + dynamic goals + contact solver), 10 beams — informational, not the headline line")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.repeats < 1:
+        ap.error("--gpus/--steps/--repeats must be >= 1 and --warmup >= 0")
+
+    in_dist_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_dist_env:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     from ship_sim_gym_amd.vec_env import ShipVecEnv
     from ship_sim_gym_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_dist_env else 1
+    rank = int(os.environ.get("RANK", "0")) if in_dist_env else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_dist_env else 0
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a line for the wrong N\n"
+                         % (args.gpus, world))
+        sys.exit(2)
+    n_dev = torch.cuda.device_count()
+    if n_dev < (local_rank + 1) or (in_dist_env and n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))):
+        sys.stderr.write("bench.py: rank %d/%d needs device %d but this node shows %d HIP device(s): one process per "
+                         "GPU, no oversubscription\n" % (rank, world, local_rank, n_dev))
+        sys.exit(3)
+    use_dist = in_dist_env
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        world = dist.get_world_size()
 
     n = args.envs_per_gpu
     c4 = args.workload == "c4"
@@ -133,56 +219,55 @@ def main():
     if use_dist:
         sharding.broadcast_bank(vec, src=0)  # RCCL broadcast of the map bank over xGMI; the only collective on the path
 
-    K, W = args.steps, args.warmup
-    acts = vec.random_actions(12345, 0, K + W)  # [K+W, n] int32, generated on device before the timed region
+    K, W, R = args.steps, args.warmup, args.repeats
+    acts = vec.random_actions(12345, 0, W + K * R)  # int32 [W + R*K, n], generated on device before any timed region
     vec.reset_tensor()
-    vec.rollout_tensor(acts[:W]) if W > 0 else None
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    vec.rollout_tensor(acts[W:])  # K launches of the step kernel on torch's current stream
-    ev1.record()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    # for information: the policy-in-the-loop path, one ssg_step launch per step (not the headline number)
-    single_us = None
-    if world == 1 and not args.no_single_step:
-        ks = min(K, 500)
+    if W > 0:
+        vec.rollout_tensor(acts[:W])
+    walls, evs = [], []
+    for r in range(R):
+        a = acts[W + r * K: W + (r + 1) * K]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for k in range(ks):
-            vec.step_tensor(acts[W + k])
-        e1.record()
+        if use_dist:
+            dist.barrier()
         torch.cuda.synchronize()
-        single_us = e0.elapsed_time(e1) * 1e3 / ks
+        t0 = time.perf_counter()
+        ev0.record()
+        vec.rollout_tensor(a)  # exactly K steps: ceil(K / steps_per_launch) launches of the step kernel
+        ev1.record()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        walls.append(time.perf_counter() - t0)
+        evs.append(ev0.elapsed_time(ev1))
     if use_dist:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time
-        wall = float(t.item())
+        t = torch.tensor(walls, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time, repeat by repeat
+        walls = [float(v) for v in t.tolist()]
+    order = sorted(range(R), key=lambda i: walls[i])
+    med = order[R // 2]
+    wall, ev_ms = walls[med], evs[med]
 
     if rank == 0:
         total_steps = float(n) * world * K
         B = algorithmic_bytes(4 if c4 else 1, n_beams, 2)
         # ssg_rollout fuses SSG_ROLLOUT_STEPS_PER_LAUNCH (100) steps into each launch of the step kernel:
         # algorithmic bytes per launch = B * n * steps_per_launch, launch duration = HIP-event time / launches
-        # (config 4 has no fused rollout: one "launch" below is one step = dyn classify + dyn step + step kernel)
-        spl = 1 if c4 else int(os.environ.get("SSG_FUSE", "100"))
+        # (config 4 has no fused rollout: one "launch" below is one step = dyn kernels + step kernel)
+        spl = 1 if c4 else steps_per_launch_cfg()
         n_launch = (K + spl - 1) // spl
         launch_s = ev_ms * 1e-3 / n_launch
-        achieved = B * n * (K / n_launch) / launch_s / 1e9
-        traffic = None
+        steps_in_launch = K / n_launch
+        achieved = B * n * steps_in_launch / launch_s / 1e9
+        traffic, traffic_src, traffic_per_step = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and not c4:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")  # rocprofv3 PMC, same command (profiles/)
+                tj = json.load(open(tpath))
+                traffic_per_step = float(tj["hbm_bytes_per_env_step"])
+                traffic = traffic_per_step * n * steps_in_launch  # scaled to the launch timed in THIS run
+                traffic_src = tj.get("source")
             except Exception:
                 traffic = None
         copy_gbps = measured_copy_gbps(dev)
@@ -196,17 +281,41 @@ def main():
                                    ("BASELINE configs[2]: 65536 parallel envs per GPU, 1 ship, 8-beam lidar, 64-map "
                                     "bank (600x600, SPEED 10), random Philox actions, auto-reset in-kernel"),
                        "envs_per_gpu": n, "total_envs": n * world, "n_beams": n_beams, "history": 2,
-                       "parallelism": "env-sharded x%d, no data-path collective" % world},
+                       "parallelism": "env-sharded x%d, one process per GPU (RCCL world size %d), no data-path "
+                                      "collective" % (world, world)},
+            "repeats": R, "repeats_ms": [w * 1e3 for w in walls], "timing": "median of %d repeats of the K-step rollout" % R,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_bytes_per_env_step": traffic_per_step, "traffic_source": traffic_src,
                          "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
-                         "kernel": ("ssg::dyn_classify_kernel + ssg::dyn_step_kernel + ssg::step_kernel<10, 256, true, false, true>"
+                         "kernel": ("ssg::dyn_* kernels + ssg::step_kernel<10, 256, true, false, true>"
                                     if c4 else "ssg::step_kernel<8, 256, true, false, false>"),
                          "algorithmic_bytes_per_env_step": B,
-                         "steps_per_launch": K / n_launch, "avg_launch_us": launch_s * 1e6,
-                         "us_per_step_in_launch": launch_s * 1e6 * n_launch / K},
-            "single_step_launch_us": single_us,
+                         "steps_per_launch": steps_in_launch, "avg_launch_us": launch_s * 1e6,
+                         "us_per_step_in_launch": launch_s * 1e6 / steps_in_launch},
         }
+        other = {}
+        if world == 1 and not args.no_single_step:
+            # the policy-in-the-loop path: one ssg_step launch per step
+            ks = min(K, 500)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(ks):
+                vec.step_tensor(acts[W + k])
+            e1.record()
+            torch.cuda.synchronize()
+            out["single_step_launch_us"] = e0.elapsed_time(e1) * 1e3 / ks
+        else:
+            out["single_step_launch_us"] = None
+        if world == 1 and not args.no_other_configs and not c4:
+            try:
+                other["c2_4096_envs_10_beams"] = side_config(dev, 4096, 10, 1, 1000, 200)
+                other["c4_65536_envs_x4_ships_10_beams"] = side_config(dev, 65536, 10, 4, 200, 200)
+                other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
+            except Exception as ex:  # informational only: never lose the headline line
+                other["error"] = repr(ex)
+        out["other_configs"] = other or None
         if world == 1 and not args.no_cpu_baseline and not c4:
             out["cpu_baseline"] = cpu_baseline(vec)
         else:

@@ -4,7 +4,8 @@ the global ``random`` / ``np.random`` streams in the reference's call order, so 
 worlds.  ``env.game`` offers the attribute reach-through the reference's tests use (tests/test_ship_env.py:22-36).
 
 Stepping after ``done`` without ``reset()`` is outside the contract: the reference would keep simulating contact
-response with Chipmunk's impulse solver, which this path does not carry.
+response with Chipmunk's impulse solver, which this path does not carry for the player — so
+``step()`` on a finished episode RAISES instead of silently returning states the reference would not produce.
 """
 import numpy as np
 
@@ -126,6 +127,9 @@ class ShipEnv(_GymEnv):
 
     def __init__(self, game_config=None, env_config=None, device="cuda:0", **kw):
         self._vec = ShipVecEnv(1, game_config, env_config, device=device, map_mode="fresh", auto_reset=False, **kw)
+        self.game_config = self._vec.game_config   # what ShipVecEnv.from_env_fns reads back from a probe env
+        self._ctor_kw = dict(kw)
+        self._done = False
         self.action_space = self._vec.action_space
         self.observation_space = self._vec.observation_space
         self.env_config = env_config
@@ -148,9 +152,11 @@ class ShipEnv(_GymEnv):
         """ShipEnv.reset (ship_env.py:171-184).  Extensions for scenario tests, mirroring what the reference's own
         (older-API) tests did with `reset(spawn_point=...)` and `game.add_goal(x, y)` (tests/test_ship_env.py:26-38):
         `goals` replaces the generated goal path with the given N_GOALS centres, `spawn_point` moves the ship."""
-        obs = self._vec.reset()[0]
-        if goals is not None or spawn_point is not None:
-            obs = self._override(obs, spawn_point, goals)
+        if goals is None and spawn_point is None:
+            obs = self._vec.reset()[0]
+        else:
+            obs = self._reset_with_override(spawn_point, goals)
+        self._done = False
         self.last_action = None
         self.reward = 0
         self.cumulative_reward = 0
@@ -160,30 +166,38 @@ class ShipEnv(_GymEnv):
         self.states = obs
         return obs
 
-    def _override(self, obs, spawn_point, goals):
+    def _reset_with_override(self, spawn_point, goals):
+        """reset() onto a world whose goal path / spawn point the caller dictates.  The world is still drawn first (same
+        RNG consumption as a plain reset); the override goes into the map record BEFORE ssg_reset, so everything the
+        reset derives from it — the reset observation's nearest goal and, in config 4, the dynamic goal bodies and the
+        previous-frame goal columns — sees the overridden goals."""
         import torch
         from . import worldgen
         v = self._vec
+        v._fresh_world(0)
         polys, g0 = v.worlds[0]
         g = np.asarray(goals if goals is not None else g0, dtype=np.float64).reshape(v.cfg.n_goals, 2)
         sp = (float(spawn_point[0]), float(spawn_point[1])) if spawn_point is not None else (v.cfg.spawn_x, v.cfg.spawn_y)
         v.worlds[0] = (polys, g)
         v.bank_host[0] = worldgen.build_record(polys[0], polys[1], g, sp)
         v.bank.copy_(torch.from_numpy(v.bank_host))
-        v.field(N.F_X)[0] = sp[0]
-        v.field(N.F_Y)[0] = sp[1]
-        obs = obs.copy()
-        F = self.n_states
-        obs[-F + 0], obs[-F + 1] = sp
-        obs[-F + 4] = v.bank_host[0][N.MAP_OFF_SPAWN_GOAL]      # closest_goal from the new position
-        obs[-F + 5] = v.bank_host[0][N.MAP_OFF_SPAWN_GOAL + 1]
-        v.obs[0].copy_(torch.from_numpy(obs))
+        obs = v.reset_tensor().cpu().numpy()[0].copy()
+        if spawn_point is not None:  # the reset kernel spawns at the configured point: move the body and its frame
+            v.field(N.F_X)[0] = sp[0]
+            v.field(N.F_Y)[0] = sp[1]
+            F = self.n_states
+            obs[-F + 0], obs[-F + 1] = sp
+            v.obs[0].copy_(torch.from_numpy(obs))
         torch.cuda.synchronize()
         return obs
 
     def step(self, action):
         assert self.action_space.contains(action), "%r (%s) invalid" % (action, type(action))  # ship_env.py:143
+        if self._done:
+            raise N.ShipSimError("ShipEnv.step() called after done=True: call reset() first (the player's contact "
+                                 "response after a collision is not simulated, DESIGN.md §2)")
         obs, rew, done, _ = self._vec.step(np.asarray([action]))
+        self._done = bool(done[0])
         self._last_flags = int(self._vec.flags[0].item())
         self.last_action = action
         self.reward = float(rew[0])

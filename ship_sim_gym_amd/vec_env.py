@@ -36,13 +36,66 @@ def _torch():
     return torch
 
 
-class ShipVecEnv(object):
+def _trainer_bases():
+    """Base classes for ShipVecEnv: the trainers' own abstract vector-env classes when they are importable, so that
+    PPO2's `isinstance(env, VecEnv)` (stable-baselines, train/stable_baselines/ppo.py:88,122-123) and RLlib's
+    `isinstance(env, VectorEnv)` (train/rllib/ppo.py:21-24,43) gates accept the batched env; `object` otherwise."""
+    bases = []
+    for mod, name in (("stable_baselines.common.vec_env", "VecEnv"), ("stable_baselines3.common.vec_env", "VecEnv"),
+                      ("ray.rllib.env.vector_env", "VectorEnv")):
+        if mod.startswith("stable_baselines3") and bases:
+            continue  # one VecEnv flavour is enough
+        try:
+            cls = getattr(__import__(mod, fromlist=[name]), name)
+        except Exception:
+            continue
+        if isinstance(cls, type) and cls not in bases:
+            bases.append(cls)
+    return tuple(bases) or (object,)
+
+
+_BASES = _trainer_bases()
+
+
+class EnvHandle(object):
+    """One env of a ShipVecEnv, for the per-env calls of the trainers' APIs (`env_method`, `get_attr`, `set_attr`,
+    RLlib's `get_unwrapped()`): attribute reads fall through to the batch, `reset()`/`seed()`/`render()` act on
+    this env only."""
+
+    def __init__(self, vec, index):
+        object.__setattr__(self, "_vec", vec)
+        object.__setattr__(self, "index", int(index))
+        object.__setattr__(self, "_attrs", {})
+
+    def __getattr__(self, name):
+        attrs = object.__getattribute__(self, "_attrs")
+        if name in attrs:
+            return attrs[name]
+        return getattr(object.__getattribute__(self, "_vec"), name)
+
+    def __setattr__(self, name, value):
+        self._attrs[name] = value
+
+    def reset(self):
+        return self._vec.reset_at(self.index)
+
+    def seed(self, seed=None):
+        return self._vec.seed(seed)
+
+    def render(self, mode='human', close=False):
+        return self._vec.render(mode=mode, close=close, env=self.index)
+
+    def close(self):
+        return None
+
+
+class ShipVecEnv(*_BASES):
     metadata = {'render.modes': ['human', 'rgb_array']}  # ship_env.py:18
     reward_range = (-1, 1)                                # ship_env.py:20
 
     def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
                  map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
-                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1):
+                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1, rllib=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -56,8 +109,12 @@ class ShipVecEnv(object):
         self.map_mode = map_mode
         self.bounds = tuple(game_config.BOUNDS)
         self.width_frac = float(width_frac)
-        self.auto_reset = bool(auto_reset)
+        # rllib=True: the RLlib VectorEnv flow — vector_step returns the TERMINAL observation of a done env and the
+        # caller's reset_at(i) is the one reset it gets (no in-kernel auto-reset underneath)
+        self.rllib = bool(rllib)
+        self.auto_reset = bool(auto_reset) and not self.rllib
         self.env_id_base = int(env_id_base)
+        self.game_config, self.env_config = game_config, env_config
 
         c = N.default_config()
         c.device_id = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -133,6 +190,37 @@ class ShipVecEnv(object):
             raise ValueError("map_mode must be 'bank' or 'fresh'")
         self._pending = None
         self._closed = False
+        self._handles = {}
+        self._await_reset = np.zeros(self.num_envs, dtype=bool)  # rllib flow: done envs already re-initialised
+        self._reset_obs_h = None
+        for base in _BASES:  # the trainers' base-class constructors (SB: VecEnv.__init__(num_envs, obs_space, act_space))
+            if base is object:
+                continue
+            try:
+                base.__init__(self, self.num_envs, self.observation_space, self.action_space)
+            except TypeError:
+                try:
+                    base.__init__(self)
+                except Exception:
+                    pass
+
+    @classmethod
+    def from_env_fns(cls, env_fns, **kw):
+        """SubprocVecEnv-shaped constructor (train/stable_baselines/ppo.py:122-123: ``SubprocVecEnv([make_env() for i in
+        range(num_cpu)])``): one batched env of ``len(env_fns)`` envs instead of one OS process per env.  The first
+        thunk is called once to learn the (game_config, env_config) the caller's ``ShipEnv(...)`` line passes."""
+        env_fns = list(env_fns)
+        if not env_fns:
+            raise ValueError("need at least one env thunk")
+        probe = env_fns[0]()
+        gc, ec = getattr(probe, "game_config", None), getattr(probe, "env_config", None)
+        extra = dict(getattr(probe, "_ctor_kw", {}))
+        try:
+            probe.close()
+        except Exception:
+            pass
+        extra.update(kw)
+        return cls(len(env_fns), gc, ec, **extra)
 
     # ------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -195,9 +283,13 @@ class ShipVecEnv(object):
             mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
             N.check(N.lib().ssg_dyn_invalidate(self._h, mp, self._stream()), self._h, "ssg_dyn_invalidate")
 
+    def field_stats_tensor(self):
+        """int64 device tensor [4]: sum_return*100, sum_length, episodes, goals_hit of this handle (slots summed)."""
+        return self.field(N.F_STATS).sum(dim=0)
+
     def stats(self):
         """Per-handle episode counters accumulated in-kernel: sum_return, sum_length, episodes, goals_hit."""
-        s = self.field(N.F_STATS).sum(dim=0).cpu().numpy()
+        s = self.field_stats_tensor().cpu().numpy()
         return {"sum_return": float(s[0]) / 100.0, "sum_length": int(s[1]), "episodes": int(s[2]), "goals_hit": int(s[3])}
 
     # ------------------------------------------------------------------------------------------------
@@ -257,8 +349,9 @@ class ShipVecEnv(object):
 
     def step_async(self, actions):
         a = np.asarray(actions)
-        for v in a.reshape(-1):
-            assert self.action_space.contains(int(v)), "%r (%s) invalid" % (v, type(v))  # ship_env.py:143
+        # ship_env.py:143 `assert self.action_space.contains(action)` for the whole batch in one range check
+        ok = a.dtype.kind in "iu" and a.size == self.num_envs and bool(np.all((a >= 0) & (a < self.action_space.n)))
+        assert ok, "%r (%s) invalid" % (a, a.dtype)
         self._pending = a.astype(np.int32).reshape(self.num_envs)
 
     def step_wait(self):
@@ -312,11 +405,47 @@ class ShipVecEnv(object):
             return self.get_screen(env).permute(1, 0, 2).cpu().numpy()
         return None
 
-    def get_attr(self, name, indices=None):
-        return [getattr(self, name)] * self.num_envs
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, (int, np.integer)):
+            return [int(indices)]
+        return [int(i) for i in indices]
 
-    def env_method(self, method_name, *args, **kwargs):
-        raise NotImplementedError(method_name)
+    def env(self, index):
+        """Per-env handle (cached): what `env_method` / `get_attr` / `set_attr` / `get_unwrapped` act on."""
+        index = int(index)
+        if not 0 <= index < self.num_envs:
+            raise IndexError(index)
+        h = self._handles.get(index)
+        if h is None:
+            h = self._handles[index] = EnvHandle(self, index)
+        return h
+
+    def get_attr(self, attr_name, indices=None):
+        """VecEnv.get_attr: the attribute of each selected env (per-env values set by set_attr win over the batch's)."""
+        return [getattr(self.env(i), attr_name) for i in self._indices(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        """VecEnv.set_attr: stored per env; the batched physics configuration itself is fixed at construction."""
+        for i in self._indices(indices):
+            setattr(self.env(i), attr_name, value)
+
+    def env_method(self, method_name, *method_args, **method_kwargs):
+        """VecEnv.env_method: call `method_name` on each selected env handle (reset / seed / render / close, or any
+        batch method that takes no env index) and return the list of results."""
+        indices = method_kwargs.pop("indices", None)
+        return [getattr(self.env(i), method_name)(*method_args, **method_kwargs) for i in self._indices(indices)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._indices(indices)]
+
+    def get_images(self):
+        return [self.render(mode='rgb_array', env=i) for i in range(self.num_envs)]
+
+    @property
+    def unwrapped(self):
+        return self
 
     def __del__(self):
         try:
@@ -328,10 +457,18 @@ class ShipVecEnv(object):
     # RLlib VectorEnv protocol
     # ------------------------------------------------------------------------------------------------
     def vector_reset(self):
+        self._await_reset[:] = False
         return list(self.reset())
 
     def reset_at(self, index):
+        """VectorEnv.reset_at: the ONE reset of env `index` (game.py:260-277).  In the rllib flow vector_step has
+        already re-initialised every env it reported done, in one masked launch, and cached the reset observations;
+        this call hands that observation out instead of resetting (and advancing the map) a second time."""
         torch = _torch()
+        index = int(index)
+        if self._await_reset[index]:
+            self._await_reset[index] = False
+            return self._reset_obs_h[index].copy()
         mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
         mask[index] = 1
         if self.map_mode == "fresh":
@@ -346,9 +483,42 @@ class ShipVecEnv(object):
         torch.cuda.current_stream(self.device).synchronize()
         return self.obs[index].cpu().numpy()
 
+    def _reset_done_envs(self, done_h):
+        """rllib flow: re-initialise all done envs with ONE masked reset launch (next map of the bank, exactly the
+        sequence the in-kernel auto-reset follows) into a side buffer, leaving self.obs = the terminal observations."""
+        torch = _torch()
+        mask = torch.from_numpy(done_h.astype(np.uint8)).to(self.device)
+        if self.map_mode == "fresh":
+            for e in np.nonzero(done_h)[0]:
+                self._fresh_world(int(e))
+            self.bank.copy_(torch.from_numpy(self.bank_host))
+            ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+        else:
+            ids = self.field(N.F_MAP_ID).clone()
+            ids = torch.where(mask != 0, (ids + 1) % self.n_maps, ids).to(torch.int32).contiguous()
+        side = torch.empty_like(self.obs)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ssg_reset(self._h, C.c_void_p(mask.data_ptr()), C.c_void_p(ids.data_ptr()),
+                                      C.c_void_p(side.data_ptr()), self._stream()), self._h, "ssg_reset")
+        torch.cuda.current_stream(self.device).synchronize()
+        if self._reset_obs_h is None:
+            self._reset_obs_h = np.empty((self.num_envs, self.states_history), dtype=np.float64)
+        idx = np.nonzero(done_h)[0]
+        self._reset_obs_h[idx] = side[torch.from_numpy(idx).to(self.device)].cpu().numpy()
+        self._await_reset |= done_h
+
     def vector_step(self, actions):
-        obs, rew, done, infos = self.step(np.asarray(actions))
+        if not self.rllib:
+            obs, rew, done, infos = self.step(np.asarray(actions))
+            return list(obs), list(rew), list(done), infos
+        if self._await_reset.any():
+            raise N.ShipSimError("vector_step: envs %r were reported done and have not been reset_at()"
+                                 % (np.nonzero(self._await_reset)[0][:8].tolist(),))
+        obs, rew, done, infos = self.step(np.asarray(actions))  # no auto-reset: obs rows of done envs are terminal
+        if done.any():
+            self._reset_done_envs(done)
         return list(obs), list(rew), list(done), infos
 
     def get_unwrapped(self):
-        return []
+        """VectorEnv.get_unwrapped: the underlying envs, as per-env handles."""
+        return [self.env(i) for i in range(self.num_envs)]

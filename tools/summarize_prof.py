@@ -45,5 +45,10 @@ if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
     hbm = (big["FETCH_SIZE"] / fcal + big["WRITE_SIZE"] / wcal) * 1024
     print("== HBM traffic of one 100-step rollout launch: (FETCH_SIZE/%.3f + WRITE_SIZE/%.3f) KB = %.6g bytes per launch ==" % (fcal, wcal, hbm))
     import json
-    json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kb": big["FETCH_SIZE"], "write_size_kb": big["WRITE_SIZE"],
-               "fetch_calibration": fcal, "write_calibration": wcal}, open(os.path.join(out, "traffic.json"), "w"))
+    envs = int(os.environ.get("SSG_PROF_ENVS", "65536"))
+    spl = int(os.environ.get("SSG_FUSE", "100"))
+    json.dump({"hbm_bytes_per_launch": hbm, "hbm_bytes_per_env_step": hbm / (envs * spl), "envs": envs,
+               "steps_per_launch": spl, "fetch_size_kb": big["FETCH_SIZE"], "write_size_kb": big["WRITE_SIZE"],
+               "fetch_calibration": fcal, "write_calibration": wcal,
+               "source": os.environ.get("SSG_PROF_SOURCE", os.path.basename(out))},
+              open(os.path.join(out, "traffic.json"), "w"))
