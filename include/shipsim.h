@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 2 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4) */
+#define SSG_ABI_VERSION 3 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -162,9 +162,19 @@ int ssg_state_nbytes(const ssg_handle *h, size_t *nbytes);
 /* offset (bytes) of a field's first column in the blob, element size, columns per env-field. */
 int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_size, int *n_columns,
                     size_t *column_stride_bytes);
+/* dev_state: ssg_state_nbytes() bytes of device memory, 256-byte aligned.  The blob must start out ZEROED (episode
+ * counters, the config-4 queue counter and rest/arbiter columns are only ever updated, never initialised, by the step
+ * kernels): either hand over zeroed memory, or call ssg_init_state, or let the first full reset after binding do it —
+ * ssg_reset with dev_mask == NULL on a freshly bound blob zeroes it first. */
 int ssg_bind_state(ssg_handle *h, void *dev_state);
+/* Zero the whole bound state blob asynchronously on `stream` (hipMemsetAsync): episode statistics, config-4 columns and
+ * all body state; follow with ssg_reset.  Replaces nothing in the reference (a fresh ShipEnv object starts empty). */
+int ssg_init_state(ssg_handle *h, void *stream);
 /* Replaces: gen_level + PolyEnv (game.py:60-71, models.py:153-196) and the goal list (game.py:77-95).
- * dev_bank: n_maps records of SSG_MAP_STRIDE doubles in device memory. */
+ * dev_bank: n_maps records of SSG_MAP_STRIDE doubles in device memory.  Installing a bank with FEWER maps than the
+ * previous one re-maps every env's record index modulo the new n_maps before the next reset / step (an env keeps
+ * stepping on a record that exists; callers normally reset after a bank change anyway).  Map ids handed to ssg_reset
+ * are likewise taken modulo n_maps: a record index can never point outside the bank. */
 int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps);
 
 /* ---------------------------------------------------------------------------------------------------

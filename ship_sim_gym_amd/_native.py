@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libshipsim.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3
 MAP_STRIDE = 193
 MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 7
@@ -24,6 +24,7 @@ EXPORTS = (
     "ssg_config_set_ship", "ssg_state_nbytes", "ssg_state_field", "ssg_bind_state", "ssg_set_map_bank", "ssg_reset",
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
+    "ssg_init_state",
 )
 
 
@@ -79,6 +80,7 @@ def lib():
     L.ssg_state_nbytes.argtypes = [vp, szp]
     L.ssg_state_field.argtypes = [vp, C.c_int, szp, ip, ip, szp]
     L.ssg_bind_state.argtypes = [vp, vp]
+    L.ssg_init_state.argtypes = [vp, vp]
     L.ssg_set_map_bank.argtypes = [vp, vp, C.c_int]
     L.ssg_reset.argtypes = [vp, vp, vp, vp, vp]
     L.ssg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]

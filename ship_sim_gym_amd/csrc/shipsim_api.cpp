@@ -28,6 +28,8 @@ struct ssg_handle {
     bool lds = false;
     size_t lds_bytes = 0;
     bool prepared = false;
+    bool zeroed = false;       // the bound blob is known to have been zeroed by us (ssg_init_state / first full reset)
+    bool remap_pending = false; // the bank shrank: ICOL_MAP must be taken modulo n_maps before the next kernel reads it
     std::string err;
 };
 
@@ -531,7 +533,18 @@ int ssg_bind_state(ssg_handle *h, void *dev_state)
     if (reinterpret_cast<uintptr_t>(dev_state) % 256 != 0)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_bind_state: state blob must be 256-byte aligned");
     h->state = dev_state;
+    h->zeroed = false;
     refresh_dev(h);
+    return SSG_OK;
+}
+
+int ssg_init_state(ssg_handle *h, void *stream)
+{
+    int rc = check_ready(h, false);
+    if (rc != SSG_OK) return rc;
+    hipError_t e = hipMemsetAsync(h->state, 0, h->nbytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_init_state: ") + hipGetErrorString(e));
+    h->zeroed = true;
     return SSG_OK;
 }
 
@@ -546,6 +559,7 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     if (!(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL))
         while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) > 160u * 1024u) h->block /= 2;
     if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64; // the config-4 step kernel is built for 64 and 256
+    if (h->bank && n_maps < h->n_maps) h->remap_pending = true; // stale record indices >= n_maps must not survive
     h->bank = dev_bank;
     h->n_maps = n_maps;
     h->dyn.bank_epoch++; // resting traffic must be re-collided against the new banks
@@ -558,9 +572,24 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     return SSG_OK;
 }
 
+static int flush_remap(ssg_handle *h, void *stream)
+{
+    if (!h->remap_pending) return SSG_OK;
+    hipError_t e = ssg::launch_remap_map_ids(h->dev, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("map id remap launch: ") + hipGetErrorString(e));
+    h->remap_pending = false;
+    return SSG_OK;
+}
+
 int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids, double *dev_obs, void *stream)
 {
     int rc = check_ready(h, true);
+    if (rc != SSG_OK) return rc;
+    if (!dev_mask && !h->zeroed) { // first full reset on a freshly bound blob: start from zeroed counters / columns
+        rc = ssg_init_state(h, stream);
+        if (rc != SSG_OK) return rc;
+    }
+    rc = flush_remap(h, stream);
     if (rc != SSG_OK) return rc;
     hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
     if (e == hipSuccess && h->cfg.n_ships > 1) // add_default_traffic + fresh goal bodies for the reset envs
@@ -597,6 +626,8 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         return fail(h, SSG_ERR_BAD_ARG, "ssg_step/ssg_rollout: NULL buffer or K < 1");
     rc = prepare(h);
     if (rc != SSG_OK) return rc;
+    rc = flush_remap(h, stream);
+    if (rc != SSG_OK) return rc;
     // One launch runs up to kFuse consecutive steps (state in registers, bank staged once): 100 by default, which
     // keeps a launch near a millisecond and amortises the fixed launch cost to < 1 %.  SSG_FUSE=1 in the environment
     // forces one launch per step (the path a policy-in-the-loop caller gets through ssg_step).
@@ -620,7 +651,11 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
                                             shift ? h->dev.obs2 : dev_obs, dev_reward, dev_done, dev_flags,
                                             static_cast<hipStream_t>(stream));
             if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, dev_done, dev_obs, static_cast<hipStream_t>(stream));
-            if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+            if (e != hipSuccess) {
+                // the step kernel is what empties the dyn queue counter: do not leave it set for the next call
+                if (dyn) (void)hipMemsetAsync(h->dev.dyn_count, 0, sizeof(unsigned), static_cast<hipStream_t>(stream));
+                return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+            }
         }
         return SSG_OK;
     }

@@ -636,7 +636,10 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
     __syncthreads();
     if (threadIdx.x == 0) wg_base = wg_cnt ? atomicAdd(c.dyn_count, wg_cnt) : 0u;
     __syncthreads();
-    if (need_full) c.dyn_queue[wg_base + wave_base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    if (need_full) {
+        const unsigned slot = wg_base + wave_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < (unsigned)c.n_pad) c.dyn_queue[slot] = e; // (only an uninitialised counter could point past the queue)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
     const int lane = threadIdx.x;
-    const unsigned n_queued = *c.dyn_count;
+    // (clamped: a counter that was never initialised must not index past the queue; include/shipsim.h ssg_bind_state)
+    const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_envs);
     if ((unsigned)blockIdx.x * (unsigned)kGrp >= n_queued) return; // wave-uniform: nothing queued for this workgroup
     const bool queued = (lane < kGrp) & ((unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane < n_queued);
     const int e = queued ? c.dyn_queue[blockIdx.x * kGrp + lane] : 0;

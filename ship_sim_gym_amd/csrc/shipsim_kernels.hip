@@ -957,7 +957,7 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
     if (mask && !mask[e]) return;
     const size_t np = (size_t)c.n_pad;
     int m;
-    if (map_ids) m = map_ids[e];
+    if (map_ids) m = (int)((unsigned)map_ids[e] % (unsigned)c.n_maps); // a record index never points outside the bank
     else m = (int)((c.env_id_base + (long long)e) % (long long)c.n_maps);
     const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
     c.f64cols[COL_X * np + e] = c.spawn_x;
@@ -981,6 +981,16 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
         orow[4] = rec[SSG_MAP_OFF_SPAWN_GOAL]; orow[5] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
         for (int i = 0; i < c.n_beams; ++i) orow[6 + i] = -1.0;
     }
+}
+
+// After ssg_set_map_bank installed a SMALLER bank: stale record indices are folded into the new range.
+__global__ void remap_map_ids_kernel(const DevCfg c)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.n_envs) return;
+    int32_t *p = c.i32cols + (size_t)ICOL_MAP * (size_t)c.n_pad + e;
+    const unsigned m = (unsigned)*p;
+    if (m >= (unsigned)c.n_maps) *p = (int32_t)(m % (unsigned)c.n_maps);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1156,6 +1166,13 @@ hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map
 {
     const int block = 256, grid = (c.n_envs + block - 1) / block;
     hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(block), 0, stream, c, mask, map_ids, obs);
+    return hipGetLastError();
+}
+
+hipError_t launch_remap_map_ids(const DevCfg &c, hipStream_t stream)
+{
+    const int block = 256, grid = (c.n_envs + block - 1) / block;
+    hipLaunchKernelGGL(remap_map_ids_kernel, dim3(grid), dim3(block), 0, stream, c);
     return hipGetLastError();
 }
 

@@ -301,3 +301,26 @@ def test_config4_shard_equivalence():
     assert torch.equal(tw[:, :256], a.field(N.F_TRAFFIC)) and torch.equal(tw[:, 256:], b.field(N.F_TRAFFIC))
     for v in (whole, a, b):
         v.close()
+
+
+def test_config4_goal_override_moves_the_goal_bodies():
+    """ShipEnv.reset(goals=...) with n_ships=4: the dynamic goal BODIES (not only the map record and the reset
+    observation) must sit on the overridden centres, so the physics and the nearest-goal report agree."""
+    import random
+    from ship_gym.ship_env import ShipEnv
+    random.seed(5); np.random.seed(5)
+    e = ShipEnv(n_ships=4)
+    goals = [[300, 100], [300, 170], [300, 240], [300, 310], [300, 380]]
+    o = e.reset(spawn_point=(295, 30), goals=goals)
+    assert (o[20], o[21]) == (300, 100)
+    assert [(g.x, g.y) for g in e.game.goals] == [tuple(map(float, g)) for g in goals]   # body.position of each goal
+    got = 0
+    for _ in range(14):
+        o, r, d, _ = e.step(0)
+        got += int(r == 1.0)
+        c = e.game.closest_goal()
+        if c is None or d:
+            break
+        assert (c.x, c.y) == (o[20], o[21])
+    assert got >= 2      # the ship sails up x = 295..315 and collects the overridden goals, not the generated ones
+    e.close()

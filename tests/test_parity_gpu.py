@@ -265,7 +265,9 @@ def test_vec_env_protocols(torch_cuda, native):
     obs_l, rew_l, done_l, infos = v.vector_step([0] * 8)        # RLlib VectorEnv
     assert len(obs_l) == 8 and obs_l[0].shape == (32,) and len(v.vector_reset()) == 8
     o1 = v.reset_at(3)
-    assert o1.shape == (32,) and np.all(o1[:16] == -1) and o1[16] == 300 and v.get_unwrapped() == []
+    assert o1.shape == (32,) and np.all(o1[:16] == -1) and o1[16] == 300
+    assert [h.index for h in v.get_unwrapped()] == list(range(8)) and v.get_attr('num_envs', indices=[2]) == [8]
+    assert v.env_method('seed', 11, indices=[0, 1]) == [[11], [11]]
     assert v.seed(7) == [7]
     # auto-reset returns the reset observation: run until some env is done
     seen = False
@@ -281,6 +283,70 @@ def test_vec_env_protocols(torch_cuda, native):
         class E(EnvConfig):
             HISTORY_SIZE = 0
         _vec(4, env_config=E)
+
+
+def test_rllib_flow_terminal_obs_and_single_reset(torch_cuda, native):
+    """RLlib VectorEnv flow (train/rllib/ppo.py:21-24,43): vector_step returns the TERMINAL observation of a done env,
+    reset_at(i) is the single reset.  The trajectory must equal the SB-protocol env's (in-kernel auto-reset) step for
+    step: same rewards / dones, same observations except on done rows, where SB reports the reset observation that
+    RLlib gets from reset_at."""
+    sb = _vec(64, n_maps=8)
+    rl = _vec(64, n_maps=8, rllib=True)
+    assert rl.rllib and not rl.auto_reset
+    o_sb, o_rl = sb.reset(), np.stack(rl.vector_reset())
+    np.testing.assert_array_equal(o_sb, o_rl)
+    acts = sb.random_actions(77, 0, 300).cpu().numpy()
+    n_done = 0
+    for k in range(300):
+        o_sb, r_sb, d_sb, _ = sb.step(acts[k])
+        o_l, r_l, d_l, _ = rl.vector_step(list(acts[k]))
+        o_rl = np.stack(o_l)
+        np.testing.assert_array_equal(np.asarray(r_l), r_sb)
+        np.testing.assert_array_equal(np.asarray(d_l), d_sb)
+        np.testing.assert_array_equal(o_rl[~d_sb], o_sb[~d_sb])
+        for i in np.nonzero(d_sb)[0]:
+            n_done += 1
+            assert not np.all(o_rl[i][:16] == -1)                 # terminal observation: a real previous frame
+            np.testing.assert_array_equal(rl.reset_at(int(i)), o_sb[i])   # the one reset == SB's auto-reset observation
+    assert n_done > 30
+    np.testing.assert_array_equal(sb.field(native.F_MAP_ID).cpu().numpy(), rl.field(native.F_MAP_ID).cpu().numpy())
+    sb.close(); rl.close()
+
+
+def test_from_env_fns_and_step_after_done(torch_cuda, native):
+    """`SubprocVecEnv([make_env() for i in range(n)])` (train/stable_baselines/ppo.py:54-76,122-123) -> one batched env;
+    the ShipEnv facade refuses to step a finished episode."""
+    from ship_gym.config import EnvConfig, GameConfig
+    from ship_gym.ship_env import ShipEnv
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+
+    class GC(GameConfig):
+        SPEED = 30
+        BOUNDS = (1000, 1000)
+
+    def make_env():
+        def _init():
+            return ShipEnv(GC, EnvConfig)
+        return _init
+
+    v = ShipVecEnv.from_env_fns([make_env() for _ in range(12)], n_maps=4)
+    assert v.num_envs == 12 and v.bounds == (1000, 1000) and v.cfg.dt == 30 * 0.1 and v.game_config is GC
+    o = v.reset()
+    assert o.shape == (12, 32) and np.all(o[:, 16] == 500)
+    v.close()
+    e = ShipEnv(GC, EnvConfig)
+    e.reset()
+    done = False
+    for _ in range(1000):
+        _, _, done, _ = e.step(0)
+        if done:
+            break
+    assert done
+    with pytest.raises(native.ShipSimError):
+        e.step(0)
+    e.reset()
+    e.step(0)
+    e.close()
 
 
 def test_curriculum_maps_switch_banks(torch_cuda, oracle, native):
@@ -467,3 +533,37 @@ def test_rgb_array_frames():
     half = vec.get_screen(3, width=300, height=300).cpu().numpy()
     assert tuple(half[150, 300 - 13]) == (255, 255, 0)
     vec.close()
+
+
+@pytest.mark.parametrize("n_ships", [1, 4])
+def test_abi_garbage_blob_and_shrinking_bank(torch_cuda, native, n_ships):
+    """A C caller may bind device memory that was never zeroed: the first full ssg_reset after ssg_bind_state must
+    start from clean counters / config-4 columns.  Record indices can never leave the bank: ids given to ssg_reset
+    are folded modulo n_maps, and installing a smaller bank folds the ids already stored."""
+    import ctypes as C
+    torch = torch_cuda
+    n = 700
+    ref = _vec(n, n_maps=8, n_ships=n_ships)
+    dirty = _vec(n, n_maps=8, n_ships=n_ships)
+    dirty.state.fill_(0xAB)                                             # garbage everywhere, incl. dyn_count
+    native.check(native.lib().ssg_bind_state(dirty._h, C.c_void_p(dirty.state.data_ptr())), dirty._h, "rebind")
+    ref.reset_tensor(); dirty.reset_tensor()
+    acts = ref.random_actions(31, 0, 120)
+    for k in range(120):
+        a = [t.clone() for t in ref.step_tensor(acts[k])]
+        b = dirty.step_tensor(acts[k])
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert ref.stats() == dirty.stats() and ref.stats()["episodes"] > 0
+    # ids beyond the bank at reset time are folded, not used as they are
+    ids = torch.full((n,), 8 + 3, dtype=torch.int32, device=ref.device)
+    ref.reset_tensor(map_ids=ids)
+    assert torch.all(ref.field(native.F_MAP_ID) == 3)
+    # shrink the bank from 8 to 3 maps without resetting: stored ids must be folded before the next step reads them
+    dirty.reset_tensor(map_ids=torch.arange(n, dtype=torch.int32, device=ref.device) % 8)
+    small = dirty.bank[:3].clone()
+    dirty.set_bank(small)
+    dirty.step_tensor(acts[0])
+    torch.cuda.synchronize()
+    assert int(dirty.field(native.F_MAP_ID).max()) < 3
+    ref.close(); dirty.close()

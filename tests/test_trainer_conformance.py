@@ -1,0 +1,165 @@
+"""Trainer base-class conformance without the trainers: minimal stand-ins for `stable_baselines.common.vec_env.VecEnv`
+(an ABC with the abstract methods of SB 2.x) and `ray.rllib.env.vector_env.VectorEnv` are put into sys.modules, the
+package is re-imported, and ShipVecEnv must (a) subclass both, so PPO2's / RLlib's isinstance gates accept it
+(train/stable_baselines/ppo.py:88,122-123; train/rllib/ppo.py:21-24,43), and (b) leave no abstract method undefined.
+No GPU: nothing is instantiated against a device; the host-side logic (vectorised action check, env handles, the
+rllib reset bookkeeping) is exercised on an object whose device calls are stubbed."""
+import abc
+import importlib
+import sys
+import types
+
+import numpy as np
+import pytest
+
+
+def _fake_trainer_modules():
+    class VecEnv(abc.ABC):  # the abstract surface of stable-baselines 2.x VecEnv
+        def __init__(self, num_envs, observation_space, action_space):
+            self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+            self.sb_init_called = True
+
+        @abc.abstractmethod
+        def reset(self): ...
+        @abc.abstractmethod
+        def step_async(self, actions): ...
+        @abc.abstractmethod
+        def step_wait(self): ...
+        @abc.abstractmethod
+        def close(self): ...
+        @abc.abstractmethod
+        def get_attr(self, attr_name, indices=None): ...
+        @abc.abstractmethod
+        def set_attr(self, attr_name, value, indices=None): ...
+        @abc.abstractmethod
+        def env_method(self, method_name, *method_args, indices=None, **method_kwargs): ...
+
+        def step(self, actions):
+            self.step_async(actions)
+            return self.step_wait()
+
+    class VectorEnv(object):  # ray 0.6 VectorEnv: plain methods raising NotImplementedError
+        def vector_reset(self): raise NotImplementedError
+        def reset_at(self, index): raise NotImplementedError
+        def vector_step(self, actions): raise NotImplementedError
+        def get_unwrapped(self): raise NotImplementedError
+
+    mods = {}
+    for name in ("stable_baselines", "stable_baselines.common", "stable_baselines.common.vec_env", "ray", "ray.rllib",
+                 "ray.rllib.env", "ray.rllib.env.vector_env"):
+        mods[name] = types.ModuleType(name)
+        mods[name].__path__ = []
+    mods["stable_baselines.common.vec_env"].VecEnv = VecEnv
+    mods["ray.rllib.env.vector_env"].VectorEnv = VectorEnv
+    return mods, VecEnv, VectorEnv
+
+
+@pytest.fixture
+def vec_env_with_fake_trainers():
+    mods, VecEnv, VectorEnv = _fake_trainer_modules()
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    import ship_sim_gym_amd.vec_env as ve
+    ve = importlib.reload(ve)
+    try:
+        yield ve, VecEnv, VectorEnv
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        importlib.reload(ve)
+
+
+def test_subclasses_trainer_bases_and_defines_every_abstract_method(vec_env_with_fake_trainers):
+    ve, VecEnv, VectorEnv = vec_env_with_fake_trainers
+    assert issubclass(ve.ShipVecEnv, VecEnv) and issubclass(ve.ShipVecEnv, VectorEnv)
+    assert not getattr(ve.ShipVecEnv, "__abstractmethods__", frozenset()), ve.ShipVecEnv.__abstractmethods__
+    for name in ("vector_reset", "reset_at", "vector_step", "get_unwrapped"):  # overridden, not inherited stubs
+        assert getattr(ve.ShipVecEnv, name) is not getattr(VectorEnv, name)
+    for name in ("reset", "step_async", "step_wait", "step", "close", "get_attr", "set_attr", "env_method", "seed",
+                 "render", "get_images", "env_is_wrapped"):
+        assert callable(getattr(ve.ShipVecEnv, name))
+
+
+def test_without_trainers_base_is_object():
+    import ship_sim_gym_amd.vec_env as ve
+    if "stable_baselines" not in sys.modules and "ray" not in sys.modules:
+        assert ve._BASES == (object,)
+
+
+class _Stub(object):
+    """Host-side behaviour of ShipVecEnv with the device calls replaced (no GPU in the CPU suite)."""
+
+    @staticmethod
+    def make(ve, n=6, rllib=False):
+        from ship_sim_gym_amd import spaces
+        v = object.__new__(ve.ShipVecEnv)
+        v.num_envs, v.rllib, v.auto_reset, v.map_mode = n, rllib, not rllib, "bank"
+        v.action_space = spaces.Discrete(3)
+        v.states_history = 4
+        v._handles, v._pending = {}, None
+        v._await_reset = np.zeros(n, dtype=bool)
+        v._reset_obs_h = None
+        v._closed, v._h = True, None
+        v.calls = []
+        return v
+
+
+def test_action_check_is_vectorised_and_strict():
+    import ship_sim_gym_amd.vec_env as ve
+    v = _Stub.make(ve)
+    v.step_async(np.array([0, 1, 2, 0, 1, 2]))
+    assert v._pending.dtype == np.int32 and v._pending.tolist() == [0, 1, 2, 0, 1, 2]
+    v.step_async([2] * 6)
+    for bad in (np.full(6, 3), np.array([0, 0, 0, 0, 0, -1]), np.zeros(5, dtype=np.int64), np.zeros(6)):
+        with pytest.raises(AssertionError):
+            v.step_async(bad)  # ship_env.py:143: Discrete(3).contains
+    src = open(ve.__file__).read()
+    body = src.split("def step_async", 1)[1].split("def step_wait", 1)[0]
+    assert "\n        for " not in body, "step_async must not loop over envs in Python"
+
+
+def test_env_handles_get_set_attr_env_method():
+    import ship_sim_gym_amd.vec_env as ve
+    v = _Stub.make(ve)
+    v.reward_range = (-1, 1)
+    assert v.get_attr("reward_range") == [(-1, 1)] * 6
+    assert v.get_attr("num_envs", indices=[1, 3]) == [6, 6]
+    v.set_attr("tag", "a")
+    v.set_attr("tag", "b", indices=2)
+    assert v.get_attr("tag") == ["a", "a", "b", "a", "a", "a"]
+    assert [h.index for h in v.get_unwrapped()] == list(range(6)) and v.get_unwrapped()[2] is v.env(2)
+    v.reset_at = lambda i: ("reset", i)
+    assert v.env_method("reset", indices=[4, 5]) == [("reset", 4), ("reset", 5)]
+    assert v.env_method("seed", 7, indices=0) == [[7]]
+    with pytest.raises(IndexError):
+        v.env(6)
+
+
+def test_rllib_flow_returns_terminal_obs_and_resets_once():
+    """vector_step in rllib mode: terminal observation out, ONE masked reset for all done envs, reset_at(i) hands out the
+    cached reset observation without a second reset, and stepping before reset_at raises."""
+    import ship_sim_gym_amd.vec_env as ve
+    from ship_sim_gym_amd import _native as N
+    v = _Stub.make(ve, rllib=True)
+    term = np.arange(24, dtype=np.float64).reshape(6, 4)
+    done = np.array([0, 1, 0, 0, 1, 0], dtype=bool)
+    v.step = lambda a: (term.copy(), np.zeros(6), done.copy(), [{}] * 6)
+    resets = []
+
+    def fake_reset_done(d):
+        resets.append(d.copy())
+        v._reset_obs_h = -np.ones((6, 4))
+        v._await_reset |= d
+    v._reset_done_envs = fake_reset_done
+    obs, rew, dn, infos = v.vector_step([0] * 6)
+    assert np.array_equal(np.stack(obs), term) and list(dn) == list(done) and len(resets) == 1
+    with pytest.raises(N.ShipSimError):
+        v.vector_step([0] * 6)  # envs 1 and 4 still await their reset_at
+    assert np.all(v.reset_at(1) == -1) and np.all(v.reset_at(4) == -1) and len(resets) == 1
+    assert not v._await_reset.any()
+    done[:] = False
+    v.vector_step([0] * 6)
+    assert len(resets) == 1
