@@ -42,7 +42,11 @@ class Config(C.Structure):
                 ("ship_w", C.c_double), ("ship_h", C.c_double), ("ship_mass", C.c_double), ("force_y", C.c_double),
                 ("rudder_step", C.c_int), ("rudder_max", C.c_int),
                 ("thrust_px0", C.c_double), ("thrust_py0", C.c_double),
-                ("spawn_x", C.c_double), ("spawn_y", C.c_double), ("n_traffic", C.c_int)]
+                ("spawn_x", C.c_double), ("spawn_y", C.c_double), ("n_traffic", C.c_int), ("variant", C.c_int)]
+
+
+# ORA_VAR_* (ssg_oracle.h): one switch per named, unverifiable assumption
+VAR_TOUCH_STRICT, VAR_ORDER_REVERSED, VAR_SWAP_AB, VAR_GJK_WARM, VAR_CHECK_SAT, VAR_PLAYER_CPCOLLIDE = 1, 2, 4, 8, 16, 32
 
 
 class Bank(C.Structure):
@@ -109,6 +113,7 @@ def lib():
         L.ora_rollout.argtypes = [C.c_void_p, C.c_int, C.POINTER(Bank), C.c_uint64, C.c_int64, C.c_int, C.c_int, dp, dp,
                                   C.POINTER(C.c_uint8)]
         L.ora_max_threads.restype = C.c_int
+        L.ora_batch_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -271,6 +276,13 @@ class Batch:
     def poke_traffic(self, i, k, x, y, angle=0.0, vx=0.0, vy=0.0, w=0.0):
         lib().ora_world_poke_traffic(lib().ora_world_at(self._p, int(i)), int(k),
                                      _dp(np.array([x, y, angle, vx, vy, w], dtype=np.float64)))
+
+    def counters(self):
+        """ORA_VAR_CHECK_SAT census summed over the batch: player pairs checked, SAT != cpCollide(player, other),
+        SAT != cpCollide(other, player), pairs with |signed distance| < 1e-9."""
+        out = (C.c_int64 * 4)()
+        lib().ora_batch_counters(self._p, self.n, out)
+        return dict(zip(("checked", "disagree_ab", "disagree_ba", "near_zero"), [int(v) for v in out]))
 
     def peek_all(self):
         out = np.empty((self.n, PEEK_LEN))

@@ -184,15 +184,32 @@ static closest_pts epa(const shape_ref *s1, const shape_ref *s2, mink_pt v0, min
     }
 }
 
-static closest_pts gjk(const shape_ref *s1, const shape_ref *s2)
+static support_pt shape_point(const shape_ref *s, uint32_t i) /* ShapePoint: vertex i of a poly, the centre of a circle */
 {
-    /* GJK-ID: cold start from the axis perpendicular to the line between the bounding-box centres */
-    ora_v2 axis = vperp(vsub(bb_center(s1), bb_center(s2)));
-    mink_pt v0 = support(s1, s2, axis);
-    mink_pt v1 = support(s1, s2, vneg(axis));
+    support_pt r;
+    if (s->is_circle) { r.p = s->tc; r.index = 0; }
+    else { uint32_t k = i < (uint32_t)s->poly->count ? i : 0u; r.p = s->poly->wv[k]; r.index = k; }
+    return r;
+}
+
+static closest_pts gjk(const shape_ref *s1, const shape_ref *s2, uint32_t *id)
+{
+    /* GJK-ID: cold start from the axis perpendicular to the line between the bounding-box centres, unless the
+     * ORA_VAR_GJK_WARM variant hands in the pair's cached collision id (cpCollide's `id` argument): then the
+     * search restarts from the two Minkowski vertices the previous query ended on. */
+    mink_pt v0, v1;
+    if (id && *id) {
+        v0 = mink_new(shape_point(s1, (*id >> 24) & 0xFF), shape_point(s2, (*id >> 16) & 0xFF));
+        v1 = mink_new(shape_point(s1, (*id >> 8) & 0xFF), shape_point(s2, (*id) & 0xFF));
+    } else {
+        ora_v2 axis = vperp(vsub(bb_center(s1), bb_center(s2)));
+        v0 = support(s1, s2, axis);
+        v1 = support(s1, s2, vneg(axis));
+    }
+    closest_pts out;
     int iteration = 1;
     for (;;) {
-        if (iteration > MAX_GJK_ITERATIONS) return closest_new(v0, v1);
+        if (iteration > MAX_GJK_ITERATIONS) { out = closest_new(v0, v1); break; }
         ora_v2 delta = vsub(v1.ab, v0.ab);
         if (vcross(delta, vadd(v0.ab, v1.ab)) > 0.0) {
             mink_pt tmp = v0; v0 = v1; v1 = tmp; /* origin is behind the axis: flip, same iteration */
@@ -202,11 +219,13 @@ static closest_pts gjk(const shape_ref *s1, const shape_ref *s2)
         ora_v2 n = (-1.0 < t && t < 1.0) ? vperp(delta) : vneg(lerp_t(v0.ab, v1.ab, t));
         mink_pt p = support(s1, s2, n);
         if (vcross(vsub(v1.ab, p.ab), vadd(v1.ab, p.ab)) > 0.0 && vcross(vsub(v0.ab, p.ab), vadd(v0.ab, p.ab)) < 0.0)
-            return epa(s1, s2, v0, p, v1); /* the triangle v0, p, v1 contains the origin */
-        if (vdot(p.ab, n) <= cfmax(vdot(v0.ab, n), vdot(v1.ab, n))) return closest_new(v0, v1);
+            { out = epa(s1, s2, v0, p, v1); break; } /* the triangle v0, p, v1 contains the origin */
+        if (vdot(p.ab, n) <= cfmax(vdot(v0.ab, n), vdot(v1.ab, n))) { out = closest_new(v0, v1); break; }
         if (closest_dist(v0.ab, p.ab) < closest_dist(p.ab, v1.ab)) v1 = p; else v0 = p;
         iteration++;
     }
+    if (id) *id = out.id;
+    return out;
 }
 
 /* CP_HASH_PAIR mixes pointer-sized ids with a multiplicative constant; only equality of hashes is ever used
@@ -270,17 +289,17 @@ static void contact_points(edge_t e1, edge_t e2, closest_pts points, collision_i
     }
 }
 
-static void poly_to_poly(const shape_ref *a, const shape_ref *b, collision_info *info)
+static void poly_to_poly(const shape_ref *a, const shape_ref *b, collision_info *info, uint32_t *id)
 {
-    closest_pts points = gjk(a, b);
+    closest_pts points = gjk(a, b, id);
     info->d = points.d;
     if (points.d - 0.0 - 0.0 <= 0.0)
         contact_points(support_edge(a, points.n), support_edge(b, vneg(points.n)), points, info);
 }
 
-static void circle_to_poly(const shape_ref *c, const shape_ref *p, collision_info *info)
+static void circle_to_poly(const shape_ref *c, const shape_ref *p, collision_info *info, uint32_t *id)
 {
-    closest_pts points = gjk(c, p);
+    closest_pts points = gjk(c, p, id);
     double mindist = c->r + 0.0;
     info->d = points.d;
     if (points.d <= mindist) {
@@ -314,7 +333,7 @@ int ora_collide_poly_poly(const ora_poly *a, const ora_poly *b, int slot_a, int 
     shape_ref ra = ref_poly(a, (uint32_t)slot_a), rb = ref_poly(b, (uint32_t)slot_b);
     collision_info info;
     memset(&info, 0, sizeof(info));
-    poly_to_poly(&ra, &rb, &info);
+    poly_to_poly(&ra, &rb, &info, NULL);
     *n = info.n; *dist = info.d;
     for (int i = 0; i < info.count; i++) { p1[i] = info.p1[i]; p2[i] = info.p2[i]; hash[i] = info.hash[i]; }
     return info.count;
@@ -325,7 +344,7 @@ int ora_collide_circle_poly(ora_v2 c, double r, const ora_poly *b, ora_v2 *n, or
     shape_ref rc = ref_circle(c, r, 0), rb = ref_poly(b, 1);
     collision_info info;
     memset(&info, 0, sizeof(info));
-    circle_to_poly(&rc, &rb, &info);
+    circle_to_poly(&rc, &rb, &info, NULL);
     *n = info.n; *dist = info.d;
     if (info.count) { p1[0] = info.p1[0]; p2[0] = info.p2[0]; }
     return info.count;
@@ -535,13 +554,24 @@ static ora_arbiter *arb_at(ora_world *w, int s1, int s2)
  * solver list.  (Default handler: begin/preSolve return true.) */
 static int collide_pair(ora_world *w, int a, int b)
 {
+    const int var = w->cfg.variant;
     shape_ref sa = slot_shape(w, a), sb = slot_shape(w, b);
-    if (!bb_intersects(&sa, &sb)) return 0; /* queryReject */
+    uint32_t *id = NULL;
+    if (var & ORA_VAR_GJK_WARM) id = a < b ? &w->dyn.pair_id[a][b] : &w->dyn.pair_id[b][a];
+    if (!bb_intersects(&sa, &sb)) { /* queryReject; the broadphase pair (and its cached id) goes when the boxes part */
+        if (id) *id = 0;
+        return 0;
+    }
+    if ((var & ORA_VAR_SWAP_AB) && !sa.is_circle && !sb.is_circle) { /* ORDER variant: the other poly is "a" */
+        shape_ref ts = sa; sa = sb; sb = ts;
+        int ti = a; a = b; b = ti;
+        if (id) *id = 0; /* (an id is only meaningful for one a/b order; the variant is run cold) */
+    }
     collision_info info;
     memset(&info, 0, sizeof(info));
     if (sa.is_circle && sb.is_circle) circle_to_circle(&sa, &sb, &info);
-    else if (sa.is_circle) circle_to_poly(&sa, &sb, &info);
-    else poly_to_poly(&sa, &sb, &info);
+    else if (sa.is_circle) circle_to_poly(&sa, &sb, &info, id);
+    else poly_to_poly(&sa, &sb, &info, id);
     if (info.count == 0) return 0;
     ora_arbiter *arb = arb_at(w, a, b);
     if (arb->state == ORA_ARB_NONE) { /* cpArbiterInit */
@@ -629,6 +659,8 @@ void ora_dyn_collide_solve(ora_world *w, int reached_mask)
     for (int k = 0; k < nt; k++) update_velocity(&d->tbody[k], damping, dt);
     /* (5) cached impulses + solver */
     const double dt_coef = (d->prev_dt == 0.0 ? 0.0 : dt / d->prev_dt);
+    if (c->variant & ORA_VAR_ORDER_REVERSED) /* ORDER variant: the broadphase reported the pairs the other way round */
+        for (int i = 0; i < n_list / 2; i++) { ora_arbiter *t = list[i]; list[i] = list[n_list - 1 - i]; list[n_list - 1 - i] = t; }
     for (int i = 0; i < n_list; i++) arbiter_apply_cached(w, list[i], dt_coef);
     for (int it = 0; it < SOLVER_ITERATIONS; it++)
         for (int i = 0; i < n_list; i++) arbiter_apply_impulse(w, list[i]);

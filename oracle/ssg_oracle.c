@@ -258,7 +258,10 @@ static inline int bb_intersects(double al, double ab, double ar, double at, doub
     return (al <= br && bl <= ar && ab <= bt && bb <= at);
 }
 
-int ora_polys_collide(const ora_poly *a, const ora_poly *b)
+int ora_polys_collide(const ora_poly *a, const ora_poly *b) { return ora_polys_collide_v(a, b, 0); }
+int ora_circle_poly_collide(ora_v2 c, double r, const ora_poly *poly) { return ora_circle_poly_collide_v(c, r, poly, 0); }
+
+int ora_polys_collide_v(const ora_poly *a, const ora_poly *b, int strict)
 {
     if (!bb_intersects(a->bb_l, a->bb_b, a->bb_r, a->bb_t, b->bb_l, b->bb_b, b->bb_r, b->bb_t)) return 0;
     for (int pass = 0; pass < 2; pass++) {
@@ -268,16 +271,52 @@ int ora_polys_collide(const ora_poly *a, const ora_poly *b)
             double off = vdot(n, p->wv[i]);
             double mn = INFINITY;
             for (int j = 0; j < q->count; j++) mn = fmin(mn, vdot(n, q->wv[j]));
-            if (mn > off) return 0; /* separating axis */
+            if (strict ? (mn >= off) : (mn > off)) return 0; /* separating axis (strict: touching separates too) */
         }
     }
     return 1;
 }
 
-int ora_circle_poly_collide(ora_v2 c, double r, const ora_poly *poly)
+int ora_circle_poly_collide_v(ora_v2 c, double r, const ora_poly *poly, int strict)
 {
     if (!bb_intersects(c.x - r, c.y - r, c.x + r, c.y + r, poly->bb_l, poly->bb_b, poly->bb_r, poly->bb_t)) return 0;
-    return ora_poly_point_query(poly, c, NULL) <= r;
+    const double d = ora_poly_point_query(poly, c, NULL);
+    return strict ? (d < r) : (d <= r);
+}
+
+/* cpCollide restated (ssg_dynamics.c) */
+int ora_collide_poly_poly(const ora_poly *a, const ora_poly *b, int slot_a, int slot_b, ora_v2 *n, ora_v2 *p1, ora_v2 *p2,
+                          uint32_t *hash, double *dist);
+
+/* collide_ship's predicate for one player pair under the variant switches (+ the SAT / cpCollide agreement census) */
+static int player_pair_collides(ora_world *w, const ora_poly *other, int other_slot)
+{
+    const int var = w->cfg.variant;
+    const ora_poly *pl = &w->ship_shape;
+    const int sat = ora_polys_collide_v(pl, other, var & ORA_VAR_TOUCH_STRICT);
+    if (!(var & (ORA_VAR_CHECK_SAT | ORA_VAR_PLAYER_CPCOLLIDE))) return sat;
+    if (!bb_intersects(pl->bb_l, pl->bb_b, pl->bb_r, pl->bb_t, other->bb_l, other->bb_b, other->bb_r, other->bb_t))
+        return 0; /* queryReject: Chipmunk never runs cpCollide */
+    ora_v2 n, p1[2], p2[2];
+    uint32_t hash[2];
+    double d_ab = 0.0, d_ba = 0.0;
+    /* begin() fires when cpCollide pushes >= 1 contact; both a/b orders are evaluated (ORDER is unknown) */
+    const int c_ab = ora_collide_poly_poly(pl, other, 7, other_slot, &n, p1, p2, hash, &d_ab) > 0;
+    const int c_ba = ora_collide_poly_poly(other, pl, other_slot, 7, &n, p1, p2, hash, &d_ba) > 0;
+    w->sat_checked++;
+    if (c_ab != sat) w->sat_disagree_ab++;
+    if (c_ba != sat) w->sat_disagree_ba++;
+    if (fabs(d_ab) < 1e-9 || fabs(d_ba) < 1e-9) w->sat_near_zero++;
+    return (var & ORA_VAR_PLAYER_CPCOLLIDE) ? c_ab : sat;
+}
+
+void ora_batch_counters(const ora_world *ws, int n, int64_t *out4)
+{
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (int i = 0; i < n; i++) {
+        out4[0] += ws[i].sat_checked; out4[1] += ws[i].sat_disagree_ab;
+        out4[2] += ws[i].sat_disagree_ba; out4[3] += ws[i].sat_near_zero;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -438,11 +477,11 @@ static void space_step(ora_world *w)
     /* (2) cpShapeUpdateFunc + collide */
     ora_poly_update(&w->ship_shape, b->p, b->rot);
     for (int k = 0; k < 2; k++)
-        if (ora_polys_collide(&w->ship_shape, &w->bank[k])) w->colliding = 1; /* collide_ship game.py:232-241 */
+        if (player_pair_collides(w, &w->bank[k], k)) w->colliding = 1; /* collide_ship game.py:232-241 */
     for (int k = 0; dyn && k < c->n_traffic; k++) /* traffic ships are collision_type 1 too (models.py:100) */
-        if (ora_polys_collide(&w->ship_shape, &w->dyn.tshape[k])) w->colliding = 1;
+        if (player_pair_collides(w, &w->dyn.tshape[k], ORA_SLOT_TRAFFIC0 + k)) w->colliding = 1;
     for (int g = 0; g < w->n_goals_alive;) {
-        if (ora_circle_poly_collide(w->goal_p[g], c->goal_radius, &w->ship_shape)) {
+        if (ora_circle_poly_collide_v(w->goal_p[g], c->goal_radius, &w->ship_shape, c->variant & ORA_VAR_TOUCH_STRICT)) {
             /* collide_goal game.py:243-257: goal dropped from the list, no physical response */
             w->goal_reached = 1;
             reached_mask |= 1 << w->goal_id[g];

@@ -70,7 +70,17 @@ typedef struct {
     double thrust_px0, thrust_py0; /* shape.bb.center() before space.add = (0,0)  models.py:109, App. A.3 */
     double spawn_x, spawn_y;  /* (BOUNDS[0]/2, 25)                   game.py:274   */
     int n_traffic;            /* 0, or 3 = add_default_traffic() after every reset   game.py:279-286 (config 4) */
+    int variant;              /* ORA_VAR_* bits: 0 = the named assumptions as documented; test-only switches that flip one
+                                 assumption each, for the sensitivity table (tools/assumption_sensitivity.py) */
 } ora_config;
+
+/* Switches for the named, unverifiable assumptions (pymunk is absent).  Each flips ONE of them. */
+#define ORA_VAR_TOUCH_STRICT      0x01 /* touching does NOT count: a zero-width gap separates (SAT `>=`, circle `<`) */
+#define ORA_VAR_ORDER_REVERSED    0x02 /* ORDER: the solver walks the arbiter list in the reverse of the canonical order */
+#define ORA_VAR_SWAP_AB           0x04 /* ORDER: poly-poly pairs are collided with a/b exchanged (which poly is "a") */
+#define ORA_VAR_GJK_WARM          0x08 /* GJK-ID: GJK restarts from the pair's cached collision id while the AABBs overlap */
+#define ORA_VAR_CHECK_SAT         0x10 /* count player pairs on which the SAT predicate and cpCollide's contact count differ */
+#define ORA_VAR_PLAYER_CPCOLLIDE  0x20 /* the player's `colliding` comes from cpCollide's contact count, not from SAT */
 
 /* ---- config 4 (BASELINE configs[3]): traffic ships, dynamic goal bodies, Chipmunk contact solver ----
  * Shape slots in space-insertion order: 0,1 banks (static) | 2..6 goal circles | 7 player | 8..10 traffic.   */
@@ -108,6 +118,7 @@ typedef struct {
     int last_arbiters;                  /* solver list length of the last step (inspection) */
     ora_body static_body;               /* the banks' body: all zero (cpBodyNewStatic at the origin) */
     ora_arbiter arb[ORA_N_SLOTS][ORA_N_SLOTS]; /* cachedArbiters keyed by (lower slot, higher slot) */
+    uint32_t pair_id[ORA_N_SLOTS][ORA_N_SLOTS]; /* ORA_VAR_GJK_WARM only: cpCollisionID of the broadphase pair */
 } ora_dyn;
 
 typedef struct {
@@ -131,6 +142,9 @@ typedef struct {
     int map_id;
     int64_t episodes;
     ora_dyn dyn;                       /* used only when cfg.n_traffic > 0 */
+    /* ORA_VAR_CHECK_SAT: player pairs that passed the AABB test; disagreements SAT vs cpCollide(player, other) and
+     * vs cpCollide(other, player); pairs where cpCollide's signed distance was within 1e-9 of zero */
+    int64_t sat_checked, sat_disagree_ab, sat_disagree_ba, sat_near_zero;
 } ora_world;
 
 /* ---- geometry primitives (Chipmunk restated) ---- */
@@ -142,6 +156,9 @@ double ora_poly_point_query(const ora_poly *poly, ora_v2 p, ora_v2 *closest);
 int ora_poly_segment_query(const ora_poly *poly, ora_v2 a, ora_v2 b, double radius, ora_seg_info *info);
 int ora_polys_collide(const ora_poly *a, const ora_poly *b);
 int ora_circle_poly_collide(ora_v2 c, double r, const ora_poly *poly);
+int ora_polys_collide_v(const ora_poly *a, const ora_poly *b, int strict);           /* strict: ORA_VAR_TOUCH_STRICT */
+int ora_circle_poly_collide_v(ora_v2 c, double r, const ora_poly *poly, int strict);
+void ora_batch_counters(const ora_world *ws, int n, int64_t *out4); /* sums of the four sat_* counters */
 
 /* ---- world ---- */
 void ora_default_config(ora_config *cfg);

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshipsim.so")
+# SSG_LIB_PATH: development override (tools/build_variant.sh builds diagnostic variants next to the product library)
+LIB_PATH = os.environ.get("SSG_LIB_PATH") or os.path.join(_HERE, "libshipsim.so")
 
 ABI_VERSION = 3
 MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3

@@ -155,25 +155,36 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LDS layout of the step kernel (doubles unless noted), after the optional bank copy:
-//   beamtab  [2][16]      cos/sin(phi_i)
-//   shiptab  [6][8]       per ship vertex i: local vertex, local plane normal, previous vertex
-//   xchg     [3][EPW]     -> role 3: force x, force y, torque (role 0)
-//   gres     [EPW] u32    -> role 3: colliding flag (role 2)
-//   goal scratch per role-3 wave: (lane, goal) pair queue u16[512] + consumed-goal masks u32[64]
-//   scratch  per lidar wave (roles 0,1): res0[NBH][64], res1[NBH][64], queue[2*NBH*64 + 64 trash] u16, NBH = ceil(NB/2)
+// LDS layout of the step kernel (after the optional bank copy); EPW envs = EPW/64 tiles of 64 envs per workgroup:
+//   beamtab  [2][16] f64    cos/sin(phi_i)
+//   shiptab  [6][8]  f64    per ship vertex i: local vertex, local plane normal, previous vertex;
+//                           [0][6], [1][6]: the lidar origin of a ship standing at the spawn pose (a reset env)
+//   pose     [6][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y   (role 3 -> roles 0-2)
+//   posem    [EPW] i32      the env's map id
+//   gres     [EPW] u32      colliding (role 2 -> role 3 and the lidar roles)
+//   gdone    [EPW] u32      role 3's share of is_done: no goals left | out of bounds | max_steps (-> the lidar roles)
+//   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
+//   per tile: res [2 parities][NB][64] u64 lidar result keys (step k's results live in parity k & 1; the parity role 3
+//             has just consumed is its transposition buffer for the observation rows), then one (beam, hull) pair
+//             queue u16[2*NB0*64 + 64 trash] per lidar wave
 // ---------------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ constexpr int lds_wave_scratch_bytes(int nb)
-{
-    return 2 * nb * 64 * 8 + (2 * nb * 64 + 64) * 2;
-}
+__host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
+constexpr int kPoseDoubles = 6;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
-    return kBeamTabBytes + kShipTabBytes + 3 * epw * 8 + epw * 4 + (epw / 64) * kGoalScratchBytes;
+    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 3 * epw * 4 + (epw / 64) * kGoalScratchBytes;
 }
+__host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
+__host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
+__host__ __device__ __forceinline__ constexpr int lds_tile_bytes(int nb)
+{
+    return 2 * lds_res_bytes(nb) + 2 * lds_queue_bytes(nb_lo(nb));
+}
+
+constexpr unsigned long long kLidarMiss = ~0ull; // result key of a beam no hull reported a hit for
 
 // ---------------------------------------------------------------------------------------------------------
 // LiDAR (models.py:39-76), wave-compacted.
@@ -190,15 +201,17 @@ __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 //                  within its length (d >= 0 and d <= den, i.e. 0 <= t <= 1) only the one with the largest t can
 //                  be the entry edge of a convex polygon, so only that plane gets the exact t = d/den, lerp and
 //                  edge-extent test.  Identical results except when a ray passes within rounding of a hull vertex.
-// Results travel back through two per-wave LDS arrays res0/res1[beam][lane] (-1 = no hit), one per hull; the reader
-// then applies "the first shape in list order that reports a hit wins" (models.py:61-72): left bank first.
+// A hit is published as a 64-bit key (hull index << 63 | bits of the distance) with an LDS atomic min into
+// res[beam][lane]: the smallest key is the hit of the FIRST shape in list order that reports one (models.py:61-72:
+// the left bank before the right), whatever order the pairs were processed in; kLidarMiss = no hit.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kPlaneChunk = 4; // hull planes fetched from LDS ahead of their arithmetic, per loop trip
 
 template <bool LDS_BANK, bool EXACT>
-__device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue, double *res0,
-                                           double *res1, const double *beamtab, const double cx, const double cy,
-                                           const double ca, const double sa, const int rec_off, const int lane)
+__device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue,
+                                           unsigned long long *res /* [this role's first beam][64] */, const double *beamtab,
+                                           const double cx, const double cy, const double ca, const double sa,
+                                           const int rec_off, const int lane)
 {
     for (int base = 0; base < n_items; base += 64) {
         const int idx = base + lane;
@@ -273,7 +286,10 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         const double px = outside ? ptx : ex, py = outside ? pty : ey;
         const double dx = px - wcx, dy = py - wcy;
         const double dist = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
-        if (hit) (s ? res1 : res0)[bi * 64 + src] = dist;
+        if (hit) {
+            const unsigned long long key = ((unsigned long long)s << 63) | (unsigned long long)__double_as_longlong(dist);
+            atomicMin(&res[bi * 64 + src], key); // ds_min_u64: hull 0's hit beats hull 1's
+        }
     }
 }
 
@@ -295,8 +311,10 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             for (int k_ = 0; k_ < (n); ++k_) d_[k_] = stamp_[k_];                                 \
         }                                                                                         \
     } while (0)
+#define SSG_STAMP_K(i) do { if (k == K - 2) SSG_STAMP(i); } while (0) /* the second-to-last step of a fused launch */
 #else
 #define SSG_STAMP(k) do { } while (0)
+#define SSG_STAMP_K(i) do { } while (0)
 #define SSG_STAMP_FLUSH(n) do { } while (0)
 #endif
 
@@ -308,34 +326,143 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
 #define SSG_ABL(bit) false
 #endif
 
+// cpPolyShapeCacheData of the ship: world vertices and AABB for the body rotation (ca, sa) at (x, y).  Every role
+// that needs them runs exactly these operations on the same inputs, so all of them hold the same bits.
+__device__ __forceinline__ void ship_world(const double *shiptab, double ca, double sa, double x, double y,
+                                           double (&swx)[SSG_SHIP_VERTS], double (&swy)[SSG_SHIP_VERTS], double &sbl,
+                                           double &sbr, double &sbb, double &sbt)
+{
+    sbl = INFINITY; sbr = -INFINITY; sbb = INFINITY; sbt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+        const double hx = shiptab[0 * 8 + i], hy = shiptab[1 * 8 + i];
+        swx[i] = ca * hx + (-sa) * hy + x;
+        swy[i] = sa * hx + ca * hy + y;
+        sbl = dmin(sbl, swx[i]); sbr = dmax(sbr, swx[i]);
+        sbb = dmin(sbb, swy[i]); sbt = dmax(sbt, swy[i]);
+    }
+}
+
+// One LiDAR.query of a lidar wave for its NB0 beams [b_first, b_first + b_count) of the 64 envs of its tile, from the
+// lidar origin (cx, cy) and body rotation (ca, sa): cull, compact, segment queries; results into res[beam][lane].
+template <int NB, bool LDS_BANK, bool EXACT>
+__device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long *res, unsigned short *queue,
+                                            const double *beamtab, const int b_first, const int b_count, const double cx,
+                                            const double cy, const double ca, const double sa, const int rec_off,
+                                            const bool live, const int lane)
+{
+    constexpr int NB0 = nb_lo(NB);
+    constexpr int kTrash = 2 * NB0 * 64; // 64 u16 past the queue swallow the writes of culled pairs
+    int n_items = 0;
+    // hull AABBs widened by eps: culling must never drop a pair the reference would hit
+    const double eps = 1e-6;
+    double al[2], ab[2], ar[2], at[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        al[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0) - eps;
+        ab[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1) - eps;
+        ar[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2) + eps;
+        at[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3) + eps;
+    }
+#pragma unroll
+    for (int k = 0; k < NB0; ++k) {
+        if (k < b_count) { // wave-uniform
+            const int i = b_first + k;
+            res[i * 64 + lane] = kLidarMiss;
+            if (!SSG_ABL(1)) {
+                // Beam i points along heading + phi_i, phi_i = rad(90 - spread/2) + i*rad(spread/n_beams)
+                // (models.py:48-49,62-64); endpoint via the angle-addition identity (beam_end): agrees with the
+                // reference's per-beam cos/sin to ~1e-13 and only feeds lidar readings, never the dynamics.
+                double ex, ey;
+                beam_end(cx, cy, ca, sa, beamtab[i], beamtab[SSG_MAX_BEAMS + i], c.lidar_dist, ex, ey);
+                const double lox = dmin(cx, ex), hix = dmax(cx, ex), loy = dmin(cy, ey), hiy = dmax(cy, ey);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // keep the pair unless the beam's box and the hull's (widened) box are disjoint
+                    const bool need = live & (lox <= ar[s]) & (al[s] <= hix) & (loy <= at[s]) & (ab[s] <= hiy);
+                    const unsigned long long m = __ballot(need);
+                    const int pos = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (k << 6) | (s << 10));
+                    n_items += __popcll(m);
+                }
+            }
+        }
+    }
+    if (!SSG_ABL(3))
+        lidar_pass<LDS_BANK, EXACT>(c, n_items, queue, res + b_first * 64, beamtab + b_first, cx, cy, ca, sa, rec_off, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Observation rows of one tile (64 envs, ship_env.py:79-113,156): row = [previous frame | new frame] (history 2) or
+// [new frame] (history 1), DH doubles per row, rows of neighbouring envs adjacent in HBM.  A lane holds ITS env's row
+// in registers; scattered 8-byte stores of it cost 64 write requests per instruction and used to dominate the step, so
+// the tile is transposed through LDS: CP columns at a time (what fits the buffer role 3 is handed: the lidar result
+// buffer it has just emptied) every lane writes its values column-major — conflict-free, full-wave ds_writes — and
+// reads the chunk back row-major, so that consecutive lanes store consecutive doubles of a row's CP-column segment.
+// LDS operations of one wave execute in issue order, so no wait separates the passes.  Column stride 73 doubles: the
+// read-back of ~9 rows x CP columns by one wave-instruction then falls on distinct banks.
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, bool H2, class Val>
+__device__ __forceinline__ void write_obs_tile(double *colbuf, const Val &val /* val(j): column j of this lane's row */,
+                                               double *__restrict__ obase, const int rows_live, const int lane)
+{
+    constexpr int FF = 6 + NB;
+    constexpr int DH = H2 ? 2 * FF : FF;
+    constexpr int CS = (NB >= 2) ? 73 : 64;  // column stride (doubles)
+    constexpr int CP = (NB * 64) / CS;       // columns per pass
+    static_assert(CP >= 1 && CP * CS * 8 <= lds_res_bytes(NB), "observation chunk does not fit the lidar result buffer");
+    // launder the lane index: the (row, column) index arithmetic below is loop-invariant across the fused steps, and
+    // hoisted out of the step loop its ~3 registers per element are spilled to scratch
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int p0 = 0; p0 < DH; p0 += CP) {
+        const int cpp = (DH - p0 < CP) ? (DH - p0) : CP; // columns of this pass (a constant once unrolled)
+#pragma unroll
+        for (int cc = 0; cc < CP; ++cc) {
+            if (cc < cpp) colbuf[cc * CS + ln] = val(p0 + cc); // (computed here, not ahead: registers)
+        }
+#pragma unroll
+        for (int jj = 0; jj < CP; ++jj) {
+            if (jj < cpp) {
+                const int t = ln + 64 * jj;  // element t of the 64 x cpp chunk, row-major
+                const int r = t / cpp, cc = t - r * cpp;
+                const double v = colbuf[cc * CS + r];
+                if (r < rows_live) obase[(unsigned)(r * DH + p0 + cc)] = v; // uniform base + 32-bit lane offset
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the passes apart: the next pass's values are not computed (and held) early
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
-//   role 0  LIDAR-lo : body rotation on the pre-step pose, handle_discrete_action's force/torque, beams [0, NB0)
-//   role 1  LIDAR-hi : body rotation on the pre-step pose, beams [NB0, NB)
-//   role 2  BANKS    : integrator + ship transform, bank-hull narrowphase (collide_ship)
-//   role 3  BODY     : integrator + ship transform, goal-circle narrowphase, nearest goals, then (after the workgroup
-//                      barrier) velocity update, reward/done, statistics, sticky-lidar merge, observation and state
-//                      write-back; its registers carry the body state from step to step in a fused rollout
-// Roles 0-2 hand their results to role 3 through LDS.  A lone wave on a SIMD issues FP64 at half rate and runs
-// latency-bound; 65 536 envs are only one wave per SIMD, so each env's step is cut into four shorter instruction
-// streams that run as four co-resident waves per SIMD.
+//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0)
+//   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB)
+//   role 2  BANKS    : bank-hull narrowphase (collide_ship)
+//   role 3  BODY     : handle_discrete_action, integrator, ship transform, goal-circle narrowphase, nearest goals,
+//                      reward / done, statistics, sticky-lidar merge, observation and state write-back; its registers
+//                      carry the body state from step to step in a fused rollout
+// A lone wave on a SIMD issues FP64 at half rate and runs latency-bound, and 65 536 envs are only one wave per SIMD, so
+// each env's step is cut into four instruction streams on four co-resident waves per SIMD.  They are PIPELINED through
+// LDS with two workgroup barriers per step:
+//   role 3 integrates and publishes the post-step pose                                   -> barrier A(k)
+//   role 2 collides that pose with the banks while role 3 does the goals                 -> barrier B(k)
+//   role 3 closes step k (reward, done, observation rows, state) WHILE roles 0/1 already run step k+1's lidar query:
+//   LiDAR.query sees the pre-step pose, which is step k's post-step pose, or the spawn pose if the env is done — the
+//   lidar roles read role 2's and role 3's done bits after B(k) and decide that themselves.  Results are handed over in
+//   LDS buffers indexed by the parity of the step.  (The first step's query runs between A(0) and B(0), from the state
+//   columns.)  Nothing but role 3 touches the state in HBM, so no store of a step has to drain before the next begins.
 // ---------------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
-
-// post-step pose shared by roles 2 and 3 (bitwise identical in both: same loads, same operations)
-struct PostPose {
-    double x, y, ang, ca, sa, sbl, sbr, sbb, sbt;
-};
-
 template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
                                                        uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out,
                                                        const int K)
 {
-    // K consecutive steps in one launch (K = 1 for ssg_step): the bank is staged once, role 3 keeps the body state in
-    // registers, and the other roles re-read the few columns they need from the L2 after role 3 has stored them.
-    // Step k reads actions_kn + k*n_envs; obs / reward / done / flags are rewritten by every step.
+    // K consecutive steps in one launch (K = 1 for ssg_step): the bank is staged once and role 3 keeps the body state in
+    // registers.  Step k reads actions_kn + k*n_envs; obs / reward / done / flags are rewritten by every step.
     constexpr int NB0 = nb_lo(NB);
     const int role = threadIdx.x / EPW;                        // wave-uniform (EPW is a multiple of 64)
     const int tl = threadIdx.x - role * EPW;                   // env slot inside the workgroup
@@ -361,10 +488,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *xchg = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [3][EPW]
-    unsigned *gres = reinterpret_cast<unsigned *>(xchg + 3 * EPW);                         // [EPW]
-    char *goal_scratch0 = reinterpret_cast<char *>(gres + EPW);
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [6][EPW]
+    int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
+    unsigned *gres = reinterpret_cast<unsigned *>(posem + EPW);                              // [EPW]
+    unsigned *gdone = gres + EPW;                                                            // [EPW]
+    char *goal_scratch0 = reinterpret_cast<char *>(gdone + EPW);
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
+    char *tile_base = scratch0 + (tl >> 6) * lds_tile_bytes(NB); // this env tile's lidar buffers
 
 #ifdef SSG_STAMPS
     unsigned long long stamp_[16] = {};
@@ -381,202 +511,94 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[2 * 8 + i] = c.nrm[2 * i];      shiptab[3 * 8 + i] = c.nrm[2 * i + 1];    // plane normal i
         shiptab[4 * 8 + i] = c.hull[2 * ip];    shiptab[5 * 8 + i] = c.hull[2 * ip + 1];  // vertex i-1 (edge start)
     }
+    if (threadIdx.x == 128) {
+        // lidar origin of a freshly reset ship (angle 0: cpvforangle(0) = (1, 0)): pos + half the world AABB extents,
+        // by the very operations ship_world() runs
+        double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+            const double hx = c.hull[2 * i], hy = c.hull[2 * i + 1];
+            const double wx = 1.0 * hx + (-0.0) * hy + c.spawn_x, wy = 0.0 * hx + 1.0 * hy + c.spawn_y;
+            bl = dmin(bl, wx); br = dmax(br, wx); bb = dmin(bb, wy); bt = dmax(bt, wy);
+        }
+        shiptab[0 * 8 + 6] = c.spawn_x + (br - bl) / 2;
+        shiptab[1 * 8 + 6] = c.spawn_y + (bt - bb) / 2;
+    }
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
+    const bool auto_reset = (c.flags & SSG_FLAG_AUTO_RESET) != 0u;
 
     if (role < 2) {
         // =====================================================================================================
-        // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step);
-        //              role 0 also evaluates handle_discrete_action's force and torque.
+        // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step)
         // =====================================================================================================
-        if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
-        for (int k = 0; k < K; ++k) {
-        const bool fresh = k > 0;
-        // Launder the env index once per step: the per-lane column addresses are loop-invariant, and hoisted out of
-        // the loop they cost ~70 VGPRs of live 64-bit pointers (spilled to scratch at the 128-VGPR budget of a
-        // 1024-thread workgroup); recomputing an address is one v_lshl_add_u64.
-        int el = el_;
-        asm volatile("" : "+v"(el));
-        const double x = ld_f64(colX + el, fresh), y = ld_f64(colY + el, fresh), ang = ld_f64(colA + el, fresh);
-        const int map_id = ld_i32(colMap + el, fresh);
-        int rudder = 0, act = 3;
-        unsigned gm = 0;
-        if (role == 0) {
-            rudder = ld_i32(colRud + el, fresh);
-            gm = ld_u8(c.mask + el, fresh);
-            act = actions_kn[(size_t)k * c.n_envs + el];
-        }
-        const int rec_off = map_id * SSG_MAP_STRIDE;
-
-        double sa0, ca0;
-        { const double2 sc = sincos_call(ang); sa0 = sc.x; ca0 = sc.y; } // body->transform rotation
-        if (role == 0) {
-            // handle_discrete_action (game.py:140-153): Ship.move_forward ->
-            // cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust); the rudder update itself is role 3's
-            const double px = (gm & 0x80u) ? (0.0 - (double)rudder) : c.px0; // models.py:109,146
-            const double py = c.py0;
-            const double fwx = (-sa0) * c.force_y, fwy = ca0 * c.force_y;    // cpTransformVect(transform, (0,F))
-            const double pwx = ca0 * px + (-sa0) * py + x, pwy = sa0 * px + ca0 * py + y; // cpTransformPoint
-            const double rx = pwx - x, ry = pwy - y;                         // minus transform * cog, cog = (0,0)
-            const bool thrust = act == 0;
-            xchg[0 * EPW + tl] = thrust ? fwx : 0.0;
-            xchg[1 * EPW + tl] = thrust ? fwy : 0.0;
-            xchg[2 * EPW + tl] = thrust ? (rx * fwy - ry * fwx) : 0.0;
-        }
-        SSG_STAMP(1);
-        if (k == 0) {
-            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-            __syncthreads();                             // barrier 1: bank + tables visible
-        }
-        SSG_STAMP(2);
-
-        // lidar origin: pos + half the world AABB extents (models.py:51-53)
-        double cx, cy;
+        unsigned short *queue = reinterpret_cast<unsigned short *>(tile_base + 2 * lds_res_bytes(NB) + role * lds_queue_bytes(NB0));
+        const int b_first = role ? NB0 : 0, b_count = role ? (NB - NB0) : NB0;
+        // the first step's pre-step pose comes from the state columns
+        double ca, sa, cx, cy;
+        int map_id;
         {
-            double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-                const double hx = shiptab[0 * 8 + i], hy = shiptab[1 * 8 + i];
-                const double wx = ca0 * hx + (-sa0) * hy + x, wy = sa0 * hx + ca0 * hy + y;
-                bl = dmin(bl, wx); br = dmax(br, wx);
-                bb = dmin(bb, wy); bt = dmax(bt, wy);
-            }
-            cx = x + (br - bl) / 2;
+            const double x = colX[el_], y = colY[el_], ang = colA[el_];
+            map_id = colMap[el_];
+            { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; } // body->transform rotation
+            if (role == 0) { pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa; } // -> role 3: the first step's thrust direction
+            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+            __syncthreads();                             // barrier 0: bank + tables visible
+            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], bl, br, bb, bt;
+            ship_world(shiptab, ca, sa, x, y, swx, swy, bl, br, bb, bt);
+            cx = x + (br - bl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
             cy = y + (bt - bb) / 2;
         }
-
-        const int lw = 2 * (tl >> 6) + role; // scratch slot: the two lidar waves of an env tile are neighbours
-        char *wscr = scratch0 + lw * lds_wave_scratch_bytes(NB0);
-        double *res0 = reinterpret_cast<double *>(wscr);
-        double *res1 = res0 + NB0 * 64;
-        unsigned short *queue = reinterpret_cast<unsigned short *>(res1 + NB0 * 64);
-        constexpr int kTrash = 2 * NB0 * 64; // 64 u16 past the queue swallow the writes of culled pairs
-        const int b_first = role ? NB0 : 0, b_count = role ? (NB - NB0) : NB0;
-        int n_items = 0;
-        // hull AABBs widened by eps: culling must never drop a pair the reference would hit
-        const double eps = 1e-6;
-        double al[2], ab[2], ar[2], at[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            al[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0) - eps;
-            ab[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1) - eps;
-            ar[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2) + eps;
-            at[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3) + eps;
-        }
-#pragma unroll
-        for (int k = 0; k < NB0; ++k) {
-            res0[k * 64 + lane] = -1.0;
-            res1[k * 64 + lane] = -1.0;
-            if (k < b_count && !SSG_ABL(1)) { // wave-uniform
-                const int i = b_first + k;
-                // Beam i points along heading + phi_i, phi_i = rad(90 - spread/2) + i*rad(spread/n_beams)
-                // (models.py:48-49,62-64); endpoint via the angle-addition identity (beam_end): agrees with the
-                // reference's per-beam cos/sin to ~1e-13 and only feeds lidar readings, never the dynamics.
-                double ex, ey;
-                beam_end(cx, cy, ca0, sa0, beamtab[i], beamtab[SSG_MAX_BEAMS + i], c.lidar_dist, ex, ey);
-                const double lox = dmin(cx, ex), hix = dmax(cx, ex), loy = dmin(cy, ey), hiy = dmax(cy, ey);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    // keep the pair unless the beam's box and the hull's (widened) box are disjoint
-                    const bool need = live & (lox <= ar[s]) & (al[s] <= hix) & (loy <= at[s]) & (ab[s] <= hiy);
-                    const unsigned long long m = __ballot(need);
-                    const int pos = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (k << 6) | (s << 10));
-                    n_items += __popcll(m);
-                }
+        for (int k = 0; k < K; ++k) {
+            __syncthreads(); // barrier A(k): role 3 has published this step's post-step pose
+            SSG_STAMP_K(0);
+            const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
+            const double ncx = pose[4 * EPW + tl], ncy = pose[5 * EPW + tl];
+            const int nmap = posem[tl];
+            if (k == 0)
+                lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first,
+                                                 b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
+            __syncthreads(); // barrier B(k): collide_ship and role 3's done bits are in
+            SSG_STAMP_K(1);
+            if (k + 1 < K) {
+                // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
+                const bool rs = auto_reset & ((gres[tl] | gdone[tl]) != 0u);
+                ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
+                cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
+                int nm = nmap + 1;
+                nm = (nm >= c.n_maps) ? 0 : nm;
+                map_id = rs ? nm : nmap;
+                lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base + ((k + 1) & 1) * lds_res_bytes(NB)),
+                                                 queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
             }
+            SSG_STAMP_K(2);
         }
-        SSG_STAMP(3);
-        if (!SSG_ABL(3))
-            lidar_pass<LDS_BANK, EXACT>(c, n_items, queue, res0, res1, beamtab + b_first, cx, cy, ca0, sa0, rec_off, lane);
-        SSG_STAMP(4);
-        __syncthreads(); // barrier 2: results complete
-        SSG_STAMP(5);
-        if (k + 1 < K) __syncthreads(); // barrier 3: role 3 has stored the next step's state
-        } // k
-        SSG_STAMP_FLUSH(6);
+        SSG_STAMP_FLUSH(3);
         return;
     }
 
-    // =========================================================================================================
-    // ROLES 2 / 3 share the post-step pose: cpSpaceStep (1) cpBodyUpdatePosition, (2) cpPolyShapeCacheData
-    // =========================================================================================================
-    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
-    // role 3's registers carry the whole body state from step to step; role 2 re-reads what it needs
-    double x = 0, y = 0, vx = 0, vy = 0, ang = 0, w = 0, cum = 0;
-    double lid[NB];
-    unsigned gm = 0;
-    int map_id = 0, rudder = 0, steps = 0;
-    if (role == 3) {
-        const int el = el_;
-        x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el];
-        gm = c.mask[el];
-        map_id = colMap[el];
-        rudder = colRud[el];
-    }
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
-    double cg_x = 0.0, cg_y = 0.0; // role 3: the newest frame's nearest goal, i.e. the next step's older-frame goal
-
-    for (int k = 0; k < K; ++k) {
-    const bool fresh = k > 0;
-    int el = el_; // laundered once per step (see the lidar roles): keeps column addresses out of long-lived registers
-    asm volatile("" : "+v"(el));
-    int act = 3;
-    if (role == 2) {
-        x = ld_f64(colX + el, fresh); y = ld_f64(colY + el, fresh);
-        vx = ld_f64(colVX + el, fresh); vy = ld_f64(colVY + el, fresh);
-        ang = ld_f64(colA + el, fresh); w = ld_f64(colW + el, fresh);
-        gm = ld_u8(c.mask + el, fresh);
-        map_id = ld_i32(colMap + el, fresh);
-    } else {
-        act = actions_kn[(size_t)k * c.n_envs + el];
-    }
-    const int rec_off = map_id * SSG_MAP_STRIDE;
-    const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
-    const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang; // previous frame = pre-step state
-    const unsigned gm0 = gm;
-
-    x = x + vx * c.dt;
-    y = y + vy * c.dt;
-    ang = ang + w * c.dt;
-    double sa, ca;
-    { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; }
-
-    SSG_STAMP(1);
-    if (k == 0) {
-        if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-        __syncthreads();                             // barrier 1: bank + tables visible
-    }
-    SSG_STAMP(2);
-
-    // cpPolyShapeCacheData: world vertices and AABB of the ship
-    double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
-    double sbl = INFINITY, sbr = -INFINITY, sbb = INFINITY, sbt = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-        const double hx = shiptab[0 * 8 + i], hy = shiptab[1 * 8 + i];
-        swx[i] = ca * hx + (-sa) * hy + x;
-        swy[i] = sa * hx + ca * hy + y;
-        sbl = dmin(sbl, swx[i]); sbr = dmax(sbr, swx[i]);
-        sbb = dmin(sbb, swy[i]); sbt = dmax(sbt, swy[i]);
-    }
-
-    // ---- narrowphase, wave-cooperative ----------------------------------------------------------------------
-    // Per lane only the cheap cpBBIntersects rejects run.  The few lanes that pass are then served one at a time
-    // by the WHOLE wave: lane L = 5*q + i works on (bank plane q or goal q, ship vertex/edge i) of the served
-    // env, whose pose is broadcast with v_readlane.  The arithmetic of every product and sum is exactly the
-    // per-env formulation's (cpPolyShapeCacheData, SAT dot products, cpPolyShapePointQuery); only the min/any
-    // reductions over vertices and planes are done with ballots instead of sequential loops.
-    const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
-    const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
 
     if (role == 2) {
         // =====================================================================================================
         // ROLE 2: player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed
         //         convex sets intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals:
         //         separated iff some axis has every vertex of the other polygon strictly in front.
+        // Per lane only the cheap rejects run; the few lanes that pass are then served one at a time by the WHOLE wave:
+        // lane L = 5*q + i works on (bank plane q, ship vertex/edge i) of the served env, whose pose is broadcast with
+        // v_readlane.  The arithmetic of every product and sum is exactly the per-env formulation's; only the min/any
+        // reductions over vertices and planes are done with ballots instead of sequential loops.
         // =====================================================================================================
-        bool colliding = false;
-        {
+        if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads(); // barrier 0
+        const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
+        const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
+        for (int k = 0; k < K; ++k) {
+            __syncthreads(); // barrier A(k)
+            SSG_STAMP_K(0);
+            const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl], ca = pose[2 * EPW + tl], sa = pose[3 * EPW + tl];
+            const int rec_off = posem[tl] * SSG_MAP_STRIDE;
+            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], sbl, sbr, sbb, sbt;
+            ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
+            bool colliding = false;
             unsigned nearbits = 0;
             int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
 #pragma unroll
@@ -651,28 +673,114 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 }
                 colliding = (lane == src) ? col : colliding;
             }
+            gres[tl] = colliding ? 1u : 0u;
+            SSG_STAMP_K(1);
+            __syncthreads(); // barrier B(k)
+            SSG_STAMP_K(2);
         }
-
-        SSG_STAMP(3);
-        gres[tl] = colliding ? 1u : 0u;
-        SSG_STAMP(4);
-        __syncthreads(); // barrier 2
-        SSG_STAMP(5);
-        if (k + 1 < K) __syncthreads(); // barrier 3: role 3 has stored the next step's state
-        continue;
+        SSG_STAMP_FLUSH(3);
+        return;
     }
 
     // =========================================================================================================
-    // ROLE 3: goal narrowphase and nearest goals before the barrier; everything that closes the step after it
+    // ROLE 3: the body.  Its registers carry the state from step to step.
     // =========================================================================================================
+    double x, y, vx, vy, ang, w;
+    unsigned gm;
+    int map_id, rudder, steps;
+    {
+        const int el = el_;
+        x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el];
+        gm = c.mask[el];
+        map_id = colMap[el];
+        rudder = colRud[el];
+        steps = colStep[el];
+    }
+    if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+    __syncthreads();                             // barrier 0: bank + tables + role 0's initial rotation visible
+    const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
+    const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
+    double cg_x = 0.0, cg_y = 0.0; // the newest frame's nearest goal, i.e. the next step's older-frame goal
     const int F = 6 + NB;
     const bool hist2 = c.history >= 2;
+
+    for (int k = 0; k < K; ++k) {
+    // Launder the env index once per step: the per-lane column addresses are loop-invariant, and hoisted out of the
+    // loop they cost ~70 VGPRs of live 64-bit pointers (spilled to scratch at the 128-VGPR budget of a 1024-thread
+    // workgroup); recomputing an address is one v_lshl_add_u64.
+    SSG_STAMP_K(0);
+    int el = el_;
+    asm volatile("" : "+v"(el));
+    const int act = actions_kn[(size_t)k * c.n_envs + el];
+    const int rec_off = map_id * SSG_MAP_STRIDE;
+    const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
+    const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang; // previous frame = pre-step state
+    const unsigned gm0 = gm;
+
+    // ---- handle_discrete_action (game.py:140-153) on the pre-step pose --------------------------------------------
+    double fx = 0.0, fy = 0.0, tq = 0.0;
+    {
+        // body->transform rotation of the pre-step angle: what the previous step (or role 0, for the first one) left in
+        // the pose slot; a reset env was given (1, 0) there
+        const double ca0 = pose[2 * EPW + tl], sa0 = pose[3 * EPW + tl];
+        // Ship.move_forward -> cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust)
+        const double px = (gm & 0x80u) ? (0.0 - (double)rudder) : c.px0; // models.py:109,146
+        const double py = c.py0;
+        const double fwx = (-sa0) * c.force_y, fwy = ca0 * c.force_y;    // cpTransformVect(transform, (0,F))
+        const double pwx = ca0 * px + (-sa0) * py + x, pwy = sa0 * px + ca0 * py + y; // cpTransformPoint
+        const double rx = pwx - x, ry = pwy - y;                         // minus transform * cog, cog = (0,0)
+        const bool thrust = act == 0;
+        fx = thrust ? fwx : 0.0;
+        fy = thrust ? fwy : 0.0;
+        tq = thrust ? (rx * fwy - ry * fwx) : 0.0;
+    }
     if (act == 1 || act == 2) {
         // Ship.rotate(-5 / +5) + clamp_rudder (models.py:136-146)
         rudder += (act == 1) ? -c.rudder_step : c.rudder_step;
         rudder = max(-c.rudder_max, min(c.rudder_max, rudder));
         gm |= 0x80u;
     }
+
+    // ---- cpSpaceStep (1) cpBodyUpdatePosition, (3) cpBodyUpdateVelocity (gravity 0) with the force / torque just
+    //      accumulated (forces are cleared afterwards).  The narrowphase in between reads positions only, so updating the
+    //      velocities here changes nothing. ----
+    x = x + vx * c.dt;
+    y = y + vy * c.dt;
+    ang = ang + w * c.dt;
+    vx = vx * c.damp + (fx * c.m_inv) * c.dt;
+    vy = vy * c.damp + (fy * c.m_inv) * c.dt;
+    w = w * c.damp + tq * c.i_inv * c.dt;
+    // (4) impulse solver: its output cannot reach an observation before the env is reset.
+    double sa, ca;
+    { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; }
+
+    // cpPolyShapeCacheData: world vertices and AABB of the ship
+    double sbl, sbr, sbb, sbt;
+    {
+        double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
+        ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
+    }
+    // publish the post-step pose: role 2 collides it now, the lidar roles query from it for the next step
+    pose[0 * EPW + tl] = x; pose[1 * EPW + tl] = y; pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa;
+    pose[4 * EPW + tl] = x + (sbr - sbl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
+    pose[5 * EPW + tl] = y + (sbt - sbb) / 2;
+    posem[tl] = map_id;
+    SSG_STAMP_K(1);
+    __syncthreads(); // barrier A(k)
+    SSG_STAMP_K(2);
+
+    // the columns only needed to close the step: requested now, consumed after barrier B (L2 latency under the goals)
+    double cum;
+    double lid[NB];
+    {
+        int el2 = el_;
+        asm volatile("" : "+v"(el2));
+        const bool fresh = k > 0; // rewritten by this wave one step ago: read them from the L2, not this CU's L1
+        cum = ld_f64(colCum + el2, fresh);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) lid[i] = ld_f64(colLid + (size_t)i * np + el2, fresh);
+    }
+
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
 
@@ -687,7 +795,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         unsigned *gw = reinterpret_cast<unsigned *>(gq + 64 * SSG_MAX_GOALS);
         gw[lane] = 0u;
         int n_pairs = 0;
-        SSG_STAMP(10);
         for (int g = 0; g < c.n_goals; ++g) {
             const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
             const double gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
@@ -699,7 +806,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (near) gq[pos] = (unsigned short)(lane | (g << 6));
             n_pairs += __popcll(m);
         }
-        SSG_STAMP(11);
         for (int base = 0; base < n_pairs; base += 12) {
             const int p = base + wq;
             const bool valid = (lane < 60) & (p < n_pairs);
@@ -723,8 +829,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // min over the five edges of this pair (lanes 5p' .. 5p'+4), any(outside) over the same five lanes
             double md = dist;
 #pragma unroll
-            for (int k = 1; k < SSG_SHIP_VERTS; ++k) {
-                int o = wi + k;
+            for (int kk = 1; kk < SSG_SHIP_VERTS; ++kk) {
+                int o = wi + kk;
                 o = (o >= SSG_SHIP_VERTS) ? o - SSG_SHIP_VERTS : o;
                 md = dmin(md, __shfl(dist, 5 * wq + o));
             }
@@ -733,15 +839,20 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const double sd = outside ? md : -md;
             if (valid & (wi == 0) & (sd <= c.goal_r)) atomicOr(&gw[src], 1u << g); // goal g of env src consumed
         }
-        SSG_STAMP(12);
         const unsigned gotmask = gw[lane];
         goal_reached = gotmask != 0u;
         gm &= ~gotmask;
     }
+    // ---- step_count += 1; role 3's share of is_done (ship_env.py:115-134,152-154), handed to the lidar roles ----
+    steps += 1;
+    const int steps_after = steps;
+    const unsigned alive = gm & ((1u << c.n_goals) - 1u);
+    const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
+    gdone[tl] = done3 ? 1u : 0u;
+
     // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position
     double nf_gx = 0, nf_gy = 0;
     if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, goff, gm, x, y, nf_gx, nf_gy);
-    SSG_STAMP(3);
 
     // previous frame's nearest goal (oldest slot of the 2-frame history): a function of the pre-step state
     double pf_gx = 0, pf_gy = 0;
@@ -755,20 +866,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         else { pf_gx = cg_x; pf_gy = cg_y; }
     }
 
-    SSG_STAMP(4);
-    __syncthreads(); // barrier 2: lidar results, force/torque and the goal results are complete
-    SSG_STAMP(5);
+    SSG_STAMP_K(3);
+    __syncthreads(); // barrier B(k): collide_ship (role 2) and this step's lidar results are complete
+    SSG_STAMP_K(4);
 
-    {
-        // the columns only needed to close the step are (re)read here instead of being carried through the goal
-        // narrowphase in registers; the index is laundered again so their addresses are not computed (and kept) early
-        int el2 = el_;
-        asm volatile("" : "+v"(el2));
-        cum = ld_f64(colCum + el2, fresh);
-        steps = ld_i32(colStep + el2, fresh);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) lid[i] = ld_f64(colLid + (size_t)i * np + el2, fresh);
-    }
     bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
     unsigned dflag = 0;
     if constexpr (DYN) {
@@ -777,27 +878,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
     }
 
-    // ---- cpSpaceStep (3): cpBodyUpdateVelocity (gravity 0) with the force/torque role 0 accumulated; forces are
-    //      cleared afterwards.  (The narrowphase reads positions only, so doing this last changes nothing.) ----
-    {
-        const double fx = xchg[0 * EPW + tl], fy = xchg[1 * EPW + tl], tq = xchg[2 * EPW + tl];
-        vx = vx * c.damp + (fx * c.m_inv) * c.dt;
-        vy = vy * c.damp + (fy * c.m_inv) * c.dt;
-        w = w * c.damp + tq * c.i_inv * c.dt;
-        // (4) impulse solver: its output cannot reach an observation before the env is reset.
-    }
-
     // ---- determine_reward (ship_env.py:62-77) ----
     double rew = goal_reached ? 1.0 : ((oob_x | oob_y) ? -1.0 : -0.01);
     if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;
     cum += rew;
 
-    // ---- step_count += 1; is_done (ship_env.py:115-134,152-154) ----
-    steps += 1;
-    const int steps_after = steps;
-    const unsigned alive = gm & ((1u << c.n_goals) - 1u);
-    const bool done = colliding | (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
-    const bool do_reset = done & ((c.flags & SSG_FLAG_AUTO_RESET) != 0u);
+    const bool done = colliding | done3;
+    const bool do_reset = done & auto_reset;
 
     if (live && !SSG_ABL(6)) {
         // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
@@ -815,25 +902,24 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // ---- observation (ship_env.py:79-113,156): row = [previous frame | new frame]; for a done env under VecEnv
     //      auto-reset, ShipGame.reset + ShipEnv.reset onto the next bank record: a history of -1, then the spawn frame.
     //      A lane's row is 8*D bytes and rows of neighbouring envs are adjacent in HBM, so the wave's 64 rows form one
-    //      contiguous tile: it is transposed through LDS (the scratch of this tile's two lidar waves, idle between
-    //      barrier 2 and barrier 3) and written with 16-byte-per-lane, 1 KiB-per-instruction coalesced stores.
+    //      contiguous tile: it is transposed through LDS (the lidar result buffer of this step's parity, free once the
+    //      results are in registers) and written with 16-byte-per-lane, 1 KiB-per-instruction coalesced stores.
     //      Scattered 8-byte stores of the same data cost 64 write requests per instruction and dominated the step. ----
-    SSG_STAMP(6);
     int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);                 // wave-uniform; laundered like `el`:
     int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                        // no hoisted tile addresses
     asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
-    char *tile_scr = scratch0 + (2 * tile_w) * lds_wave_scratch_bytes(NB0);
+    char *res_k = scratch0 + tile_w * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB);
     double nl[NB];
+    {
+        const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(res_k);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        // results of the lidar wave that served these 64 envs: role 0 holds beams [0,NB0), role 1 the rest
-        const int lr = (i < NB0) ? 0 : 1, kk = i - lr * NB0;
-        const double *res0 = reinterpret_cast<const double *>(tile_scr + lr * lds_wave_scratch_bytes(NB0));
-        const double *res1 = res0 + NB0 * 64;
-        // first shape in list order that reports a hit wins (models.py:61-72): the left bank before the right
-        const double r0 = res0[kk * 64 + lane], r1 = res1[kk * 64 + lane];
-        nl[i] = (r0 >= 0.0) ? r0 : r1;
+        for (int i = 0; i < NB; ++i) {
+            // smallest key = the first shape in list order that reported a hit (models.py:61-72); none = miss
+            const unsigned long long key = rk[i * 64 + lane];
+            nl[i] = (key == kLidarMiss) ? -1.0 : __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
+        }
     }
+    SSG_STAMP_K(5);
     if (do_reset) {
         map_id = map_id + 1;
         if (map_id >= c.n_maps) map_id = 0;
@@ -841,64 +927,32 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const double rs_gx = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
     const double rs_gy = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
     {
-        constexpr int D = 2 * (6 + NB);           // widest row (history 2); history 1 uses the first F columns
-        constexpr int LD = D + 1;                 // padded LDS row: odd stride in 8-byte units, conflict-free writes
-        constexpr int kAvail = 2 * lds_wave_scratch_bytes(NB0);
-        constexpr int RP = (64 * LD * 8 <= kAvail) ? 64 : (32 * LD * 8 <= kAvail) ? 32 : (16 * LD * 8 <= kAvail) ? 16 : 8;
-        static_assert(RP * LD * 8 <= kAvail, "observation tile does not fit the lidar scratch");
-        const int Dh = F * c.history;             // doubles per row actually written
-        double *tile = reinterpret_cast<double *>(tile_scr);
-        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the result reads above are done before we overwrite
-        double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)Dh; // tile start in HBM
-        const int rows_live = min(64, c.n_envs - tile_e0);               // rows of this tile in range
-#pragma unroll
-        for (int p0 = 0; p0 < 64; p0 += RP) {
-            const bool mine = (lane >= p0) & (lane < p0 + RP);
-            double *trow = tile + (lane - p0) * LD;
-            if (mine) {
-                int col = 0;
-                if (hist2) {
-                    trow[0] = do_reset ? -1.0 : pf_x;   trow[1] = do_reset ? -1.0 : pf_y;
-                    trow[2] = do_reset ? -1.0 : pf_rud; trow[3] = do_reset ? -1.0 : pf_a;
-                    trow[4] = do_reset ? -1.0 : pf_gx;  trow[5] = do_reset ? -1.0 : pf_gy;
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) trow[6 + i] = do_reset ? -1.0 : lid[i]; // readings before this query
-                    col = F;
-                }
-                trow[col + 0] = do_reset ? c.spawn_x : x;
-                trow[col + 1] = do_reset ? c.spawn_y : y;
-                trow[col + 2] = do_reset ? 0.0 : (double)rudder;
-                trow[col + 3] = do_reset ? 0.0 : ang;
-                trow[col + 4] = do_reset ? rs_gx : nf_gx;
-                trow[col + 5] = do_reset ? rs_gy : nf_gy;
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const double v = (nl[i] >= 0.0) ? nl[i] : lid[i]; // a miss keeps the previous reading (sticky)
-                    trow[col + 6 + i] = do_reset ? -1.0 : v;
-                }
+        double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)(F * c.history); // tile start in HBM
+        const int rows_live = min(64, c.n_envs - tile_e0);                             // rows of this tile in range
+        // column q of the previous frame (pre-step state, readings before this query) / of the new frame; q is a
+        // constant at every call once the passes are unrolled
+        auto prev_col = [&](int q) -> double {
+            double v = (q == 0) ? pf_x : (q == 1) ? pf_y : (q == 2) ? pf_rud : (q == 3) ? pf_a : (q == 4) ? pf_gx : pf_gy;
+            if (q >= 6) v = lid[(q >= 6) ? q - 6 : 0];
+            return do_reset ? -1.0 : v;
+        };
+        auto new_col = [&](int q) -> double {
+            if (q >= 6) {
+                const int i = (q >= 6) ? q - 6 : 0;
+                const double v = (nl[i] >= 0.0) ? nl[i] : lid[i]; // a miss keeps the previous reading (sticky)
+                return do_reset ? -1.0 : v;
             }
-            // linear read-back: element o of the pass (row-major, Dh per row) -> 16 bytes per lane per instruction
-            const int n_el = min(RP, max(0, rows_live - p0)) * Dh;
-            if (!SSG_ABL(7)) {
-                if (!(Dh & 1)) { // even row length: pairs never straddle rows and stay 16-byte aligned
-                    for (int o = 2 * lane; o < n_el; o += 128) {
-                        const int r = o / Dh, cc = o - r * Dh;
-                        double2 v2;
-                        v2.x = tile[r * LD + cc];
-                        v2.y = tile[r * LD + cc + 1];
-                        *reinterpret_cast<double2 *>(obase + (size_t)p0 * Dh + o) = v2;
-                    }
-                } else {
-                    for (int o = lane; o < n_el; o += 64) {
-                        const int r = o / Dh, cc = o - r * Dh;
-                        obase[(size_t)p0 * Dh + o] = tile[r * LD + cc];
-                    }
-                }
-            }
-            if (p0 + RP < 64) __builtin_amdgcn_s_waitcnt(0xC07F); // reads done before the next pass overwrites the tile
+            const double a = (q == 0) ? x : (q == 1) ? y : (q == 2) ? (double)rudder : (q == 3) ? ang : (q == 4) ? nf_gx : nf_gy;
+            const double r = (q == 0) ? c.spawn_x : (q == 1) ? c.spawn_y : (q == 4) ? rs_gx : (q == 5) ? rs_gy : 0.0;
+            return do_reset ? r : a;
+        };
+        if (!SSG_ABL(7)) {
+            double *colbuf = reinterpret_cast<double *>(res_k);
+            if (hist2) write_obs_tile<NB, true>(colbuf, [&](int j) -> double { return (j < F) ? prev_col(j) : new_col(j - F); }, obase, rows_live, lane);
+            else write_obs_tile<NB, false>(colbuf, [&](int j) -> double { return new_col(j); }, obase, rows_live, lane);
         }
     }
-    SSG_STAMP(13);
+    SSG_STAMP_K(6);
 #pragma unroll
     for (int i = 0; i < NB; ++i) lid[i] = do_reset ? -1.0 : ((nl[i] >= 0.0) ? nl[i] : lid[i]);
     if (live) {
@@ -927,6 +981,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
         rudder = 0; steps = 0;
         gm = (1u << c.n_goals) - 1u;
+        // the pre-step rotation the next step's thrust will read: cpvforangle(0)
+        pose[2 * EPW + tl] = 1.0; pose[3 * EPW + tl] = 0.0;
     }
     if (live) {
         colX[el] = x; colY[el] = y; colVX[el] = vx; colVY[el] = vy; colA[el] = ang; colW[el] = w; colCum[el] = cum;
@@ -935,14 +991,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         colRud[el] = rudder; colStep[el] = steps; colMap[el] = map_id;
         c.mask[el] = (uint8_t)gm;
     }
-    SSG_STAMP(14);
-    if (k + 1 < K) {
-        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): this wave's state stores have reached the L2
-        SSG_STAMP(15);
-        __syncthreads();               // barrier 3: the other roles may now read the next step's state
-    }
+    SSG_STAMP_K(7);
     } // k
-    SSG_STAMP_FLUSH(16);
+    SSG_STAMP_FLUSH(8);
 }
 
 #ifndef SSG_NB_GROUP
@@ -1133,12 +1184,12 @@ static step_fn_t step_fn(int nb, int epw, bool lds, int variant)
     }
 }
 
-// dynamic LDS: [bank (if staged)] [tables + exchange] [per-lidar-wave scratch]
+// dynamic LDS: [bank (if staged)] [tables + pose exchange] [per-tile lidar result buffers and queues]
 size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
 {
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
     b += (size_t)lds_fixed_bytes(epw);
-    b += (size_t)(2 * (epw / 64)) * (size_t)lds_wave_scratch_bytes(nb_lo(n_beams));
+    b += (size_t)(epw / 64) * (size_t)lds_tile_bytes(n_beams);
     return b;
 }
 

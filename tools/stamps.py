@@ -1,47 +1,42 @@
 #!/usr/bin/env python3
-"""Diagnostic (needs a -DSSG_STAMPS build): average per-wave cycles between the s_memtime stamps of the step kernel."""
+"""Diagnostic (needs a -DSSG_STAMPS build: `make -C ship_sim_gym_amd/csrc EXTRA=-DSSG_STAMPS`): per-wave s_memtime
+stamps of the second-to-last step of fused launches of the pipelined step kernel, averaged over waves and launches.
+All stamps of a workgroup come from one CU's clock, so differences ACROSS roles are meaningful too."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ship_sim_gym_amd import _native as N
 from ship_sim_gym_amd.vec_env import ShipVecEnv
 n = int(os.environ.get("SSG_N", "65536"))
-vec = ShipVecEnv(n, n_maps=64, n_beams=8)
+nb = int(os.environ.get("SSG_NB", "8"))
+vec = ShipVecEnv(n, n_maps=64, n_beams=nb)
 L = N.lib()
 epw = 64 if n <= 64 * 256 else (128 if n <= 128 * 256 else 256)
 nw = 4 * ((n + epw - 1) // epw) * epw // 64
 buf = torch.zeros((nw, 16), dtype=torch.int64, device="cuda")
 L.ssg_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 L.ssg_debug_set_stamp_buffer(vec._h, C.c_void_p(buf.data_ptr()))
-acts = vec.random_actions(12345, 0, 300)
+acts = vec.random_actions(12345, 0, 400)
 vec.reset_tensor()
 vec.rollout_tensor(acts[:200])
-names = {
-    0: ["loads+sincos+force", "wait DMA+barrier1", "bb+cull+queue", "lidar passes", "wait barrier2"],
-    1: ["loads+sincos", "wait DMA+barrier1", "bb+cull+queue", "lidar passes", "wait barrier2"],
-    2: ["loads+integrate+sincos", "wait DMA+barrier1", "bb+SAT+publish", "-", "wait barrier2"],
-    3: ["loads+integrate+sincos", "wait DMA+barrier1", "bb+goals+nearest", "prev nearest goal", "wait barrier2", "tail"],
-}
 wpr = epw // 64
-acc = {r: np.zeros(len(v)) for r, v in names.items()}
-fused = int(os.environ.get("SSG_STAMP_FUSED", "1"))
-for k in range(200, 300):
-    if fused:
-        vec.rollout_tensor(acts[k - 50:k])   # 50 fused steps; the stamps left behind are the last iteration's
-    else:
-        vec.step_tensor(acts[k])
+R = 40
+acc = np.zeros((4, 8))
+for r in range(R):
+    vec.rollout_tensor(acts[200 + r: 250 + r])  # 50 fused steps; stamps are those of step 48
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().astype(np.int64).reshape(-1, 4, wpr, 16)
-    for r in range(4):
-        m = len(names[r])
-        acc[r] += np.diff(b[:, r, :, :m + 1], axis=-1).mean(axis=(0, 1))
-b3 = b[:, 3, :, :]
-print("role 3 goals fine: 2->10 bb+consts %.0f | 10->11 near tests+queue %.0f | 11->12 pair passes %.0f | 12->3 gw read+nearest goal %.0f" % (
-    (b3[..., 10] - b3[..., 2]).mean(), (b3[..., 11] - b3[..., 10]).mean(), (b3[..., 12] - b3[..., 11]).mean(), (b3[..., 3] - b3[..., 12]).mean()))
-print("role 3 post: 6->13 lidar results + obs tile + obs stores %.0f | 13->14 outputs + state stores issued %.0f | 14->15 store drain (vmcnt 0) %.0f" % (
-    (b3[..., 13] - b3[..., 6]).mean(), (b3[..., 14] - b3[..., 13]).mean(), (b3[..., 15] - b3[..., 14]).mean()))
-for r in range(4):
-    print("role %d" % r)
-    for nme, v in zip(names[r], acc[r] / 100):
-        print("   %-26s %8.0f cycles" % (nme, v))
-    print("   total %.0f" % (acc[r].sum() / 100))
+    b = buf.cpu().numpy().astype(np.int64).reshape(-1, 4, wpr, 16)  # [workgroup][role][tile][stamp]
+    t0 = b[:, 3, :, 0][:, None, :, None]                             # role 3's loop-top stamp of the same tile
+    acc += (b[..., :8] - t0).mean(axis=(0, 2))
+acc /= R
+names3 = ["iter start", "pose published (before A)", "after A", "goals+nearest done (before B)", "after B", "results in regs",
+          "obs tile + obs stores issued", "outputs + state stores issued"]
+print("all times in cycles after role 3's iteration start (mean over tiles / workgroups / %d launches)" % R)
+print("role 3 (body):")
+for i, nme in enumerate(names3):
+    print("   %-36s %8.0f   (+%.0f)" % (nme, acc[3, i], acc[3, i] - (acc[3, i - 1] if i else 0)))
+for role, nm in ((0, "lidar lo"), (1, "lidar hi")):
+    print("role %d (%s): after A %.0f | after B %.0f | next step's query done %.0f  (query = %.0f cycles)" % (
+        role, nm, acc[role, 0], acc[role, 1], acc[role, 2], acc[role, 2] - acc[role, 1]))
+print("role 2 (banks): after A %.0f | narrowphase done %.0f (= %.0f cycles) | after B %.0f" % (
+    acc[2, 0], acc[2, 1], acc[2, 1] - acc[2, 0], acc[2, 2]))
