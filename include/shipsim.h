@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 3 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state */
+#define SSG_ABI_VERSION 4 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
+                             4: map record without dtMin/dtMax (SSG_MAP_STRIDE 145, SSG_PLANE_DOUBLES 5) */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -62,22 +63,24 @@ typedef enum ssg_status {
  *   [2..5]  left  hull AABB l,b,r,t     [6..9] right hull AABB
  *   [10..22)  goal centres x0,y0,x1,y1,...  (SSG_MAX_GOALS pairs)
  *   [22] [23] the goal nearest to the spawn point (the reset observation's goal, ship_env.py:102-108)
- *   [24 + 7*j ..)  left  plane j: v0x v0y nx ny (v0.n) dtMin dtMax       j < 12
- *   [108 + 7*j ..) right plane j
- * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180); v0.n, dtMin =
- * cross(n, v[j-1]) and dtMax = cross(n, v[j]) are the per-plane constants cpPolyShapeSegmentQuery derives.
- *   [192] spare
- * 193 doubles: an ODD stride in 8-byte units, so the same field of different maps falls on different LDS banks
+ *   [24 + 5*j ..)  left  plane j: v0x v0y nx ny (v0.n)       j < 12
+ *   [84 + 5*j ..)  right plane j
+ * v0/n are Chipmunk's splitting planes of the hulled polygon (pm.Poly, models.py:180) and v0.n the plane offset
+ * cpPolyShapeSegmentQuery uses; its per-plane edge extents dtMin = cross(n, v[j-1]) and dtMax = cross(n, v[j]) are
+ * recomputed where needed from the neighbouring plane's v0 (the same two products and one difference).
+ *   [144] spare
+ * 145 doubles: an ODD stride in 8-byte units, so the same field of different maps falls on different LDS banks
  * (lanes of a wave sit on different maps; an even stride made such reads 8-way bank conflicts).  A 64-map bank is
- * 100 864 bytes and fits the CU's 160 KiB of LDS beside the lidar waves' scratch.
+ * 74 240 bytes and fits the CU's 160 KiB of LDS beside the pose exchange and the lidar waves' buffers, for up to 12
+ * beams at 256 envs per workgroup.
  */
-#define SSG_MAP_STRIDE 193
+#define SSG_MAP_STRIDE 145
 #define SSG_MAP_OFF_COUNTS 0
 #define SSG_MAP_OFF_AABB 2
 #define SSG_MAP_OFF_GOALS 10
 #define SSG_MAP_OFF_SPAWN_GOAL 22
 #define SSG_MAP_OFF_PLANES 24
-#define SSG_PLANE_DOUBLES 7
+#define SSG_PLANE_DOUBLES 5
 
 typedef struct ssg_config {
     uint32_t struct_size;  /* sizeof(ssg_config), checked by ssg_create */

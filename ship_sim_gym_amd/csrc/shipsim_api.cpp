@@ -109,8 +109,9 @@ struct HullView {
     double nx(int i) const { return pl[SSG_PLANE_DOUBLES * i + 2]; }
     double ny(int i) const { return pl[SSG_PLANE_DOUBLES * i + 3]; }
     double v0n(int i) const { return pl[SSG_PLANE_DOUBLES * i + 4]; }
-    double dtmin(int i) const { return pl[SSG_PLANE_DOUBLES * i + 5]; }
-    double dtmax(int i) const { return pl[SSG_PLANE_DOUBLES * i + 6]; }
+    // cpPolyShapeSegmentQuery's edge extents: cpvcross(n, v[i-1]) and cpvcross(n, v[i])
+    double dtmin(int i) const { const int p = (i - 1 + n) % n; return nx(i) * v0y(p) - ny(i) * v0x(p); }
+    double dtmax(int i) const { return nx(i) * v0y(i) - ny(i) * v0x(i); }
 };
 
 inline double clamp01(double f) { return std::max(0.0, std::min(f, 1.0)); }
@@ -772,7 +773,7 @@ int ssg_host_build_map(const double *left_xy, int n_left, const double *right_xy
         for (size_t i = 0; i < pl.size(); ++i) {
             double *q = pp + SSG_PLANE_DOUBLES * i;
             q[0] = pl[i].v0x; q[1] = pl[i].v0y; q[2] = pl[i].nx; q[3] = pl[i].ny;
-            q[4] = pl[i].v0n; q[5] = pl[i].dtmin; q[6] = pl[i].dtmax;
+            q[4] = pl[i].v0n;
         }
     }
     for (int g = 0; g < n_goals; ++g) {

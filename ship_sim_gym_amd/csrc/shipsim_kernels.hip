@@ -159,10 +159,12 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //   beamtab  [2][16] f64    cos/sin(phi_i)
 //   shiptab  [6][8]  f64    per ship vertex i: local vertex, local plane normal, previous vertex;
 //                           [0][6], [1][6]: the lidar origin of a ship standing at the spawn pose (a reset env)
-//   pose     [6][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y   (role 3 -> roles 0-2)
-//   posem    [EPW] i32      the env's map id
-//   gres     [EPW] u32      colliding (role 2 -> role 3 and the lidar roles)
-//   gdone    [EPW] u32      role 3's share of is_done: no goals left | out of bounds | max_steps (-> the lidar roles)
+//   pose     [9][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y, angle (role 3 -> roles
+//                           0-2, before barrier A); the new frame's nearest goal x, y (role 3 -> role 2, before B)
+//   posem    [EPW] i32      the env's map id;   poser [EPW] i32  its rudder angle after this step's action
+//   gres     [EPW] u32      colliding with a bank (role 2 -> role 3 and the lidar roles)
+//   gdone    [EPW] u32      role 3's share of is_done: bit 0 = no goals left | out of bounds | max_steps, bit 1 = the
+//                           player touches a traffic ship (config 4)   (-> role 2 and the lidar roles)
 //   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
 //   per tile: res [2 parities][NB][64] u64 lidar result keys (step k's results live in parity k & 1; the parity role 3
 //             has just consumed is its transposition buffer for the observation rows), then one (beam, hull) pair
@@ -171,11 +173,11 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 __host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-constexpr int kPoseDoubles = 6;
+constexpr int kPoseDoubles = 9;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
-    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 3 * epw * 4 + (epw / 64) * kGoalScratchBytes;
+    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 4 * epw * 4 + (epw / 64) * kGoalScratchBytes;
 }
 __host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
 __host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
@@ -239,7 +241,15 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
                 pv0x[u] = bank_at<LDS_BANK>(c, q + 0); pv0y[u] = bank_at<LDS_BANK>(c, q + 1);
                 pnx[u] = bank_at<LDS_BANK>(c, q + 2); pny[u] = bank_at<LDS_BANK>(c, q + 3);
                 pv0n[u] = bank_at<LDS_BANK>(c, q + 4);
-                if (EXACT) { pdtmin[u] = bank_at<LDS_BANK>(c, q + 5); pdtmax[u] = bank_at<LDS_BANK>(c, q + 6); }
+                if (EXACT) {
+                    // the edge's extent along the plane: cpvcross(n, v[j-1]) .. cpvcross(n, v[j]); v[j-1] is the
+                    // previous plane's v0 (the last plane's for j = 0)
+                    const int jp = (j == 0) ? cnt - 1 : j - 1;
+                    const int qp = pb + SSG_PLANE_DOUBLES * ((jp >= 0 && jp < SSG_MAX_HULL) ? jp : 0);
+                    const double ux = bank_at<LDS_BANK>(c, qp + 0), uy = bank_at<LDS_BANK>(c, qp + 1);
+                    pdtmin[u] = pnx[u] * uy - pny[u] * ux;
+                    pdtmax[u] = pnx[u] * pv0y[u] - pny[u] * pv0x[u];
+                }
             }
 #pragma unroll
             for (int u = 0; u < kPlaneChunk; ++u) {
@@ -273,7 +283,11 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         if (!EXACT) {
             const int q = pb + SSG_PLANE_DOUBLES * bj;
             const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
-            const double dtmin = bank_at<LDS_BANK>(c, q + 5), dtmax = bank_at<LDS_BANK>(c, q + 6);
+            // the entry edge's extent: cpvcross(n, v[bj-1]) .. cpvcross(n, v[bj])
+            const int jp = (bj == 0) ? cnt - 1 : bj - 1;
+            const int qp = pb + SSG_PLANE_DOUBLES * ((jp >= 0 && jp < SSG_MAX_HULL) ? jp : 0);
+            const double dtmin = nx * bank_at<LDS_BANK>(c, qp + 1) - ny * bank_at<LDS_BANK>(c, qp + 0);
+            const double dtmax = nx * bank_at<LDS_BANK>(c, q + 1) - ny * bank_at<LDS_BANK>(c, q + 0);
             const double t = bd / bden;
             const double omt = 1.0 - t;
             ptx = wcx * omt + ex * t;
@@ -440,20 +454,22 @@ __device__ __forceinline__ void write_obs_tile(double *colbuf, const Val &val /*
 // The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
 //   role 0  LIDAR-lo : LiDAR.query beams [0, NB0)
 //   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB)
-//   role 2  BANKS    : bank-hull narrowphase (collide_ship)
+//   role 2  BANKS+OBS: bank-hull narrowphase (collide_ship); then the observer: sticky-lidar merge and the observation
+//                      rows (__add_states); its registers carry the previous frame from step to step
 //   role 3  BODY     : handle_discrete_action, integrator, ship transform, goal-circle narrowphase, nearest goals,
-//                      reward / done, statistics, sticky-lidar merge, observation and state write-back; its registers
-//                      carry the body state from step to step in a fused rollout
+//                      reward / done, statistics; its registers carry the body state from step to step
 // A lone wave on a SIMD issues FP64 at half rate and runs latency-bound, and 65 536 envs are only one wave per SIMD, so
 // each env's step is cut into four instruction streams on four co-resident waves per SIMD.  They are PIPELINED through
 // LDS with two workgroup barriers per step:
 //   role 3 integrates and publishes the post-step pose                                   -> barrier A(k)
 //   role 2 collides that pose with the banks while role 3 does the goals                 -> barrier B(k)
-//   role 3 closes step k (reward, done, observation rows, state) WHILE roles 0/1 already run step k+1's lidar query:
-//   LiDAR.query sees the pre-step pose, which is step k's post-step pose, or the spawn pose if the env is done — the
-//   lidar roles read role 2's and role 3's done bits after B(k) and decide that themselves.  Results are handed over in
+//   after B(k) three things run side by side: role 3 closes the step (reward, done, statistics, reset) and starts the
+//   next one; role 2 builds and writes the observation rows of step k; roles 0/1 run step k+1's lidar query.
+//   LiDAR.query sees the pre-step pose, which is step k's post-step pose, or the spawn pose if the env is done — roles
+//   0-2 read role 2's and role 3's done bits after B(k) and decide that themselves.  Lidar results are handed over in
 //   LDS buffers indexed by the parity of the step.  (The first step's query runs between A(0) and B(0), from the state
-//   columns.)  Nothing but role 3 touches the state in HBM, so no store of a step has to drain before the next begins.
+//   columns.)  Inside a fused launch the state lives in registers: the state columns in HBM are read by the first step
+//   and written back by the last one only; obs / reward / done / flags are written by every step.
 // ---------------------------------------------------------------------------------------------------------
 template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
@@ -488,9 +504,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [6][EPW]
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [9][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
-    unsigned *gres = reinterpret_cast<unsigned *>(posem + EPW);                              // [EPW]
+    int *poser = posem + EPW;                                                                // [EPW]
+    unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [EPW]
     unsigned *gdone = gres + EPW;                                                            // [EPW]
     char *goal_scratch0 = reinterpret_cast<char *>(gdone + EPW);
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
@@ -587,15 +604,37 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // v_readlane.  The arithmetic of every product and sum is exactly the per-env formulation's; only the min/any
         // reductions over vertices and planes are done with ballots instead of sequential loops.
         // =====================================================================================================
-        if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads(); // barrier 0
+        // The observer's previous frame (ship_env.py:79-113: [x, y, rudder, angle, goal x, goal y, L...]) of the first step =
+        // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
+        constexpr int F = 6 + NB;
+        double pv[F];
+        {
+            const int el = el_;
+            const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
+            const int rud0 = colRud[el], map0 = colMap[el];
+            const unsigned gm0 = c.mask[el];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) pv[6 + i] = colLid[(size_t)i * np + el];
+            pv[0] = x0; pv[1] = y0; pv[2] = (double)rud0; pv[3] = a0;
+            if constexpr (DYN) {
+                // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
+                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el];
+                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el];
+            }
+            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads(); // barrier 0
+            if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
+                nearest_goal<LDS_BANK, false>(c, map0 * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0, x0, y0, pv[4], pv[5]);
+        }
         const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
         const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
+        const bool hist2 = c.history >= 2;
         for (int k = 0; k < K; ++k) {
             __syncthreads(); // barrier A(k)
             SSG_STAMP_K(0);
             const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl], ca = pose[2 * EPW + tl], sa = pose[3 * EPW + tl];
-            const int rec_off = posem[tl] * SSG_MAP_STRIDE;
+            const int map_id = posem[tl];
+            const int rec_off = map_id * SSG_MAP_STRIDE;
             double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], sbl, sbr, sbb, sbt;
             ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
             bool colliding = false;
@@ -677,20 +716,81 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(1);
             __syncthreads(); // barrier B(k)
             SSG_STAMP_K(2);
+
+            // =================================================================================================
+            // The observer: __add_states (ship_env.py:79-113,156) for step k, while role 3 already runs step k+1.
+            // Row = [previous frame | new frame]; for a done env under VecEnv auto-reset, ShipGame.reset + ShipEnv.reset
+            // onto the next bank record: a history of -1, then the spawn frame.  The new frame of this step is the
+            // previous frame of the next one, so the frame (sticky lidar readings included) never leaves registers
+            // inside a fused launch.
+            // =================================================================================================
+            const unsigned gd = gdone[tl];
+            const bool do_reset = auto_reset & (colliding | (gd != 0u));
+            const double ang = pose[6 * EPW + tl];
+            const int rudder = poser[tl];
+            const double nf_gx = pose[7 * EPW + tl], nf_gy = pose[8 * EPW + tl];
+            int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
+            int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
+            asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
+            char *res_k = scratch0 + tile_w * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB);
+            int nmap = map_id + 1;
+            nmap = (nmap >= c.n_maps) ? 0 : nmap;
+            const int map_new = do_reset ? nmap : map_id;
+            const double rs_gx = bank_at<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
+            const double rs_gy = bank_at<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
+            double nv[F];
+            nv[0] = do_reset ? c.spawn_x : x;
+            nv[1] = do_reset ? c.spawn_y : y;
+            nv[2] = do_reset ? 0.0 : (double)rudder;
+            nv[3] = do_reset ? 0.0 : ang;
+            nv[4] = do_reset ? rs_gx : nf_gx;
+            nv[5] = do_reset ? rs_gy : nf_gy;
+            {
+                const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(res_k);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    // smallest key = the first shape in list order that reported a hit (models.py:61-72); a miss keeps
+                    // the previous reading (sticky, models.py:68-72); a fresh episode starts from -1 (models.py:36)
+                    const unsigned long long key = rk[i * 64 + lane];
+                    const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
+                    const double v = (key == kLidarMiss) ? pv[6 + i] : hitd;
+                    nv[6 + i] = do_reset ? -1.0 : v;
+                }
+            }
+            {
+                double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)(F * c.history); // tile start in HBM
+                const int rows_live = min(64, c.n_envs - tile_e0);                             // rows of this tile in range
+                if (!SSG_ABL(7)) {
+                    double *colbuf = reinterpret_cast<double *>(res_k); // (the result keys are in registers by now)
+                    if (hist2)
+                        write_obs_tile<NB, true>(colbuf, [&](int j) -> double {
+                            return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
+                            obase, rows_live, lane);
+                    else
+                        write_obs_tile<NB, false>(colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < F; ++i) pv[i] = nv[i];
+            if (k == K - 1 && live) { // the sticky readings go back to the state columns with the last step
+#pragma unroll
+                for (int i = 0; i < NB; ++i) colLid[(size_t)i * np + el_] = pv[6 + i];
+            }
+            SSG_STAMP_K(3);
         }
-        SSG_STAMP_FLUSH(3);
+        SSG_STAMP_FLUSH(4);
         return;
     }
 
     // =========================================================================================================
     // ROLE 3: the body.  Its registers carry the state from step to step.
     // =========================================================================================================
-    double x, y, vx, vy, ang, w;
+    double x, y, vx, vy, ang, w, cum;
     unsigned gm;
     int map_id, rudder, steps;
     {
         const int el = el_;
-        x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el];
+        x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el]; cum = colCum[el];
         gm = c.mask[el];
         map_id = colMap[el];
         rudder = colRud[el];
@@ -700,22 +800,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     __syncthreads();                             // barrier 0: bank + tables + role 0's initial rotation visible
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
-    double cg_x = 0.0, cg_y = 0.0; // the newest frame's nearest goal, i.e. the next step's older-frame goal
-    const int F = 6 + NB;
-    const bool hist2 = c.history >= 2;
 
     for (int k = 0; k < K; ++k) {
-    // Launder the env index once per step: the per-lane column addresses are loop-invariant, and hoisted out of the
-    // loop they cost ~70 VGPRs of live 64-bit pointers (spilled to scratch at the 128-VGPR budget of a 1024-thread
-    // workgroup); recomputing an address is one v_lshl_add_u64.
     SSG_STAMP_K(0);
+    // Launder the env index once per step: the per-lane addresses are loop-invariant, and hoisted out of the loop they
+    // cost live 64-bit pointers; recomputing an address is one v_lshl_add_u64.
     int el = el_;
     asm volatile("" : "+v"(el));
     const int act = actions_kn[(size_t)k * c.n_envs + el];
     const int rec_off = map_id * SSG_MAP_STRIDE;
     const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
-    const double pf_x = x, pf_y = y, pf_rud = (double)rudder, pf_a = ang; // previous frame = pre-step state
-    const unsigned gm0 = gm;
 
     // ---- handle_discrete_action (game.py:140-153) on the pre-step pose --------------------------------------------
     double fx = 0.0, fy = 0.0, tq = 0.0;
@@ -760,29 +854,22 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
         ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
     }
-    // publish the post-step pose: role 2 collides it now, the lidar roles query from it for the next step
+    // publish the post-step pose: role 2 collides it now and reports it in the observation, the lidar roles query from
+    // it for the next step
     pose[0 * EPW + tl] = x; pose[1 * EPW + tl] = y; pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa;
     pose[4 * EPW + tl] = x + (sbr - sbl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
     pose[5 * EPW + tl] = y + (sbt - sbb) / 2;
+    pose[6 * EPW + tl] = ang;
     posem[tl] = map_id;
+    poser[tl] = rudder;
     SSG_STAMP_K(1);
     __syncthreads(); // barrier A(k)
     SSG_STAMP_K(2);
 
-    // the columns only needed to close the step: requested now, consumed after barrier B (L2 latency under the goals)
-    double cum;
-    double lid[NB];
-    {
-        int el2 = el_;
-        asm volatile("" : "+v"(el2));
-        const bool fresh = k > 0; // rewritten by this wave one step ago: read them from the L2, not this CU's L1
-        cum = ld_f64(colCum + el2, fresh);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) lid[i] = ld_f64(colLid + (size_t)i * np + el2, fresh);
-    }
-
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
+    unsigned dflag = 0;
+    if constexpr (DYN) dflag = c.dyn_flag[el_]; // bit 0: the dyn kernels found the player touching a traffic ship
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -843,37 +930,25 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         goal_reached = gotmask != 0u;
         gm &= ~gotmask;
     }
-    // ---- step_count += 1; role 3's share of is_done (ship_env.py:115-134,152-154), handed to the lidar roles ----
+    // ---- step_count += 1; role 3's share of is_done (ship_env.py:115-134,152-154), handed to roles 0-2 ----
     steps += 1;
     const int steps_after = steps;
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
-    gdone[tl] = done3 ? 1u : 0u;
+    gdone[tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1);
 
-    // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position
+    // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position -> the observer (role 2)
     double nf_gx = 0, nf_gy = 0;
     if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, goff, gm, x, y, nf_gx, nf_gy);
-
-    // previous frame's nearest goal (oldest slot of the 2-frame history): a function of the pre-step state
-    double pf_gx = 0, pf_gy = 0;
-    if constexpr (DYN) {
-        // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
-        pf_gx = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_];
-        pf_gy = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_];
-    } else {
-        // = the nearest goal the previous step put into its new frame; only the first step of a launch computes it
-        if (k == 0) { if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, goff, gm0, pf_x, pf_y, pf_gx, pf_gy); }
-        else { pf_gx = cg_x; pf_gy = cg_y; }
-    }
+    pose[7 * EPW + tl] = nf_gx;
+    pose[8 * EPW + tl] = nf_gy;
 
     SSG_STAMP_K(3);
-    __syncthreads(); // barrier B(k): collide_ship (role 2) and this step's lidar results are complete
+    __syncthreads(); // barrier B(k): collide_ship (role 2) is in
     SSG_STAMP_K(4);
 
     bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
-    unsigned dflag = 0;
     if constexpr (DYN) {
-        dflag = c.dyn_flag[el_];
         colliding |= (dflag & 1u) != 0; // ... and against the traffic ships (dyn kernels)
         if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
     }
@@ -898,63 +973,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         }
         if (goal_reached) atomicAdd(slot + 3, 1ull);
     }
-
-    // ---- observation (ship_env.py:79-113,156): row = [previous frame | new frame]; for a done env under VecEnv
-    //      auto-reset, ShipGame.reset + ShipEnv.reset onto the next bank record: a history of -1, then the spawn frame.
-    //      A lane's row is 8*D bytes and rows of neighbouring envs are adjacent in HBM, so the wave's 64 rows form one
-    //      contiguous tile: it is transposed through LDS (the lidar result buffer of this step's parity, free once the
-    //      results are in registers) and written with 16-byte-per-lane, 1 KiB-per-instruction coalesced stores.
-    //      Scattered 8-byte stores of the same data cost 64 write requests per instruction and dominated the step. ----
-    int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);                 // wave-uniform; laundered like `el`:
-    int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                        // no hoisted tile addresses
-    asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
-    char *res_k = scratch0 + tile_w * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB);
-    double nl[NB];
-    {
-        const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(res_k);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            // smallest key = the first shape in list order that reported a hit (models.py:61-72); none = miss
-            const unsigned long long key = rk[i * 64 + lane];
-            nl[i] = (key == kLidarMiss) ? -1.0 : __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
-        }
-    }
-    SSG_STAMP_K(5);
-    if (do_reset) {
-        map_id = map_id + 1;
-        if (map_id >= c.n_maps) map_id = 0;
-    }
-    const double rs_gx = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
-    const double rs_gy = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
-    {
-        double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)(F * c.history); // tile start in HBM
-        const int rows_live = min(64, c.n_envs - tile_e0);                             // rows of this tile in range
-        // column q of the previous frame (pre-step state, readings before this query) / of the new frame; q is a
-        // constant at every call once the passes are unrolled
-        auto prev_col = [&](int q) -> double {
-            double v = (q == 0) ? pf_x : (q == 1) ? pf_y : (q == 2) ? pf_rud : (q == 3) ? pf_a : (q == 4) ? pf_gx : pf_gy;
-            if (q >= 6) v = lid[(q >= 6) ? q - 6 : 0];
-            return do_reset ? -1.0 : v;
-        };
-        auto new_col = [&](int q) -> double {
-            if (q >= 6) {
-                const int i = (q >= 6) ? q - 6 : 0;
-                const double v = (nl[i] >= 0.0) ? nl[i] : lid[i]; // a miss keeps the previous reading (sticky)
-                return do_reset ? -1.0 : v;
-            }
-            const double a = (q == 0) ? x : (q == 1) ? y : (q == 2) ? (double)rudder : (q == 3) ? ang : (q == 4) ? nf_gx : nf_gy;
-            const double r = (q == 0) ? c.spawn_x : (q == 1) ? c.spawn_y : (q == 4) ? rs_gx : (q == 5) ? rs_gy : 0.0;
-            return do_reset ? r : a;
-        };
-        if (!SSG_ABL(7)) {
-            double *colbuf = reinterpret_cast<double *>(res_k);
-            if (hist2) write_obs_tile<NB, true>(colbuf, [&](int j) -> double { return (j < F) ? prev_col(j) : new_col(j - F); }, obase, rows_live, lane);
-            else write_obs_tile<NB, false>(colbuf, [&](int j) -> double { return new_col(j); }, obase, rows_live, lane);
-        }
-    }
-    SSG_STAMP_K(6);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) lid[i] = do_reset ? -1.0 : ((nl[i] >= 0.0) ? nl[i] : lid[i]);
     if (live) {
         reward_out[el] = rew;
         done_out[el] = done ? 1 : 0;
@@ -968,15 +986,21 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             flags_out[el] = (uint8_t)ev;
         }
     }
+    if (do_reset) { // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
+        map_id = map_id + 1;
+        if (map_id >= c.n_maps) map_id = 0;
+    }
     if constexpr (DYN) {
         if (live) {
             // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
             c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
+            // the newest frame's goal: the next observation's older frame (goals move, so it cannot be recomputed)
+            const double rs_gx = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
+            const double rs_gy = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
             c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = do_reset ? rs_gx : nf_gx;
             c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = do_reset ? rs_gy : nf_gy;
         }
     }
-    if constexpr (!DYN) { cg_x = do_reset ? rs_gx : nf_gx; cg_y = do_reset ? rs_gy : nf_gy; }
     if (do_reset) {
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
         rudder = 0; steps = 0;
@@ -984,16 +1008,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // the pre-step rotation the next step's thrust will read: cpvforangle(0)
         pose[2 * EPW + tl] = 1.0; pose[3 * EPW + tl] = 0.0;
     }
-    if (live) {
+    if (k == K - 1 && live) { // the state goes back to its columns with the last step of the launch
         colX[el] = x; colY[el] = y; colVX[el] = vx; colVY[el] = vy; colA[el] = ang; colW[el] = w; colCum[el] = cum;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) colLid[(size_t)i * np + el] = lid[i];
         colRud[el] = rudder; colStep[el] = steps; colMap[el] = map_id;
         c.mask[el] = (uint8_t)gm;
     }
-    SSG_STAMP_K(7);
+    SSG_STAMP_K(5);
     } // k
-    SSG_STAMP_FLUSH(8);
+    SSG_STAMP_FLUSH(6);
 }
 
 #ifndef SSG_NB_GROUP

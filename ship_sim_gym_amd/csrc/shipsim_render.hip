@@ -56,7 +56,9 @@ __device__ double seg_hull(const double *pl, int n, double ax, double ay, double
         if (t < 0.0 || t > 1.0) continue;
         const double hx = ax + (bx - ax) * t, hy = ay + (by - ay) * t;
         const double dt = nx * hy - ny * hx;
-        if (q[5] <= dt && dt <= q[6] && t < best) best = t;
+        const double *qp = pl + SSG_PLANE_DOUBLES * ((j - 1 + n) % n);
+        const double dtmin = nx * qp[1] - ny * qp[0], dtmax = nx * q[1] - ny * q[0];
+        if (dtmin <= dt && dt <= dtmax && t < best) best = t;
     }
     return best;
 }

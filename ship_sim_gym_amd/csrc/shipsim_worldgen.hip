@@ -138,7 +138,9 @@ __device__ bool segment_query_x(const Hull &h, double ax, double ay, double bx, 
         const double omt = 1.0 - t;
         const double ptx = ax * omt + bx * t, pty = ay * omt + by * t;
         const double dtv = nx * pty - ny * ptx;
-        if (p[5] <= dtv && dtv <= p[6]) {
+        const double *pp = h.pl + SSG_PLANE_DOUBLES * ((i - 1 + h.n) % h.n);       // the edge's start vertex v[i-1]
+        const double dtmin = nx * pp[1] - ny * pp[0], dtmax = nx * p[1] - ny * p[0]; // cpvcross(n, v[i-1]), cpvcross(n, v[i])
+        if (dtmin <= dtv && dtv <= dtmax) {
             hit = true;
             outx = ptx - nx * r2;
             alpha = t;
@@ -223,8 +225,6 @@ __global__ void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, dou
             double *q = pp + SSG_PLANE_DOUBLES * i;
             q[0] = bb.x; q[1] = bb.y; q[2] = rx * inv; q[3] = ry * inv;
             q[4] = q[0] * q[2] + q[1] * q[3];
-            q[5] = q[2] * a.y - q[3] * a.x;
-            q[6] = q[2] * q[1] - q[3] * q[0];
             l = fmin(l, bb.x); r = fmax(r, bb.x); b = fmin(b, bb.y); t = fmax(t, bb.y);
         }
         double *bbp = rec + SSG_MAP_OFF_AABB + 4 * s;

@@ -120,7 +120,8 @@ def test_host_geometry_agrees_with_oracle(native, oracle):
             hull = oracle.convex_hull(polys[s])
             n = int(rec[s])
             assert n == len(hull)
-            pl = rec[native.MAP_OFF_PLANES + s * 12 * 7: native.MAP_OFF_PLANES + s * 12 * 7 + 7 * n].reshape(n, 7)
+            PD = native.PLANE_DOUBLES
+            pl = rec[native.MAP_OFF_PLANES + s * 12 * PD: native.MAP_OFF_PLANES + s * 12 * PD + PD * n].reshape(n, PD)
             np.testing.assert_array_equal(pl[:, :2], hull)
             op = oracle.make_poly(polys[s])
             np.testing.assert_array_equal(pl[:, 2], [op.ln[j].x for j in range(n)])

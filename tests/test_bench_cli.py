@@ -20,7 +20,7 @@ def test_gpus_n_spawns_n_ranks_and_propagates_failure():
                        text=True, timeout=600, env=_env())
     assert p.returncode != 0
     assert "launching 2 ranks" in p.stderr and "torch.distributed.run" in p.stderr
-    assert p.stderr.count("needs device") >= 2      # both ranks ran and both refused
+    assert "needs device" in p.stderr               # a rank ran and refused (torchrun may stop its sibling first)
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
