@@ -417,33 +417,75 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
 // LDS operations of one wave execute in issue order, so no wait separates the passes.  Column stride 73 doubles: the
 // read-back of ~9 rows x CP columns by one wave-instruction then falls on distinct banks.
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, bool H2, class Val>
-__device__ __forceinline__ void write_obs_tile(double *colbuf, const Val &val /* val(j): column j of this lane's row */,
+template <int NB>
+struct ObsTile {
+    static constexpr int FF = 6 + NB;
+    static constexpr int CS = (NB >= 2) ? 73 : 64;  // column stride (doubles)
+    static constexpr int CP = (NB * 64) / CS;       // columns per pass
+    static_assert(CP >= 1 && CP * CS * 8 <= lds_res_bytes(NB), "observation chunk does not fit the lidar result buffer");
+    // Read-back position of this lane's jj-th element of a full pass (element t = lane + 64*jj of the 64 x CP chunk,
+    // row-major): where it sits in the column buffer and where it goes in the tile's rows.  The same for every full pass
+    // and every step, so it is computed once per launch and kept in registers (the pass offset is an immediate).
+    int lds_at[CP]; // (column * CS + row) * 8 bytes... in doubles
+    int row[CP], col[CP];
+    __device__ __forceinline__ void init(int lane)
+    {
+#pragma unroll
+        for (int jj = 0; jj < CP; ++jj) {
+            const int t = lane + 64 * jj;
+            row[jj] = t / CP;
+            col[jj] = t - row[jj] * CP;
+            lds_at[jj] = col[jj] * CS + row[jj];
+        }
+    }
+};
+
+// One range [P_BEGIN, P_END) of the passes of a tile (the observer splits a tile's passes around a workgroup barrier).
+template <int NB, bool H2, int P_BEGIN, int P_END, class Val>
+__device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *colbuf, const Val &val /* val(j): column j of this lane's row */,
                                                double *__restrict__ obase, const int rows_live, const int lane)
 {
     constexpr int FF = 6 + NB;
     constexpr int DH = H2 ? 2 * FF : FF;
-    constexpr int CS = (NB >= 2) ? 73 : 64;  // column stride (doubles)
-    constexpr int CP = (NB * 64) / CS;       // columns per pass
-    static_assert(CP >= 1 && CP * CS * 8 <= lds_res_bytes(NB), "observation chunk does not fit the lidar result buffer");
-    // launder the lane index: the (row, column) index arithmetic below is loop-invariant across the fused steps, and
-    // hoisted out of the step loop its ~3 registers per element are spilled to scratch
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
+    constexpr int CS = ObsTile<NB>::CS, CP = ObsTile<NB>::CP;
+    // Launder the per-launch positions once per call: what is DERIVED from them (byte offsets, 64-bit addresses, one per
+    // pass) is loop-invariant across the fused steps too, and hoisted out of the step loop it is spilled to scratch.
+    int lds_at[CP], gl_at[CP];
+    unsigned okmask = 0;
 #pragma unroll
-    for (int p0 = 0; p0 < DH; p0 += CP) {
+    for (int jj = 0; jj < CP; ++jj) {
+        lds_at[jj] = ot.lds_at[jj];
+        gl_at[jj] = ot.row[jj] * DH + ot.col[jj];
+        okmask |= (ot.row[jj] < rows_live) ? (1u << jj) : 0u;
+        asm volatile("" : "+v"(lds_at[jj]), "+v"(gl_at[jj]));
+    }
+    asm volatile("" : "+v"(okmask));
+#pragma unroll
+    for (int pi = P_BEGIN; pi < P_END; ++pi) {
+        const int p0 = pi * CP;
+        if (p0 >= DH) break;
         const int cpp = (DH - p0 < CP) ? (DH - p0) : CP; // columns of this pass (a constant once unrolled)
 #pragma unroll
         for (int cc = 0; cc < CP; ++cc) {
-            if (cc < cpp) colbuf[cc * CS + ln] = val(p0 + cc); // (computed here, not ahead: registers)
+            if (cc < cpp) colbuf[cc * CS + lane] = val(p0 + cc); // (computed here, not ahead: registers)
         }
+        if (cpp == CP) {
 #pragma unroll
-        for (int jj = 0; jj < CP; ++jj) {
-            if (jj < cpp) {
-                const int t = ln + 64 * jj;  // element t of the 64 x cpp chunk, row-major
-                const int r = t / cpp, cc = t - r * cpp;
-                const double v = colbuf[cc * CS + r];
-                if (r < rows_live) obase[(unsigned)(r * DH + p0 + cc)] = v; // uniform base + 32-bit lane offset
+            for (int jj = 0; jj < CP; ++jj) {
+                const double v = colbuf[lds_at[jj]];
+                if ((okmask >> jj) & 1u) obase[(unsigned)(gl_at[jj] + p0)] = v; // uniform base + 32-bit lane offset
+            }
+        } else { // a shorter last pass (row lengths that are no multiple of CP): positions computed on the spot
+            int ln = lane;
+            asm volatile("" : "+v"(ln)); // (not hoisted out of the step loop: registers)
+#pragma unroll
+            for (int jj = 0; jj < CP; ++jj) {
+                if (jj < cpp) {
+                    const int t = ln + 64 * jj;
+                    const int r = t / cpp, cc = t - r * cpp;
+                    const double v = colbuf[cc * CS + r];
+                    if (r < rows_live) obase[(unsigned)(r * DH + p0 + cc)] = v;
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0); // keep the passes apart: the next pass's values are not computed (and held) early
@@ -451,18 +493,115 @@ __device__ __forceinline__ void write_obs_tile(double *colbuf, const Val &val /*
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// player <-> bank hulls: collide_ship (game.py:232-241) for the 64 envs of a wave.  cpBBIntersects reject, then "closed
+// convex sets intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
+// has every vertex of the other polygon strictly in front.
+// Per lane only the cheap rejects run; the few lanes that pass are then served one at a time by the WHOLE wave: lane
+// L = 5*q + i works on (bank plane q, ship vertex/edge i) of the served env, whose pose is broadcast with v_readlane.
+// The arithmetic of every product and sum is exactly the per-env formulation's; only the min/any reductions over
+// vertices and planes are done with ballots instead of sequential loops.
+// ---------------------------------------------------------------------------------------------------------
+template <bool LDS_BANK>
+__device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *shiptab, const double x, const double y,
+                                                 const double ca, const double sa, const int rec_off, const bool live,
+                                                 const int lane)
+{
+    const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative stage: lane L = 5*q + i
+    const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
+    const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
+    double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], sbl, sbr, sbb, sbt;
+    ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
+    bool colliding = false;
+    unsigned nearbits = 0;
+    int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+        const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
+        const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+        const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
+        const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
+        nearbits |= near ? (1u << s) : 0u;
+        cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
+    }
+    // Stage 1, per lane, all near lanes at once: is some BANK plane a separating axis (all five ship vertices
+    // strictly in front)?  That settles almost every ship that is merely close to a bank; the loop ends as soon
+    // as every near lane of the wave has found its plane.
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bool near_s = (nearbits >> s) & 1u;
+        if (!__any(near_s)) continue;
+        const int cnt = (cnts >> (8 * s)) & 0xFF;
+        bool sep = false;
+        for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
+            const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
+            const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+            const double v0n = bank_at<LDS_BANK>(c, q + 4);
+            bool allfront = j < cnt;
+#pragma unroll
+            for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
+            sep = sep | allfront;
+        }
+        nearbits = sep ? (nearbits & ~(1u << s)) : nearbits;
+    }
+    // Stage 2, wave-cooperative, for the few lanes still unresolved (mostly real collisions): the full SAT over
+    // both polygons' edge normals, lane L = 5*q + i on (bank plane q, ship vertex i) of the served env.
+    unsigned long long todo = __ballot(nearbits != 0u);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
+        const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
+        const int boff = __builtin_amdgcn_readlane(rec_off, src);
+        const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
+        const int bcnts = __builtin_amdgcn_readlane(cnts, src);
+        const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
+        const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
+        const double off_i = snx_ * svx + sny_ * svy;
+        bool col = false;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (!(bnear & (1u << s))) continue; // wave-uniform
+            const int cnt = (bcnts >> (8 * s)) & 0xFF;
+            const bool valid = (lane < 60) & (wq < cnt);
+            const int q = boff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) +
+                          SSG_PLANE_DOUBLES * ((wq < SSG_MAX_HULL) ? wq : 0);
+            const double v0x = bank_at<LDS_BANK>(c, q + 0), v0y = bank_at<LDS_BANK>(c, q + 1);
+            const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+            const double v0n = bank_at<LDS_BANK>(c, q + 4);
+            const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
+            const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
+            const unsigned long long mV = __ballot(valid);
+            const unsigned long long mA = __ballot(valid & frontA);
+            const unsigned long long missB = mV & ~__ballot(valid & frontB);
+            const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
+            // axis = bank plane q: all five (q,i) bits set
+            const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
+            // axis = ship plane i: no valid (q,i) bit missing
+            bool sepB = false;
+#pragma unroll
+            for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB | (((missB >> i) & P) == 0ull);
+            const bool separated = (allA != 0ull) | sepB;
+            col = col | !separated;
+        }
+        colliding = (lane == src) ? col : colliding;
+    }
+    return colliding;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
-//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0)
+//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0); bank-hull narrowphase (collide_ship) of every step but the first
 //   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB)
-//   role 2  BANKS+OBS: bank-hull narrowphase (collide_ship); then the observer: sticky-lidar merge and the observation
-//                      rows (__add_states); its registers carry the previous frame from step to step
+//   role 2  OBSERVER : sticky-lidar merge and the observation rows (__add_states); its registers carry the previous
+//                      frame from step to step; bank-hull narrowphase of the launch's first step
 //   role 3  BODY     : handle_discrete_action, integrator, ship transform, goal-circle narrowphase, nearest goals,
 //                      reward / done, statistics; its registers carry the body state from step to step
 // A lone wave on a SIMD issues FP64 at half rate and runs latency-bound, and 65 536 envs are only one wave per SIMD, so
 // each env's step is cut into four instruction streams on four co-resident waves per SIMD.  They are PIPELINED through
 // LDS with two workgroup barriers per step:
 //   role 3 integrates and publishes the post-step pose                                   -> barrier A(k)
-//   role 2 collides that pose with the banks while role 3 does the goals                 -> barrier B(k)
+//   role 0 (role 2 in the first step) collides that pose with the banks while role 3 does the goals -> barrier B(k)
 //   after B(k) three things run side by side: role 3 closes the step (reward, done, statistics, reset) and starts the
 //   next one; role 2 builds and writes the observation rows of step k; roles 0/1 run step k+1's lidar query.
 //   LiDAR.query sees the pre-step pose, which is step k's post-step pose, or the spawn pose if the env is done — roles
@@ -573,6 +712,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (k == 0)
                 lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first,
                                                  b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
+            else if (role == 0) // collide_ship of this step (role 2 is still writing the previous step's observation rows)
+                gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, pose[0 * EPW + tl], pose[1 * EPW + tl], nca, nsa,
+                                                      nmap * SSG_MAP_STRIDE, live, lane) ? 1u : 0u;
             __syncthreads(); // barrier B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
             if (k + 1 < K) {
@@ -596,13 +738,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     if (role == 2) {
         // =====================================================================================================
-        // ROLE 2: player <-> bank hulls: collide_ship (game.py:232-241).  cpBBIntersects reject, then "closed
-        //         convex sets intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals:
-        //         separated iff some axis has every vertex of the other polygon strictly in front.
-        // Per lane only the cheap rejects run; the few lanes that pass are then served one at a time by the WHOLE wave:
-        // lane L = 5*q + i works on (bank plane q, ship vertex/edge i) of the served env, whose pose is broadcast with
-        // v_readlane.  The arithmetic of every product and sum is exactly the per-env formulation's; only the min/any
-        // reductions over vertices and planes are done with ballots instead of sequential loops.
+        // ROLE 2: collide_ship for the first step of the launch (bank_narrowphase), then the OBSERVER of every step
         // =====================================================================================================
         // The observer's previous frame (ship_env.py:79-113: [x, y, rudder, angle, goal x, goal y, L...]) of the first step =
         // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
@@ -626,93 +762,19 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
                 nearest_goal<LDS_BANK, false>(c, map0 * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0, x0, y0, pv[4], pv[5]);
         }
-        const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
-        const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
         const bool hist2 = c.history >= 2;
+        ObsTile<NB> ot;
+        ot.init(lane);
+        constexpr int kObsPasses = (2 * F + ObsTile<NB>::CP - 1) / ObsTile<NB>::CP; // passes of the widest row
         for (int k = 0; k < K; ++k) {
             __syncthreads(); // barrier A(k)
             SSG_STAMP_K(0);
             const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl], ca = pose[2 * EPW + tl], sa = pose[3 * EPW + tl];
             const int map_id = posem[tl];
             const int rec_off = map_id * SSG_MAP_STRIDE;
-            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], sbl, sbr, sbb, sbt;
-            ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
-            bool colliding = false;
-            unsigned nearbits = 0;
-            int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
-                const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
-                const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
-                const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
-                const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
-                nearbits |= near ? (1u << s) : 0u;
-                cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
-            }
-            // Stage 1, per lane, all near lanes at once: is some BANK plane a separating axis (all five ship vertices
-            // strictly in front)?  That settles almost every ship that is merely close to a bank; the loop ends as soon
-            // as every near lane of the wave has found its plane.
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bool near_s = (nearbits >> s) & 1u;
-                if (!__any(near_s)) continue;
-                const int cnt = (cnts >> (8 * s)) & 0xFF;
-                bool sep = false;
-                for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
-                    const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
-                    const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
-                    const double v0n = bank_at<LDS_BANK>(c, q + 4);
-                    bool allfront = j < cnt;
-#pragma unroll
-                    for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
-                    sep = sep | allfront;
-                }
-                nearbits = sep ? (nearbits & ~(1u << s)) : nearbits;
-            }
-            // Stage 2, wave-cooperative, for the few lanes still unresolved (mostly real collisions): the full SAT over
-            // both polygons' edge normals, lane L = 5*q + i on (bank plane q, ship vertex i) of the served env.
-            unsigned long long todo = __ballot(nearbits != 0u);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const double bx = readlane_f64(x, src), by = readlane_f64(y, src);
-                const double bca = readlane_f64(ca, src), bsa = readlane_f64(sa, src);
-                const int boff = __builtin_amdgcn_readlane(rec_off, src);
-                const unsigned bnear = (unsigned)__builtin_amdgcn_readlane((int)nearbits, src);
-                const int bcnts = __builtin_amdgcn_readlane(cnts, src);
-                const double svx = bca * w_hx + (-bsa) * w_hy + bx, svy = bsa * w_hx + bca * w_hy + by;
-                const double snx_ = bca * w_nx + (-bsa) * w_ny, sny_ = bsa * w_nx + bca * w_ny;
-                const double off_i = snx_ * svx + sny_ * svy;
-                bool col = false;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (!(bnear & (1u << s))) continue; // wave-uniform
-                    const int cnt = (bcnts >> (8 * s)) & 0xFF;
-                    const bool valid = (lane < 60) & (wq < cnt);
-                    const int q = boff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) +
-                                  SSG_PLANE_DOUBLES * ((wq < SSG_MAX_HULL) ? wq : 0);
-                    const double v0x = bank_at<LDS_BANK>(c, q + 0), v0y = bank_at<LDS_BANK>(c, q + 1);
-                    const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
-                    const double v0n = bank_at<LDS_BANK>(c, q + 4);
-                    const bool frontA = (nx * svx + ny * svy) > v0n;           // ship vertex i in front of bank plane q
-                    const bool frontB = (snx_ * v0x + sny_ * v0y) > off_i;     // bank vertex q in front of ship plane i
-                    const unsigned long long mV = __ballot(valid);
-                    const unsigned long long mA = __ballot(valid & frontA);
-                    const unsigned long long missB = mV & ~__ballot(valid & frontB);
-                    const unsigned long long P = 0x0084210842108421ull;       // bit 5q, q = 0..11
-                    // axis = bank plane q: all five (q,i) bits set
-                    const unsigned long long allA = mA & (mA >> 1) & (mA >> 2) & (mA >> 3) & (mA >> 4) & P;
-                    // axis = ship plane i: no valid (q,i) bit missing
-                    bool sepB = false;
-#pragma unroll
-                    for (int i = 0; i < SSG_SHIP_VERTS; ++i) sepB = sepB | (((missB >> i) & P) == 0ull);
-                    const bool separated = (allA != 0ull) | sepB;
-                    col = col | !separated;
-                }
-                colliding = (lane == src) ? col : colliding;
-            }
-            gres[tl] = colliding ? 1u : 0u;
+            // collide_ship: the first step of a launch is collided here (role 0 is busy with that step's lidar query, and
+            // there is no observation backlog yet); every later step by role 0, which idles between A and B then
+            if (k == 0) gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, x, y, ca, sa, rec_off, live, lane) ? 1u : 0u;
             SSG_STAMP_K(1);
             __syncthreads(); // barrier B(k)
             SSG_STAMP_K(2);
@@ -724,8 +786,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // previous frame of the next one, so the frame (sticky lidar readings included) never leaves registers
             // inside a fused launch.
             // =================================================================================================
-            const unsigned gd = gdone[tl];
-            const bool do_reset = auto_reset & (colliding | (gd != 0u));
+            const bool do_reset = auto_reset & ((gres[tl] | gdone[tl]) != 0u);
             const double ang = pose[6 * EPW + tl];
             const int rudder = poser[tl];
             const double nf_gx = pose[7 * EPW + tl], nf_gy = pose[8 * EPW + tl];
@@ -763,11 +824,11 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 if (!SSG_ABL(7)) {
                     double *colbuf = reinterpret_cast<double *>(res_k); // (the result keys are in registers by now)
                     if (hist2)
-                        write_obs_tile<NB, true>(colbuf, [&](int j) -> double {
+                        write_obs_tile<NB, true, 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
                             return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
                             obase, rows_live, lane);
                     else
-                        write_obs_tile<NB, false>(colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
+                        write_obs_tile<NB, false, 0, kObsPasses>(ot, colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
                 }
             }
 #pragma unroll
