@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 4 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
-                             4: map record without dtMin/dtMax (SSG_MAP_STRIDE 145, SSG_PLANE_DOUBLES 5) */
+#define SSG_ABI_VERSION 5 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
+                             4: map record without dtMin/dtMax (SSG_MAP_STRIDE 145, SSG_PLANE_DOUBLES 5);
+                             5: ssg_config.map_ring, ssg_refill_worlds (a brand-new world per episode, generated on the device) */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -113,7 +114,13 @@ typedef struct ssg_config {
     int32_t n_ships;       /* 1 (default), or 4 = the player + ShipGame.add_default_traffic() after every reset
                               (game.py:279-286): goal bodies become dynamic and Chipmunk's contact solver runs for the
                               traffic ships and goals; every step is then two launches (no fused rollout) */
-    int32_t reserved0;
+    int32_t map_ring;      /* 0 (default): envs walk through a shared bank of worlds.  R in 2..64: EVERY EPISODE GETS A BRAND-NEW
+                              WORLD, as ShipGame.reset does (game.py:260-277: gen_level + gen_goal_path at every reset): the bank
+                              holds n_envs * R records, env e owns records [e*R, e*R + R) as a ring, episode p of env e lives
+                              in record e*R + p mod R and is drawn on the device by ssg_refill_worlds from a Philox stream keyed
+                              by (seed, global env id, p).  An (auto-)reset moves the env to its next record; the library
+                              refills the rings between launches (at most R-1 steps are fused into one launch, so an env can
+                              never outrun its ring).  The bank is read from L2/HBM in this mode (it does not fit LDS). */
 } ssg_config;
 
 typedef struct ssg_handle ssg_handle;
@@ -137,6 +144,8 @@ typedef enum ssg_field {
     SSG_F_DYN_FLAGS,    /* u8, n_ships == 4 only: bit 0 = the player touches a traffic ship (input of the step kernel),
                            bit 1 = bodies to be rebuilt after an in-kernel auto-reset, bit 2 = the traffic ships and
                            goal bodies are at rest (their cpSpaceStep is skipped as the identity; inspection only) */
+    SSG_F_EPISODES,     /* i32: episodes this env has started so far (every reset counts; in map_ring mode episode p lives in
+                           bank record e*R + p mod R) */
     SSG_F_COUNT
 } ssg_field;
 
@@ -228,6 +237,17 @@ int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_
  * Call ssg_set_map_bank afterwards (or pass the already-installed bank pointer to refresh it in place). */
 int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *dev_bank, int n_maps, double *dev_raw,
                       void *stream);
+
+/* map_ring mode (ssg_config.map_ring = R >= 2): generate every world the rings are missing — for each env the episodes
+ * from the first one not yet drawn up to (current episode + R - 1) — into the bank installed with ssg_set_map_bank
+ * (n_maps = n_envs * R), on the device: river banks as game_map.gen_river_poly draws them (game_map.py:22-73), hulls /
+ * planes as pm.Poly derives them, goals as gen_goal_path places them (game.py:300-330), Philox4x32-10 keyed by (seed,
+ * env_id_base + e, episode).  Must be called once after ssg_set_map_bank and before the first ssg_reset (it fills the
+ * rings and fixes seed / width_frac for the automatic refills ssg_reset / ssg_step / ssg_rollout issue afterwards).
+ * dev_raw (nullable): [n_envs * R][48 + 3*n_goals] doubles, row e*R + slot receives the raw polygons and goal draws of the
+ * world generated into that slot by THIS call (rows of slots not regenerated are left untouched), so a test can rebuild
+ * the records on the host and compare bit for bit.  NOT seed-compatible with the reference's Mersenne-Twister draws. */
+int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *dev_raw, void *stream);
 
 /* Config 4 only.  The traffic ships and goal bodies of an env whose space has reached a fixed point of cpSpaceStep are
  * not stepped again until something changes (SSG_F_DYN_FLAGS bit 2).  The library sees resets, goal removals and bank

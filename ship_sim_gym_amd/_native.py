@@ -10,14 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSG_LIB_PATH: development override (tools/build_variant.sh builds diagnostic variants next to the product library)
 LIB_PATH = os.environ.get("SSG_LIB_PATH") or os.path.join(_HERE, "libshipsim.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3
 MAP_STRIDE = 145
 MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 5
 FLAG_AUTO_RESET, FLAG_FIX_COLLISION_REWARD, FLAG_BANK_IN_GLOBAL, FLAG_EXACT_LIDAR = 0x1, 0x2, 0x4, 0x8
 EV_COLLIDING, EV_GOAL_REACHED, EV_OUT_OF_BOUNDS, EV_MAX_STEPS, EV_NO_GOALS_LEFT = 0x1, 0x2, 0x4, 0x8, 0x10
 (F_X, F_Y, F_VX, F_VY, F_ANGLE, F_W, F_CUM_REWARD, F_LIDAR, F_RUDDER, F_STEP_COUNT, F_MAP_ID, F_GOAL_MASK,
- F_STATS, F_TRAFFIC, F_GOAL_BODIES, F_DYN_FLAGS) = range(16)
+ F_STATS, F_TRAFFIC, F_GOAL_BODIES, F_DYN_FLAGS, F_EPISODES) = range(17)
 
 # every symbol include/shipsim.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = (
@@ -25,7 +25,7 @@ EXPORTS = (
     "ssg_config_set_ship", "ssg_state_nbytes", "ssg_state_field", "ssg_bind_state", "ssg_set_map_bank", "ssg_reset",
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
-    "ssg_init_state",
+    "ssg_init_state", "ssg_refill_worlds",
 )
 
 
@@ -45,7 +45,7 @@ class Config(C.Structure):
         ("ship_m_inv", C.c_double), ("ship_i_inv", C.c_double), ("force_y", C.c_double),
         ("thrust_px0", C.c_double), ("thrust_py0", C.c_double),
         ("rudder_step", C.c_int32), ("rudder_max", C.c_int32),
-        ("n_ships", C.c_int32), ("reserved0", C.c_int32),
+        ("n_ships", C.c_int32), ("map_ring", C.c_int32),
     ]
 
 
@@ -82,6 +82,7 @@ def lib():
     L.ssg_state_field.argtypes = [vp, C.c_int, szp, ip, ip, szp]
     L.ssg_bind_state.argtypes = [vp, vp]
     L.ssg_init_state.argtypes = [vp, vp]
+    L.ssg_refill_worlds.argtypes = [vp, C.c_uint64, C.c_double, vp, vp]
     L.ssg_set_map_bank.argtypes = [vp, vp, C.c_int]
     L.ssg_reset.argtypes = [vp, vp, vp, vp, vp]
     L.ssg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]

@@ -29,6 +29,13 @@ struct ssg_handle {
     size_t lds_bytes = 0;
     bool prepared = false;
     bool zeroed = false;       // the bound blob is known to have been zeroed by us (ssg_init_state / first full reset)
+    // map_ring mode: the ring's source (fixed by ssg_refill_worlds) and how many more episodes an env may start before the
+    // rings must be refilled (an env consumes at most one world per step or reset)
+    bool ring_ready = false;
+    uint64_t ring_seed = 0;
+    double ring_width_frac = 0.5;
+    int ring_credit = 0;
+    size_t off_ring_queue = 0, off_ring_count = 0;
     bool remap_pending = false; // the bank shrank: ICOL_MAP must be taken modulo n_maps before the next kernel reads it
     std::string err;
 };
@@ -293,6 +300,7 @@ void refresh_dev(ssg_handle *h)
     d.n_goals = c.n_goals;
     d.flags = c.flags;
     d.n_maps = h->n_maps;
+    d.map_ring = c.map_ring;
     d.rudder_step = c.rudder_step;
     d.rudder_max = c.rudder_max;
     d.spread_deg = c.lidar_spread_deg;
@@ -446,6 +454,10 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     if (cfg->max_steps < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: max_steps must be >= 1");
     if (cfg->n_ships != 0 && cfg->n_ships != 1 && cfg->n_ships != 1 + SSG_N_TRAFFIC)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_ships must be 1 or 4 (player + add_default_traffic)");
+    if (cfg->map_ring != 0 && (cfg->map_ring < 2 || cfg->map_ring > 64))
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring must be 0 or in 2..64");
+    if (cfg->map_ring != 0 && cfg->history > 2)
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring needs history <= 2");
     if (cfg->n_ships > 1 && (cfg->flags & SSG_FLAG_EXACT_LIDAR))
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: SSG_FLAG_EXACT_LIDAR is not built for n_ships = 4");
     ssg_handle *h = new (std::nothrow) ssg_handle();
@@ -460,6 +472,12 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     h->off_mask = h->off_i32 + (size_t)ssg::ICOL_COUNT * np * sizeof(int32_t);
     h->off_obs2 = (h->off_mask + np + 255) & ~(size_t)255;
     h->nbytes = (cfg->history > 2) ? h->off_obs2 + np * (size_t)(2 * (6 + cfg->n_beams)) * sizeof(double) : h->off_mask + np;
+    if (cfg->map_ring > 0) { // work queue of the ring refill: (env, episode) pairs + its length
+        h->off_ring_queue = (h->nbytes + 255) & ~(size_t)255;
+        h->off_ring_count = h->off_ring_queue + np * (size_t)cfg->map_ring * sizeof(unsigned long long);
+        h->nbytes = h->off_ring_count + 256;
+        h->cfg.flags |= SSG_FLAG_BANK_IN_GLOBAL; // n_envs * R records never fit LDS
+    }
     if (h->cfg.n_ships > 1) {
         // config 4: columns of the traffic ships, goal bodies and cached arbiters (shipsim_internal.h DC_* / DU_*)
         h->off_dyn_f64 = (h->nbytes + 255) & ~(size_t)255;
@@ -513,6 +531,8 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
         const int c0 = field == SSG_F_TRAFFIC ? ssg::DC_TRAFFIC : ssg::DC_GOALS;
         off = h->off_dyn_f64 + (size_t)c0 * np * 8; es = 8;
         nc = field == SSG_F_TRAFFIC ? 9 * SSG_N_TRAFFIC : ssg::DC_GOAL_COLS * SSG_MAX_GOALS;
+    } else if (field == SSG_F_EPISODES) {
+        off = h->off_i32 + (size_t)ssg::ICOL_EPISODE * np * 4; es = 4; nc = 1;
     } else if (field == SSG_F_DYN_FLAGS) {
         if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
         off = h->off_dyn_flag; es = 1; nc = 1;
@@ -554,6 +574,9 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     if (!h || !dev_bank || n_maps < 1) return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bad argument");
     if (reinterpret_cast<uintptr_t>(dev_bank) % 16 != 0)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
+    if (h->cfg.map_ring > 0 && (long long)n_maps != (long long)h->cfg.n_envs * h->cfg.map_ring)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: map_ring mode needs n_maps == n_envs * map_ring");
+    if (h->cfg.map_ring > 0) h->ring_ready = false; // a new bank: its rings are empty until ssg_refill_worlds
     // Envs per workgroup: start from the size preferred for this env count and halve it until the staged bank fits
     // the CU's LDS beside the lidar scratch; if even 64 does not fit, gather records from L2/HBM instead.
     h->block = pick_block(h->cfg.n_envs);
@@ -570,6 +593,20 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     h->lds_bytes = ssg::step_lds_bytes(h->cfg.n_beams, h->block, h->lds, n_maps);
     h->prepared = false;
     refresh_dev(h);
+    return SSG_OK;
+}
+
+// map_ring mode: draw the worlds the rings are missing and restore the credit of R-1 episode starts per env
+static int ring_refill(ssg_handle *h, double *dev_raw, void *stream)
+{
+    char *base = static_cast<char *>(h->state);
+    hipError_t e = ssg::launch_refill_worlds(h->dev, h->ring_seed, h->ring_width_frac,
+                                             reinterpret_cast<unsigned long long *>(base + h->off_ring_queue),
+                                             reinterpret_cast<unsigned *>(base + h->off_ring_count),
+                                             const_cast<double *>(h->bank), dev_raw, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ring refill launch: ") + hipGetErrorString(e));
+    h->ring_credit = h->cfg.map_ring - 1;
+    h->dyn.bank_epoch++;
     return SSG_OK;
 }
 
@@ -592,6 +629,14 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
     }
     rc = flush_remap(h, stream);
     if (rc != SSG_OK) return rc;
+    if (h->cfg.map_ring > 0) {
+        if (!h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds before the first ssg_reset");
+        if (h->ring_credit < 1) { // a reset starts an episode: make sure every ring still holds an unused world
+            rc = ring_refill(h, nullptr, stream);
+            if (rc != SSG_OK) return rc;
+        }
+        h->ring_credit -= 1;
+    }
     hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
     if (e == hipSuccess && h->cfg.n_ships > 1) // add_default_traffic + fresh goal bodies for the reset envs
         e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, static_cast<hipStream_t>(stream));
@@ -660,6 +705,25 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         }
         return SSG_OK;
     }
+    if (h->cfg.map_ring > 0) {
+        // a brand-new world per episode: an env starts at most one episode per step, and its ring holds `ring_credit`
+        // unused worlds — fuse at most that many steps, then refill the rings (two small launches on the same stream)
+        if (!h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds first");
+        for (int k = 0; k < K;) {
+            if (h->ring_credit < 1) {
+                rc = ring_refill(h, nullptr, stream);
+                if (rc != SSG_OK) return rc;
+            }
+            int kk = (K - k < kFuse) ? (K - k) : kFuse;
+            kk = kk < h->ring_credit ? kk : h->ring_credit;
+            hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,
+                                            dev_obs, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+            h->ring_credit -= kk;
+            k += kk;
+        }
+        return SSG_OK;
+    }
     for (int k = 0; k < K; k += kFuse) {
         const int kk = (K - k < kFuse) ? (K - k) : kFuse;
         hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,
@@ -698,6 +762,19 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("generate_bank launch: ") + hipGetErrorString(e));
     if (dev_bank == h->bank) h->dyn.bank_epoch++; // regenerated in place
     return SSG_OK;
+}
+
+int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *dev_raw, void *stream)
+{
+    int rc = check_ready(h, true);
+    if (rc != SSG_OK) return rc;
+    if (h->cfg.map_ring <= 0) return fail(h, SSG_ERR_BAD_ARG, "ssg_refill_worlds: the handle was not created with map_ring");
+    if (!(width_frac > 0.0) || !(width_frac <= 1.0)) return fail(h, SSG_ERR_BAD_ARG, "ssg_refill_worlds: bad width_frac");
+    h->ring_seed = seed;
+    h->ring_width_frac = width_frac;
+    rc = ring_refill(h, dev_raw, stream);
+    if (rc == SSG_OK) h->ring_ready = true;
+    return rc;
 }
 
 int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream)

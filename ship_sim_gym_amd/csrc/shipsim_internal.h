@@ -14,7 +14,8 @@ namespace ssg {
 // f64 column indices inside the state blob (each column = n_pad doubles, lane-contiguous)
 enum { COL_X = 0, COL_Y, COL_VX, COL_VY, COL_A, COL_W, COL_CUM, COL_LIDAR /* + n_beams columns */ };
 // i32 column indices
-enum { ICOL_RUDDER = 0, ICOL_STEP, ICOL_MAP, ICOL_COUNT };
+enum { ICOL_RUDDER = 0, ICOL_STEP, ICOL_MAP, ICOL_EPISODE /* episodes started so far (map_ring mode) */,
+       ICOL_GEN /* worlds drawn so far for this env's ring */, ICOL_COUNT };
 
 // config 4 (n_ships = 4) f64 columns of the dyn region
 enum {
@@ -44,6 +45,7 @@ struct DevCfg {
     double *obs2;         // [n_envs][2F] staging rows of the step kernel when full_history > 2 (inside the state blob)
     unsigned flags;
     int n_maps;
+    int map_ring;         // 0, or R: env e owns bank records [e*R, e*R + R) as a ring of worlds (one per episode)
     int rudder_step, rudder_max;
     double spread_deg, lidar_dist, goal_r, width, height, dt, damp, spawn_x, spawn_y;
     double hull[2 * SSG_SHIP_VERTS], nrm[2 * SSG_SHIP_VERTS];
@@ -96,6 +98,10 @@ hipError_t launch_remap_map_ids(const DevCfg &c, hipStream_t stream); // ICOL_MA
 hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);
 hipError_t launch_generate_bank(uint64_t seed, int n_maps, int n_goals, double width, double height, double width_frac,
                                 double spawn_x, double spawn_y, double *bank, double *raw, hipStream_t stream);
+// map_ring mode: scan the envs for missing worlds (queue of env << 32 | episode at `queue`, its length at `count`, which
+// the caller zeroed on the stream), then generate them densely; raw: optional per-slot debug rows
+hipError_t launch_refill_worlds(const DevCfg &c, uint64_t seed, double width_frac, unsigned long long *queue, unsigned *count,
+                                double *bank, double *raw, hipStream_t stream);
 hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long env_base, int n, int32_t *out,
                                hipStream_t stream);
 

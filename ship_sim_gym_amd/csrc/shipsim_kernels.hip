@@ -143,6 +143,19 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
     }
 }
 
+// The bank record an env moves to when ShipGame.reset gives it its next world: the next record of the shared bank, or —
+// map_ring mode — the next record of the env's own ring [base, base + R).
+__device__ __forceinline__ int next_map(const DevCfg &c, int map_id)
+{
+    if (c.map_ring > 0) {
+        const int base = map_id - map_id % c.map_ring;
+        const int nxt = map_id + 1;
+        return (nxt - base >= c.map_ring) ? base : nxt;
+    }
+    const int nxt = map_id + 1;
+    return (nxt >= c.n_maps) ? 0 : nxt;
+}
+
 // Beam i of an env whose body rotation is (ca, sa): direction heading + phi_i by the angle-addition identity from
 // host-computed cos/sin(phi_i), endpoint = origin + range * direction.  Owner lanes (culling) and worker lanes
 // (segment query) both call this, so they see the same endpoint bits.
@@ -722,9 +735,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 const bool rs = auto_reset & ((gres[tl] | gdone[tl]) != 0u);
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
-                int nm = nmap + 1;
-                nm = (nm >= c.n_maps) ? 0 : nm;
-                map_id = rs ? nm : nmap;
+                map_id = rs ? next_map(c, nmap) : nmap;
                 lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base + ((k + 1) & 1) * lds_res_bytes(NB)),
                                                  queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
             }
@@ -794,9 +805,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
             asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
             char *res_k = scratch0 + tile_w * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB);
-            int nmap = map_id + 1;
-            nmap = (nmap >= c.n_maps) ? 0 : nmap;
-            const int map_new = do_reset ? nmap : map_id;
+            const int map_new = do_reset ? next_map(c, map_id) : map_id;
             const double rs_gx = bank_at<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
             const double rs_gy = bank_at<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
             double nv[F];
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // =========================================================================================================
     double x, y, vx, vy, ang, w, cum;
     unsigned gm;
-    int map_id, rudder, steps;
+    int map_id, rudder, steps, episodes;
     {
         const int el = el_;
         x = colX[el]; y = colY[el]; vx = colVX[el]; vy = colVY[el]; ang = colA[el]; w = colW[el]; cum = colCum[el];
@@ -856,6 +865,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         map_id = colMap[el];
         rudder = colRud[el];
         steps = colStep[el];
+        episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
     }
     if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
     __syncthreads();                             // barrier 0: bank + tables + role 0's initial rotation visible
@@ -1048,8 +1058,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         }
     }
     if (do_reset) { // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
-        map_id = map_id + 1;
-        if (map_id >= c.n_maps) map_id = 0;
+        map_id = next_map(c, map_id);
+        episodes += 1;
     }
     if constexpr (DYN) {
         if (live) {
@@ -1072,6 +1082,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     if (k == K - 1 && live) { // the state goes back to its columns with the last step of the launch
         colX[el] = x; colY[el] = y; colVX[el] = vx; colVY[el] = vy; colA[el] = ang; colW[el] = w; colCum[el] = cum;
         colRud[el] = rudder; colStep[el] = steps; colMap[el] = map_id;
+        c.i32cols[(size_t)ICOL_EPISODE * np + el] = episodes;
         c.mask[el] = (uint8_t)gm;
     }
     SSG_STAMP_K(5);
@@ -1091,8 +1102,11 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
     if (mask && !mask[e]) return;
     const size_t np = (size_t)c.n_pad;
     int m;
+    const int started = c.i32cols[ICOL_EPISODE * np + e]; // episodes this env has started so far
     if (map_ids) m = (int)((unsigned)map_ids[e] % (unsigned)c.n_maps); // a record index never points outside the bank
+    else if (c.map_ring > 0) m = e * c.map_ring + started % c.map_ring;   // the env's next brand-new world
     else m = (int)((c.env_id_base + (long long)e) % (long long)c.n_maps);
+    c.i32cols[ICOL_EPISODE * np + e] = started + 1;
     const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
     c.f64cols[COL_X * np + e] = c.spawn_x;
     c.f64cols[COL_Y * np + e] = c.spawn_y;

@@ -172,22 +172,13 @@ __device__ bool segment_query_x(const Hull &h, double ax, double ay, double bx, 
     return hit;
 }
 
-} // namespace
 
-// raw: per map [2][12][2] polygon vertices, then per goal (y, u, fallback_x) = 3 doubles  -> 48 + 3*n_goals doubles
-__global__ void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, double width, double height,
-                                     double width_frac, double spawn_x, double spawn_y, double *__restrict__ bank,
-                                     double *__restrict__ raw)
+// One world: ShipGame.reset's gen_level + gen_goal_path (game.py:60-71,300-330) into the record `rec`, from the stream
+// `rng`.  rw (nullable): [2][12][2] polygon vertices, then per goal (y, u, fallback_x) = 3 doubles -> 48 + 3*n_goals.
+__device__ void generate_world(Rng &rng, int n_goals, double width, double height, double width_frac, double spawn_x,
+                               double spawn_y, double *__restrict__ rec, double *__restrict__ rw)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_maps) return;
-    Rng rng;
-    rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32);
-    rng.ctr[0] = (uint32_t)m; rng.ctr[1] = 0x57474e00u /* "WGN" domain tag */; rng.ctr[2] = 0; rng.ctr[3] = 0;
-    rng.have = 0;
-    double *rec = bank + (size_t)m * SSG_MAP_STRIDE;
     for (int i = 0; i < SSG_MAP_STRIDE; ++i) rec[i] = 0.0;
-    double *rw = raw ? raw + (size_t)m * (48 + 3 * n_goals) : nullptr;
 
     // ---- gen_river_poly (game_map.py:22-73) ----
     const int N = 10;
@@ -260,6 +251,93 @@ __global__ void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, dou
     }
     rec[SSG_MAP_OFF_SPAWN_GOAL] = sgx;
     rec[SSG_MAP_OFF_SPAWN_GOAL + 1] = sgy;
+}
+
+} // namespace
+
+// raw: per map 48 + 3*n_goals doubles (generate_world)
+__global__ void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, double width, double height,
+                                     double width_frac, double spawn_x, double spawn_y, double *__restrict__ bank,
+                                     double *__restrict__ raw)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_maps) return;
+    Rng rng;
+    rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32);
+    rng.ctr[0] = (uint32_t)m; rng.ctr[1] = 0x57474e00u /* "WGN" domain tag */; rng.ctr[2] = 0; rng.ctr[3] = 0;
+    rng.have = 0;
+    generate_world(rng, n_goals, width, height, width_frac, spawn_x, spawn_y, bank + (size_t)m * SSG_MAP_STRIDE,
+                   raw ? raw + (size_t)m * (48 + 3 * n_goals) : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// map_ring mode (ssg_config.map_ring = R): every episode of every env gets a brand-new world, as ShipGame.reset draws one
+// at every reset (game.py:260-277).  Episode p of env e lives in bank record e*R + p mod R.  Pass 1 finds, per env, the
+// episodes not yet drawn up to (current episode + R - 1) and queues them (wave-aggregated: one atomic per wave); pass 2
+// draws one world per lane, DENSELY (a world is a ~50 k-instruction sequential chain: scattered over the envs' lanes it
+// would cost every wave the whole chain for the one or two lanes that need it).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void refill_scan_kernel(const DevCfg c, unsigned long long *__restrict__ queue, unsigned *__restrict__ count)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t np = (size_t)c.n_pad;
+    int need = 0, gen = 0;
+    if (e < c.n_envs) {
+        const int started = c.i32cols[(size_t)ICOL_EPISODE * np + e];
+        gen = c.i32cols[(size_t)ICOL_GEN * np + e];
+        const int cur = started > 0 ? started - 1 : 0;
+        need = cur + c.map_ring - gen;
+        need = need < 0 ? 0 : (need > c.map_ring ? c.map_ring : need);
+        if (need) c.i32cols[(size_t)ICOL_GEN * np + e] = gen + need;
+    }
+    // exclusive prefix of `need` over the wave, one atomic per wave
+    const int lane = threadIdx.x & 63;
+    int incl = need;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        incl += (lane >= o) ? v : 0;
+    }
+    const int total = __shfl(incl, 63);
+    unsigned base = 0;
+    if (total && lane == 0) base = atomicAdd(count, (unsigned)total);
+    base = __shfl(base, 0) + (unsigned)(incl - need);
+    for (int i = 0; i < need; ++i) queue[base + i] = ((unsigned long long)(unsigned)e << 32) | (unsigned)(gen + i);
+}
+
+__global__ void refill_gen_kernel(const DevCfg c, uint64_t seed, double width_frac, const unsigned long long *__restrict__ queue,
+                                  const unsigned *__restrict__ count, double *__restrict__ bank, double *__restrict__ raw)
+{
+    const unsigned n = min(*count, (unsigned)c.n_envs * (unsigned)c.map_ring);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long it = queue[i];
+        const int e = (int)(it >> 32);
+        const unsigned episode = (unsigned)it;
+        const unsigned long long gid = (unsigned long long)(c.env_id_base + (long long)e);
+        Rng rng;
+        rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32);
+        rng.ctr[0] = (uint32_t)gid; rng.ctr[1] = 0x52494e47u /* "RING" domain tag */ ^ (uint32_t)(gid >> 32);
+        rng.ctr[2] = 0; rng.ctr[3] = episode;
+        rng.have = 0;
+        const size_t slot = (size_t)e * (size_t)c.map_ring + (size_t)(episode % (unsigned)c.map_ring);
+        generate_world(rng, c.n_goals, c.width, c.height, width_frac, c.spawn_x, c.spawn_y, bank + slot * SSG_MAP_STRIDE,
+                       raw ? raw + slot * (size_t)(48 + 3 * c.n_goals) : nullptr);
+    }
+}
+
+hipError_t launch_refill_worlds(const DevCfg &c, uint64_t seed, double width_frac, unsigned long long *queue, unsigned *count,
+                                double *bank, double *raw, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    const int block = 256;
+    hipLaunchKernelGGL(refill_scan_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), 0, stream, c, queue, count);
+    // one wave per workgroup: a world's chain is long and sequential, spread the (few hundred) waves over all SIMDs
+    const long long max_items = (long long)c.n_envs * c.map_ring;
+    const long long wg = (max_items + 63) / 64;
+    hipLaunchKernelGGL(refill_gen_kernel, dim3((unsigned)(wg < 2048 ? wg : 2048)), dim3(64), 0, stream, c, seed, width_frac, queue,
+                       count, bank, raw);
+    return hipGetLastError();
 }
 
 hipError_t launch_generate_bank(uint64_t seed, int n_maps, int n_goals, double width, double height, double width_frac,

@@ -85,7 +85,7 @@ def test_state_layout_and_unbound_errors(native):
     nbytes = C.c_size_t()
     native.check(L.ssg_state_nbytes(h, C.byref(nbytes)), h)
     n_pad = 1024
-    assert nbytes.value == 256 * 4 * 8 + (7 + 8) * n_pad * 8 + 3 * n_pad * 4 + n_pad
+    assert nbytes.value == 256 * 4 * 8 + (7 + 8) * n_pad * 8 + 5 * n_pad * 4 + n_pad  # 5 i32 columns: rudder, step, map, episodes, worlds drawn
     spans = []
     for fid, es, nc in ((native.F_X, 8, 1), (native.F_W, 8, 1), (native.F_CUM_REWARD, 8, 1), (native.F_LIDAR, 8, 8),
                         (native.F_RUDDER, 4, 1), (native.F_MAP_ID, 4, 1), (native.F_GOAL_MASK, 1, 1)):
