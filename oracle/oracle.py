@@ -50,7 +50,7 @@ VAR_TOUCH_STRICT, VAR_ORDER_REVERSED, VAR_SWAP_AB, VAR_GJK_WARM, VAR_CHECK_SAT, 
 
 
 class Bank(C.Structure):
-    _fields_ = [("n_maps", C.c_int), ("polys", C.POINTER(C.c_double)), ("goals", C.POINTER(C.c_double))]
+    _fields_ = [("n_maps", C.c_int), ("polys", C.POINTER(C.c_double)), ("goals", C.POINTER(C.c_double)), ("ring", C.c_int)]
 
 
 def build(force=False):
@@ -234,11 +234,11 @@ def collide_circle_poly(c, r, poly):
 class Batch:
     """N oracle worlds over a map bank with VecEnv auto-reset; mirrors the HIP path's bank mode."""
 
-    def __init__(self, n, cfg, polys, goals, map_ids=None):
+    def __init__(self, n, cfg, polys, goals, map_ids=None, ring=0):
         self.n, self.cfg = int(n), cfg
         self.polys = np.ascontiguousarray(polys, dtype=np.float64).reshape(-1, 2, 12, 2)
         self.goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(len(self.polys), cfg.n_goals, 2)
-        self.bank = Bank(len(self.polys), _dp(self.polys), _dp(self.goals))
+        self.bank = Bank(len(self.polys), _dp(self.polys), _dp(self.goals), int(ring))
         self.D = (6 + cfg.n_beams) * cfg.history
         self._buf = C.create_string_buffer(lib().ora_world_sizeof() * self.n)
         self._p = C.cast(self._buf, C.c_void_p)

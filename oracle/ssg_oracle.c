@@ -570,6 +570,15 @@ ora_world *ora_world_at(ora_world *ws, int i) { return ws + i; }
  * Batched driver: map bank + auto-reset (VecEnv semantics: a done env is reset in the same call and the
  * returned observation is the reset observation).  Env with map m resets onto map (m+1) mod n_maps.
  * ---------------------------------------------------------------------------------------------- */
+static int next_map(const ora_bank *bank, int map_id)
+{
+    if (bank->ring > 0) {
+        int base = map_id - map_id % bank->ring;
+        return base + (map_id - base + 1) % bank->ring;
+    }
+    return (map_id + 1) % bank->n_maps;
+}
+
 static void reset_from_bank(ora_world *w, const ora_bank *bank, int map_id, double *obs)
 {
     const double *poly = bank->polys + (size_t)map_id * 2 * ORA_MAP_POLY_VERTS * 2;
@@ -603,7 +612,7 @@ void ora_batch_step(ora_world *ws, int n, const ora_bank *bank, const int32_t *a
         done[e] = d;
         if (d && auto_reset) {
             w->episodes++;
-            reset_from_bank(w, bank, (w->map_id + 1) % bank->n_maps, obs + (size_t)e * D);
+            reset_from_bank(w, bank, next_map(bank, w->map_id), obs + (size_t)e * D);
         }
     }
 }
@@ -672,7 +681,7 @@ int64_t ora_rollout(ora_world *ws, int n, const ora_bank *bank, uint64_t seed, i
             done[e] = d;
             if (d) {
                 w->episodes++;
-                reset_from_bank(w, bank, (w->map_id + 1) % bank->n_maps, obs + (size_t)e * D);
+                reset_from_bank(w, bank, next_map(bank, w->map_id), obs + (size_t)e * D);
             }
         }
     }

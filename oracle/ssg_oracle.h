@@ -196,6 +196,8 @@ typedef struct {
     int n_maps;
     const double *polys;  /* [n_maps][2][12][2] */
     const double *goals;  /* [n_maps][n_goals][2] */
+    int ring;             /* 0: an auto-reset moves an env to map (m+1) mod n_maps; R > 0: env e owns maps [e*R, e*R + R) as a
+                             ring, one brand-new world per episode (the HIP path's map_ring mode) */
 } ora_bank;
 
 void ora_batch_reset(ora_world *ws, int n, const ora_config *cfg, const ora_bank *bank, const int32_t *map_ids,

@@ -688,7 +688,15 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         // config 4: every step is the dyn kernel (traffic ships, goal bodies, contact solver) followed by the step
         // kernel, which reads this step's goal positions and the traffic-contact bit it left in the dyn columns.
         const bool shift = h->cfg.history > 2;
+        if (h->cfg.map_ring > 0 && !h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds first");
         for (int k = 0; k < K; ++k) {
+            if (h->cfg.map_ring > 0) { // every step may start one episode per env: keep an unused world in every ring
+                if (h->ring_credit < 1) {
+                    rc = ring_refill(h, nullptr, stream);
+                    if (rc != SSG_OK) return rc;
+                }
+                h->ring_credit -= 1;
+            }
             if (dyn) {
                 hipError_t e = ssg::launch_dyn_step(h->dev, h->dyn, static_cast<hipStream_t>(stream));
                 if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));

@@ -20,6 +20,12 @@ Two map modes:
   next map.  No host involvement per step.
 * ``"fresh"``: reference-exact resets — every reset draws a brand-new world from the global ``random`` /
   ``np.random`` streams on the host (game.py:260-277), one bank slot per env.  Needs a host round trip on done.
+* ``"fresh_device"``: a brand-new world for EVERY episode of every env, like the reference (ShipGame.reset generates a
+  river and a goal path at every reset), but at batch scale and without the host: env e owns a ring of ``ring``
+  bank records, episode p lives in record ``e*ring + p % ring`` and is drawn on the device from a Philox stream keyed
+  by (map_seed, global env id, p) (ssg_config.map_ring / ssg_refill_worlds).  The in-kernel auto-reset moves an env
+  to its next record; the library refills the rings between launches.  Not seed-compatible with the reference's
+  Mersenne-Twister draws (use ``"fresh"`` for that); same geometry code as the host path, bit for bit.
 """
 import ctypes as C
 import math
@@ -95,7 +101,7 @@ class ShipVecEnv(*_BASES):
 
     def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
                  map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
-                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1, rllib=False):
+                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1, rllib=False, ring=32):
         torch = _torch()
         if not torch.cuda.is_available():
             raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -136,7 +142,7 @@ class ShipVecEnv(*_BASES):
         c.damping_pow_dt = math.pow(cfgmod.SPACE_DAMPING, c.dt)   # cpSpaceStep: pow(space.damping, dt)
         c.spawn_x, c.spawn_y = self.bounds[0] / 2, 25.0           # game.py:274
         flags = 0
-        if self.auto_reset and map_mode == "bank":
+        if self.auto_reset and map_mode in ("bank", "fresh_device"):
             flags |= N.FLAG_AUTO_RESET
         if fix_collision_reward:
             flags |= N.FLAG_FIX_COLLISION_REWARD
@@ -149,6 +155,8 @@ class ShipVecEnv(*_BASES):
         # traffic ships, dynamic goal bodies and Chipmunk's contact solver (csrc/shipsim_dynamics.hip)
         c.n_ships = int(n_ships)
         self.n_ships = int(n_ships)
+        self.ring = int(ring) if map_mode == "fresh_device" else 0
+        c.map_ring = self.ring
         self.cfg = c
         self.n_states = 6 + c.n_beams                              # ship_env.py:43
         self.states_history = self.n_states * c.history            # ship_env.py:44
@@ -186,8 +194,15 @@ class ShipVecEnv(*_BASES):
             for e in range(self.num_envs):
                 self._fresh_world(e)
             self.set_bank(self.bank_host)
+        elif map_mode == "fresh_device":
+            with torch.cuda.device(self.device):
+                bank = torch.zeros((self.num_envs * self.ring, N.MAP_STRIDE), dtype=torch.float64, device=self.device)
+            self.bank_polys = self.bank_goals = None
+            self.map_seed = int(map_seed)
+            self.set_bank(bank)
+            self.refill_worlds(self.map_seed)  # fills every ring: episodes 0 .. ring-1 of every env
         else:
-            raise ValueError("map_mode must be 'bank' or 'fresh'")
+            raise ValueError("map_mode must be 'bank', 'fresh' or 'fresh_device'")
         self._pending = None
         self._closed = False
         self._handles = {}
@@ -261,6 +276,27 @@ class ShipVecEnv(*_BASES):
         self.bank_polys = self.bank_goals = None  # host copies no longer describe the bank
         if bank is not self.bank:
             self.set_bank(bank)
+        return raw
+
+    def refill_worlds(self, seed=None, width_frac=None, return_raw=False):
+        """map_mode="fresh_device": draw every world the rings are missing (ssg_refill_worlds) and make (seed, width_frac)
+        the source of the automatic refills from now on — a curriculum lesson change passes the new width here.  With
+        return_raw, returns [num_envs*ring, 48 + 3*n_goals]: rows of the slots drawn by THIS call hold the raw polygons
+        and goal draws (rows of other slots are NaN)."""
+        torch = _torch()
+        if self.map_mode != "fresh_device":
+            raise N.ShipSimError("refill_worlds needs map_mode='fresh_device'")
+        seed = self.map_seed if seed is None else int(seed)
+        self.map_seed = seed
+        if width_frac is not None:
+            self.width_frac = float(width_frac)
+        with torch.cuda.device(self.device):
+            raw = None
+            if return_raw:
+                raw = torch.full((self.num_envs * self.ring, 48 + 3 * self.cfg.n_goals), float("nan"), dtype=torch.float64,
+                                 device=self.device)
+            N.check(N.lib().ssg_refill_worlds(self._h, seed, self.width_frac, C.c_void_p(raw.data_ptr()) if raw is not None else None,
+                                              self._stream()), self._h, "ssg_refill_worlds")
         return raw
 
     def field(self, fid):
@@ -476,6 +512,8 @@ class ShipVecEnv(*_BASES):
             self.bank.copy_(torch.from_numpy(self.bank_host))
             ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
             self.reset_tensor(mask=mask, map_ids=ids)
+        elif self.map_mode == "fresh_device":
+            self.reset_tensor(mask=mask)  # the reset kernel moves the env to the next world of its ring
         else:
             ids = self.field(N.F_MAP_ID).clone()
             ids[index] = (ids[index] + 1) % self.n_maps
@@ -493,12 +531,14 @@ class ShipVecEnv(*_BASES):
                 self._fresh_world(int(e))
             self.bank.copy_(torch.from_numpy(self.bank_host))
             ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+        elif self.map_mode == "fresh_device":
+            ids = None  # the reset kernel moves each env to the next world of its ring
         else:
             ids = self.field(N.F_MAP_ID).clone()
             ids = torch.where(mask != 0, (ids + 1) % self.n_maps, ids).to(torch.int32).contiguous()
         side = torch.empty_like(self.obs)
         with torch.cuda.device(self.device):
-            N.check(N.lib().ssg_reset(self._h, C.c_void_p(mask.data_ptr()), C.c_void_p(ids.data_ptr()),
+            N.check(N.lib().ssg_reset(self._h, C.c_void_p(mask.data_ptr()), C.c_void_p(ids.data_ptr()) if ids is not None else None,
                                       C.c_void_p(side.data_ptr()), self._stream()), self._h, "ssg_reset")
         torch.cuda.current_stream(self.device).synchronize()
         if self._reset_obs_h is None:

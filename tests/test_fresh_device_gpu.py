@@ -1,0 +1,138 @@
+"""map_mode="fresh_device" (ssg_config.map_ring): a brand-new world for every episode of every env, drawn on the device.
+
+Reference behaviour being restored at batch scale: ShipGame.reset generates a new river (gen_level ->
+game_map.gen_river_poly) and a new goal path (gen_goal_path) at EVERY reset (game.py:260-277,60-71,300-330).
+Checked here: (a) every generated record is, bit for bit, what the host geometry builds from the same raw polygons and
+goal draws; (b) the world of (env, episode) depends on (seed, global env id, episode) only — not on the ring size, the
+shard, or when it was drawn; (c) stepping with a small ring (so that the automatic refills and the ring wrap-around are
+exercised many times) matches the oracle walking the same per-env world sequences; (d) fused launches == single steps.
+"""
+import numpy as np
+import pytest
+
+from helpers import oracle_cfg
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+def _vec(n, **kw):
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    return ShipVecEnv(n, map_mode="fresh_device", **kw)
+
+
+def _rebuild(raw_row, bounds=(600.0, 600.0), spawn=(300.0, 25.0), n_goals=5):
+    """host geometry on one slot's raw polygons and goal draws -> (record, polys, goals)"""
+    from ship_sim_gym_amd import worldgen
+    polys = raw_row[:48].reshape(2, 12, 2)
+    bare = worldgen.build_record(polys[0], polys[1], np.zeros((0, 2)), spawn)
+    goals = np.zeros((n_goals, 2))
+    for i in range(n_goals):
+        y, u, fb = raw_row[48 + 3 * i: 51 + 3 * i]
+        hit, lo, hi = worldgen.goal_x_range(bare, bounds[0], y)
+        goals[i] = [lo + (hi - lo) * u if hit else fb, y]
+    return worldgen.build_record(polys[0], polys[1], goals, spawn), polys, goals
+
+
+def test_ring_records_match_host_geometry_and_depend_on_the_key_only(native):
+    import torch
+    n, R = 96, 4
+    v = _vec(n, ring=R, map_seed=77, n_beams=8)
+    raw = v.refill_worlds(return_raw=True).cpu().numpy()   # nothing missing: the constructor filled the rings
+    assert np.all(np.isnan(raw))
+    # a second env with the same seed draws the same rings; capture its raw rows by refilling after construction is
+    # not possible (rings full), so build with another ring size and compare the shared episodes instead
+    big = _vec(n, ring=16, map_seed=77, n_beams=8)
+    b4, b16 = v.bank.cpu().numpy().reshape(n, R, -1), big.bank.cpu().numpy().reshape(n, 16, -1)
+    np.testing.assert_array_equal(b4, b16[:, :R])            # world (env, episode) does not depend on the ring size
+    assert len({b16[e, p, :8].tobytes() for e in range(n) for p in range(16)}) == n * 16   # all worlds differ
+    other = _vec(n, ring=R, map_seed=78, n_beams=8)
+    assert not torch.equal(other.bank, v.bank)
+    # shard: global env ids 40.. on a handle with env_id_base 40 draw the worlds of envs 40.. of the full batch
+    sh = _vec(n - 40, ring=R, map_seed=77, n_beams=8, env_id_base=40)
+    np.testing.assert_array_equal(sh.bank.cpu().numpy().reshape(n - 40, R, -1), b4[40:])
+    # step until worlds have been consumed, refill with raw capture, and rebuild those records on the host
+    v.reset_tensor()
+    acts = v.random_actions(5, 0, 60)
+    v.rollout_tensor(acts)                                  # automatic refills happen inside (ring of 4: every 3 steps)
+    started = v.field(native.F_EPISODES).cpu().numpy()
+    assert started.max() >= 3
+    raw = v.refill_worlds(return_raw=True).cpu().numpy()
+    bank = v.bank.cpu().numpy()
+    drawn = np.nonzero(~np.isnan(raw[:, 0]))[0]
+    assert len(drawn) > 0
+    for slot in drawn:
+        rec, polys, goals = _rebuild(raw[slot])
+        np.testing.assert_array_equal(bank[slot], rec)
+        assert np.all((polys[0, :10, 0] >= 0) & (polys[0, :10, 0] <= 150)) and np.all((polys[1, :10, 0] >= 450) & (polys[1, :10, 0] <= 600))
+    # every ring holds the current episode and the ring-1 next ones of ITS env (compare with the ring-64 generator below)
+    for x in (v, big, other, sh):
+        x.close()
+
+
+@pytest.mark.parametrize("n_ships", [1, 4])
+def test_fresh_device_stepping_matches_oracle(oracle, native, n_ships):
+    """Small ring (4): refills every 3 steps and constant wrap-around.  The oracle walks rings of 64 worlds per env drawn
+    by the same device generator (same keys), so as long as no env starts more than 64 episodes both see the same
+    world sequence."""
+    import torch
+    n, R, K = 160, 4, 260
+    v = _vec(n, ring=R, map_seed=2024, n_beams=10, n_ships=n_ships)
+    gen = _vec(n, ring=64, map_seed=2024, n_beams=10)
+    gb = gen.bank.cpu().numpy()                                                  # [n*64, stride]
+    # polygons are not in the record (only hulls): rebuild the oracle's inputs from the planes' vertices
+    N = native
+    polys = np.zeros((n * 64, 2, 12, 2))
+    for m in range(n * 64):
+        for s in range(2):
+            cnt = int(gb[m, s])
+            pl = gb[m, N.MAP_OFF_PLANES + s * 12 * N.PLANE_DOUBLES: N.MAP_OFF_PLANES + s * 12 * N.PLANE_DOUBLES + cnt * N.PLANE_DOUBLES]
+            hv = pl.reshape(cnt, N.PLANE_DOUBLES)[:, :2]
+            polys[m, s, :cnt] = hv
+            polys[m, s, cnt:] = hv[0]                                            # repeats do not change the hull
+    goals = gb[:, N.MAP_OFF_GOALS: N.MAP_OFF_GOALS + 10].reshape(n * 64, 5, 2)
+    ob = oracle.Batch(n, oracle_cfg(oracle, v), polys, goals, map_ids=np.arange(n) * 64, ring=64)
+    o_ref = ob.reset()
+    o_gpu = v.reset_tensor().cpu().numpy()
+    np.testing.assert_array_equal(o_gpu, o_ref)
+    acts = v.random_actions(9, 0, K)
+    acts_h = acts.cpu().numpy()
+    n_done, worst = 0, 0.0
+    for k in range(K):
+        obs, rew, done, _ = v.step_tensor(acts[k])
+        r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True)
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done flags differ at step %d" % k)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_rew, err_msg="rewards differ at step %d" % k)
+        err = float(np.max(np.abs(obs.cpu().numpy() - r_obs)))
+        assert err <= ATOL, "obs differ by %g at step %d" % (err, k)
+        worst = max(worst, err)
+        n_done += int(r_done.sum())
+    started = v.field(native.F_EPISODES).cpu().numpy()
+    assert n_done > 3 * n and started.max() > R + 2 and started.max() <= 64     # rings wrapped around
+    # the record an env sits on is the one of its current episode
+    np.testing.assert_array_equal(v.field(native.F_MAP_ID).cpu().numpy(), np.arange(n) * R + (started - 1) % R)
+    v.close(); gen.close()
+
+
+def test_fresh_device_fused_rollout_equals_single_steps_and_vecenv_api(native):
+    import torch
+    n = 4096
+    a = _vec(n, ring=8, map_seed=3, n_beams=8)
+    b = _vec(n, ring=8, map_seed=3, n_beams=8)
+    a.reset_tensor(); b.reset_tensor()
+    acts = a.random_actions(11, 0, 90)
+    for k in range(90):
+        a.step_tensor(acts[k])
+    b.rollout_tensor(acts)        # launches of at most 7 fused steps with refills in between
+    torch.cuda.synchronize()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+    assert torch.equal(a.field(native.F_X), b.field(native.F_X)) and torch.equal(a.field(native.F_EPISODES), b.field(native.F_EPISODES))
+    assert torch.equal(a.bank, b.bank) and a.stats() == b.stats()
+    # SB protocol on top: numpy in / out, reset gives every env a world it has not seen
+    before = a.field(native.F_EPISODES).clone()
+    o = a.reset()
+    assert o.shape == (n, 28) and torch.equal(a.field(native.F_EPISODES), before + 1)
+    o, r, d, info = a.step(np.zeros(n, dtype=np.int64))
+    assert o.shape == (n, 28) and r.shape == (n,)
+    a.close(); b.close()
