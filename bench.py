@@ -27,7 +27,8 @@ Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
                   launch stream, against 8 TB/s.  `traffic` is the PMC-measured HBM bytes per env-step of the
                   committed rocprofv3 run (`traffic_source`) scaled to the launch that was timed here.
   other_configs — informational (N=1 only, outside the timed region): BASELINE configs[1] (4 096 envs, 10 beams),
-                  configs[3] (65 536 envs x 4 ships) and the one-launch-per-step (policy-in-the-loop) path.
+                  configs[3] (65 536 envs x 4 ships), the per-GPU share of configs[4], configs[2] with a brand-new world
+                  per episode (map_mode="fresh_device"), and the one-launch-per-step (policy-in-the-loop) path.
   cpu_baseline  — the CPU oracle ("port": our C restatement of the reference path, NOT pymunk) timed on this box's
                   host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -120,10 +121,10 @@ def event_time_rollout(vec, acts, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def side_config(dev, n, n_beams, n_ships, K, W):
+def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank"):
     """Informational timing of another BASELINE config on this GPU (outside the headline's timed region)."""
     from ship_sim_gym_amd.vec_env import ShipVecEnv
-    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships)
+    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships)
     acts = vec.random_actions(12345, 0, K + W)
     vec.reset_tensor()
     vec.rollout_tensor(acts[:W])
@@ -132,7 +133,7 @@ def side_config(dev, n, n_beams, n_ships, K, W):
     us = ms * 1e3 / K
     sps = n * K / (ms * 1e-3)
     vec.close()
-    return {"envs": n, "n_beams": n_beams, "n_ships": n_ships, "steps": K, "us_per_step": us, "env_steps_per_s": sps,
+    return {"envs": n, "n_beams": n_beams, "n_ships": n_ships, "map_mode": map_mode, "steps": K, "us_per_step": us, "env_steps_per_s": sps,
             "algorithmic_bytes_per_env_step": B, "achieved_GBps": sps * B / 1e9, "frac": sps * B / 1e9 / HBM_PEAK_GBPS}
 
 
@@ -313,6 +314,8 @@ def main():
                 other["c2_4096_envs_10_beams"] = side_config(dev, 4096, 10, 1, 1000, 200)
                 other["c4_65536_envs_x4_ships_10_beams"] = side_config(dev, 65536, 10, 4, 200, 200)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
+                # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 32 worlds per env)
+                other["c3_fresh_world_per_episode"] = side_config(dev, 65536, 8, 1, 310, 62, map_mode="fresh_device")
             except Exception as ex:  # informational only: never lose the headline line
                 other["error"] = repr(ex)
         out["other_configs"] = other or None

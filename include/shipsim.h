@@ -262,6 +262,11 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
  * ship_env.py:18); not a hot path. */
 int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream);
 
+/* Inspection aid: how ssg_set_map_bank laid the step kernel out for this handle — envs per workgroup (256, 128 or 64: halved
+ * until the staged bank fits the CU's 160 KiB of LDS beside the exchange and lidar buffers), whether the bank is staged in LDS
+ * (0 = gathered from L2 / HBM) and the dynamic LDS bytes per workgroup. */
+int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int *bank_in_lds, size_t *lds_bytes);
+
 /* Measurement aid (no reference counterpart): coalesced 8-byte-per-lane device copy of n_doubles doubles, the
  * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);

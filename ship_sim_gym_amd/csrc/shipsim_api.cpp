@@ -806,6 +806,15 @@ int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev
     return SSG_OK;
 }
 
+int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int *bank_in_lds, size_t *lds_bytes)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    if (envs_per_workgroup) *envs_per_workgroup = h->block;
+    if (bank_in_lds) *bank_in_lds = h->lds ? 1 : 0;
+    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    return SSG_OK;
+}
+
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream)
 {
     if (!dev_src || !dev_dst) return SSG_ERR_BAD_ARG;

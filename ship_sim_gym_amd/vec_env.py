@@ -299,6 +299,12 @@ class ShipVecEnv(*_BASES):
                                               self._stream()), self._h, "ssg_refill_worlds")
         return raw
 
+    def launch_geometry(self):
+        """(envs per workgroup, bank staged in LDS?, dynamic LDS bytes per workgroup) of the step kernel for this handle."""
+        epw, lds, nb = C.c_int(), C.c_int(), C.c_size_t()
+        N.check(N.lib().ssg_debug_launch_geometry(self._h, C.byref(epw), C.byref(lds), C.byref(nb)), self._h, "geometry")
+        return epw.value, bool(lds.value), nb.value
+
     def field(self, fid):
         """Typed torch view [n_columns, num_envs] (or [num_envs]) into the state blob."""
         torch = _torch()
