@@ -208,6 +208,7 @@ def main():
     n_beams = 10 if c4 else N_BEAMS
     vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams,
                      env_id_base=rank * n, exact_lidar=bool(int(os.environ.get("SSG_EXACT_LIDAR", "0"))),
+                     bank_in_global=bool(int(os.environ.get("SSG_BENCH_BANK_IN_GLOBAL", "0"))),  # experiments only
                      n_ships=4 if c4 else 1)
     if os.environ.get("SSG_ABLATE"):  # timing-only development aid (needs a -DSSG_ABLATION build)
         import ctypes as C

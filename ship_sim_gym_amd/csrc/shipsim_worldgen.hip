@@ -189,15 +189,19 @@ __device__ void generate_world(Rng &rng, int n_goals, double width, double heigh
         const double x_min = s ? width - bank_width : 0.0, x_max = s ? width : bank_width;
         const double centre = x_min + (x_max - x_min); // the reference's x_middle is x_max (game_map.py:48)
         P2 pts[SSG_MAX_HULL], hull[2 * SSG_MAX_HULL];
-        for (int i = 1; i <= N; ++i) {
-            double x, y;
-            int tries = 0;
-            do {
-                x = rng.gauss(centre, 50.0);
-                y = y_start + rng.gauss(y_delta * i, 20.0);
-                ++tries;
-            } while ((x < x_min || x > x_max) && tries < 1000);
-            pts[i - 1] = P2{x, y};
+        // for each vertex: draw (x, y) until x falls inside the bank's strip (at most 1000 tries), game_map.py:52-60.  Half the
+        // candidates are rejected; written as ONE loop over candidates in which every lane advances its own vertex index, a
+        // wave runs max-over-lanes of the TOTAL tries (~60) instead of the sum over vertices of the per-vertex maxima (~140).
+        // Each lane still consumes its stream in exactly the per-vertex order.
+        for (int i = 1, tries = 0; i <= N;) {
+            const double x = rng.gauss(centre, 50.0);
+            const double y = y_start + rng.gauss(y_delta * i, 20.0);
+            ++tries;
+            if (!((x < x_min || x > x_max) && tries < 1000)) {
+                pts[i - 1] = P2{x, y};
+                ++i;
+                tries = 0;
+            }
         }
         pts[N] = P2{s ? width : 0.0, height};
         pts[N + 1] = P2{s ? width : 0.0, 0.0};
