@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long randomized parity soak on the GPU box (not part of the test suite): the HIP path against the oracle over
-millions of env-steps with auto-reset, configs 3 and 4.  Round 1: 12 M + 20 M env-steps, 780 k episode ends, rewards /
-done flags identical, max |obs - oracle| 1.1e-10."""
+millions of env-steps with auto-reset, configs 3 and 4, single-step launches and (round 2) 100-step fused launches of the
+pipelined kernel at the full 65 536 envs.  Round 1: 12 M + 20 M env-steps, 780 k episode ends, rewards / done flags
+identical, max |obs - oracle| 1.1e-10; round 2 (pipelined kernel): the same, plus 26 M env-steps fused."""
 import os
 import sys
 import time
@@ -34,7 +35,33 @@ def soak(n, K, seed=777, **kw):
     vec.close()
 
 
+def soak_fused(n, chunks, seed=99, **kw):
+    """ssg_rollout in launches of 100 fused steps against the oracle stepped 100 times: the last step's outputs and the
+    body state after every launch."""
+    from ship_sim_gym_amd import _native as N
+    vec = ShipVecEnv(n, n_maps=64, **kw)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    acts = vec.random_actions(seed, 0, 100 * chunks)
+    ah = acts.cpu().numpy()
+    worst, t0 = 0.0, time.time()
+    for c in range(chunks):
+        obs, rew, done, flags = vec.rollout_tensor(acts[100 * c: 100 * c + 100])
+        for k in range(100 * c, 100 * c + 100):
+            r_obs, r_rew, r_done = ob.step(ah[k], auto_reset=True, n_threads=O.max_threads())
+        assert np.array_equal(done.cpu().numpy(), r_done), ("done", c)
+        assert np.array_equal(rew.cpu().numpy(), r_rew), ("reward", c)
+        worst = max(worst, float(np.abs(obs.cpu().numpy() - r_obs).max()))
+        pk = ob.peek_all()
+        worst = max(worst, float(np.abs(vec.field(N.F_X).cpu().numpy() - pk[:, 0]).max()), float(np.abs(vec.field(N.F_W).cpu().numpy() - pk[:, 5]).max()))
+        assert np.array_equal(vec.field(N.F_STEP_COUNT).cpu().numpy(), pk[:, 7].astype(np.int32)), ("step_count", c)
+    print(kw, "fused: n=%d, %d launches of 100 steps: max |obs/state - oracle| %.3e, %.1f s" % (n, chunks, worst, time.time() - t0), flush=True)
+    assert worst <= 1e-9
+    vec.close()
+
+
 if __name__ == "__main__":
+    soak_fused(65536, 4, n_beams=8)
     soak(8192, 1500, n_beams=8)
     soak(8192, 1200, n_beams=10, n_ships=4)
     soak(16384, 600, seed=4, n_beams=10, n_ships=4)
