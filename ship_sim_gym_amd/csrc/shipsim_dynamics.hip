@@ -562,7 +562,7 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
 // Everything else is appended to the queue of pass 2.  In steady state that is the few steps after each reset in
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kClassifyThreads = 1024;
+constexpr int kClassifyThreads = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
 __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const DevCfg c, const DynCfg d)
 {
     __shared__ unsigned wg_cnt, wg_base;
