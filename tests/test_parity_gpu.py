@@ -595,3 +595,54 @@ def test_lds_fit_fallbacks_are_exercised_and_exact(torch_cuda, oracle, native):
             v.close()
         finally:
             del os.environ["SSG_BLOCK"]
+
+
+def test_randomised_configuration_sweep(torch_cuda, oracle, native):
+    """Twenty seeded random configurations — beam count 1..16, history 1..3, SPEED, BOUNDS, river width, bank size, env
+    count (ragged), episode length limit, config 4 — stepped against the oracle with single-step launches AND fused
+    launches; every output of every step (single) / the final outputs (fused) must match: done / reward bit-exact,
+    observations within the 1e-5 tolerance."""
+    import random
+    from ship_sim_gym_amd.config import EnvConfig, GameConfig
+    from ship_sim_gym_amd import worldgen
+    rng = random.Random(20261003)
+    worst = 0.0
+    for it in range(20):
+        nb = rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 12, 16])
+        hist = rng.choice([1, 2, 2, 2, 3])
+        speed, bounds = rng.choice([(10, (600, 600)), (30, (1000, 1000)), (40, (1000, 1000)), (20, (600, 600))])
+        n = rng.choice([1, 65, 200, 257, 700, 1025])
+        n_maps = rng.choice([1, 3, 16, 64])
+        n_ships = 4 if (hist <= 2 and nb <= 10 and rng.random() < 0.25) else 1
+        wf = rng.choice([0.5, 0.6, 0.7])
+
+        class G(GameConfig):
+            SPEED = speed
+            BOUNDS = bounds
+
+        class E(EnvConfig):
+            HISTORY_SIZE = hist
+            MAX_STEPS = rng.choice([7, 50, 1000])
+
+        def make():
+            bank, polys, goals = worldgen.build_bank(n_maps, bounds, width_frac=wf, seed=500 + it)
+            v = _vec(n, game_config=G, env_config=E, n_beams=nb, bank=bank, n_ships=n_ships)
+            v.bank_polys, v.bank_goals = polys, goals
+            return v
+        cfgtxt = "it=%d nb=%d hist=%d speed=%d n=%d maps=%d ships=%d wf=%.1f" % (it, nb, hist, speed, n, n_maps, n_ships, wf)
+        v = make()
+        K = 60
+        try:
+            err, n_done = run_pair(oracle, native, v, K=K, seed=it)
+        except AssertionError as ex:
+            raise AssertionError(cfgtxt + ": " + str(ex))
+        worst = max(worst, err)
+        # fused launches from a fresh handle must end where the single steps ended
+        w = make()
+        w.reset_tensor()
+        w.rollout_tensor(w.random_actions(it, 0, K))
+        torch_cuda.cuda.synchronize()
+        assert torch_cuda.equal(w.obs, v.obs) and torch_cuda.equal(w.reward, v.reward) and torch_cuda.equal(w.done, v.done), cfgtxt
+        assert torch_cuda.equal(w.state, v.state), cfgtxt
+        v.close(); w.close()
+    assert worst <= ATOL
