@@ -643,6 +643,13 @@ def test_randomised_configuration_sweep(torch_cuda, oracle, native):
         w.rollout_tensor(w.random_actions(it, 0, K))
         torch_cuda.cuda.synchronize()
         assert torch_cuda.equal(w.obs, v.obs) and torch_cuda.equal(w.reward, v.reward) and torch_cuda.equal(w.done, v.done), cfgtxt
-        assert torch_cuda.equal(w.state, v.state), cfgtxt
+        if n_ships == 1:
+            if not torch_cuda.equal(w.state, v.state):
+                d = (w.state != v.state).nonzero().flatten().cpu().numpy()
+                raise AssertionError("%s: state blobs differ at %d bytes, first offsets %r" % (cfgtxt, len(d), d[:6].tolist()))
+        else:  # (the blob also holds the dyn work queue, whose ORDER depends on the order of the workgroups' atomics)
+            for fid in (native.F_X, native.F_Y, native.F_VX, native.F_VY, native.F_ANGLE, native.F_W, native.F_LIDAR, native.F_RUDDER,
+                        native.F_STEP_COUNT, native.F_MAP_ID, native.F_GOAL_MASK, native.F_TRAFFIC, native.F_GOAL_BODIES, native.F_DYN_FLAGS):
+                assert torch_cuda.equal(w.field(fid), v.field(fid)), (cfgtxt, fid)
         v.close(); w.close()
     assert worst <= ATOL
