@@ -172,12 +172,15 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //   beamtab  [2][16] f64    cos/sin(phi_i)
 //   shiptab  [6][8]  f64    per ship vertex i: local vertex, local plane normal, previous vertex;
 //                           [0][6], [1][6]: the lidar origin of a ship standing at the spawn pose (a reset env)
-//   pose     [9][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y, angle (role 3 -> roles
-//                           0-2, before barrier A); the new frame's nearest goal x, y (role 3 -> role 2, before B)
+//   pose     [7][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y, angle (role 3 -> roles 0-2:
+//                           published under the tile's `ready` word, consumed under its `ack` word, see the kernel)
+//   nfg      [2][2][EPW] f64  the new frame's nearest goal x, y, by step parity (role 3 -> role 2, before barrier B)
 //   posem    [EPW] i32      the env's map id;   poser [EPW] i32  its rudder angle after this step's action
-//   gres     [EPW] u32      colliding with a bank (role 2 -> role 3 and the lidar roles)
-//   gdone    [EPW] u32      role 3's share of is_done: bit 0 = no goals left | out of bounds | max_steps, bit 1 = the
-//                           player touches a traffic ship (config 4)   (-> role 2 and the lidar roles)
+//   gres     [2][EPW] u32   colliding with a bank, by step parity (role 0 / 2 -> role 3, role 2 and the lidar roles)
+//   gdone    [2][EPW] u32   role 3's share of is_done, by step parity: bit 0 = no goals left | out of bounds | max_steps,
+//                           bit 1 = the player touches a traffic ship (config 4)   (-> role 2 and the lidar roles)
+//   sync     [3][EPW/64] u32  per tile: `ready` = number of poses role 3 has published, `ack` = number of pose reads the
+//                           three consumer waves have completed, `bar` = arrivals at the tile's per-step rendezvous
 //   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
 //   per tile: res [2 parities][NB][64] u64 lidar result keys (step k's results live in parity k & 1; the parity role 3
 //             has just consumed is its transposition buffer for the observation rows), then one (beam, hull) pair
@@ -186,11 +189,11 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 __host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-constexpr int kPoseDoubles = 9;
+constexpr int kPoseDoubles = 7 + 4; // pose + the parity-double-buffered nearest goal
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
-    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 4 * epw * 4 + (epw / 64) * kGoalScratchBytes;
+    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 6 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * kGoalScratchBytes;
 }
 __host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
 __host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
@@ -656,12 +659,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [9][EPW]
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [7][EPW]
+    double *nfg = pose + 7 * EPW;                                                            // [2 parities][2][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
     int *poser = posem + EPW;                                                                // [EPW]
-    unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [EPW]
-    unsigned *gdone = gres + EPW;                                                            // [EPW]
-    char *goal_scratch0 = reinterpret_cast<char *>(gdone + EPW);
+    unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
+    unsigned *gdone = gres + 2 * EPW;                                                        // [2 parities][EPW]
+    unsigned *sync_ready = gdone + 2 * EPW;                                                  // [EPW/64]
+    unsigned *sync_ack = sync_ready + EPW / 64;                                              // [EPW/64]
+    unsigned *sync_bar = sync_ack + EPW / 64;                                                // [EPW/64] (+ one pad word each)
+    char *goal_scratch0 = reinterpret_cast<char *>(sync_bar + 2 * (EPW / 64));
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
     char *tile_base = scratch0 + (tl >> 6) * lds_tile_bytes(NB); // this env tile's lidar buffers
 
@@ -692,8 +699,30 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[0 * 8 + 6] = c.spawn_x + (br - bl) / 2;
         shiptab[1 * 8 + 6] = c.spawn_y + (bt - bb) / 2;
     }
+    if (threadIdx.x >= 192 && threadIdx.x < 192 + 4 * (EPW / 64)) sync_ready[threadIdx.x - 192] = 0u; // ready, ack, bar words
     if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
     const bool auto_reset = (c.flags & SSG_FLAG_AUTO_RESET) != 0u;
+    const int tile = tl >> 6;
+    // Pose hand-over, per tile (the four waves of a tile are the only ones that exchange anything): role 3 publishes pose k
+    // once the three consumers have acknowledged pose k-1, and raises `ready` to k+1; a consumer waits for that, copies what it
+    // needs into registers and acknowledges.  Replaces a second workgroup barrier per step, at which role 3 waited ~1.5 k
+    // cycles for the slowest of twelve waves it has no business with.
+    auto wait_pose = [&](int k) {
+        while (__hip_atomic_load(&sync_ready[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(k + 1))
+            __builtin_amdgcn_s_sleep(2);
+    };
+    auto ack_pose = [&]() {
+        if (lane == 0) __hip_atomic_fetch_add(&sync_ack[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // The per-step rendezvous "B" of the tile's four waves (collide_ship, role 3's done bits and nearest goal, and this
+    // step's lidar results are in; the result buffer of the other parity is free): an arrival counter in LDS instead of a
+    // workgroup barrier — the four tiles of a workgroup share nothing but the staged bank, and at s_barrier each waited for
+    // the slowest of the other three twice per step (~2.4 k of a step's 15 k cycles).
+    auto tile_barrier = [&](int k) {
+        if (lane == 0) __hip_atomic_fetch_add(&sync_bar[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&sync_bar[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(k + 1))
+            __builtin_amdgcn_s_sleep(1);
+    };
 
     if (role < 2) {
         // =====================================================================================================
@@ -717,22 +746,23 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             cy = y + (bt - bb) / 2;
         }
         for (int k = 0; k < K; ++k) {
-            __syncthreads(); // barrier A(k): role 3 has published this step's post-step pose
+            wait_pose(k); // role 3 has published this step's post-step pose
             SSG_STAMP_K(0);
             const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
             const double ncx = pose[4 * EPW + tl], ncy = pose[5 * EPW + tl];
+            const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
             const int nmap = posem[tl];
+            ack_pose();
             if (k == 0)
                 lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first,
                                                  b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
             else if (role == 0) // collide_ship of this step (role 2 is still writing the previous step's observation rows)
-                gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, pose[0 * EPW + tl], pose[1 * EPW + tl], nca, nsa,
-                                                      nmap * SSG_MAP_STRIDE, live, lane) ? 1u : 0u;
-            __syncthreads(); // barrier B(k): collide_ship and role 3's done bits are in
+                gres[(k & 1) * EPW + tl] = bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane) ? 1u : 0u;
+            tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
             if (k + 1 < K) {
                 // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
-                const bool rs = auto_reset & ((gres[tl] | gdone[tl]) != 0u);
+                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | gdone[(k & 1) * EPW + tl]) != 0u);
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
                 map_id = rs ? next_map(c, nmap) : nmap;
@@ -778,16 +808,19 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         ot.init(lane);
         constexpr int kObsPasses = (2 * F + ObsTile<NB>::CP - 1) / ObsTile<NB>::CP; // passes of the widest row
         for (int k = 0; k < K; ++k) {
-            __syncthreads(); // barrier A(k)
+            wait_pose(k);
             SSG_STAMP_K(0);
             const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl], ca = pose[2 * EPW + tl], sa = pose[3 * EPW + tl];
+            const double ang = pose[6 * EPW + tl];
+            const int rudder = poser[tl];
             const int map_id = posem[tl];
+            ack_pose();
             const int rec_off = map_id * SSG_MAP_STRIDE;
             // collide_ship: the first step of a launch is collided here (role 0 is busy with that step's lidar query, and
             // there is no observation backlog yet); every later step by role 0, which idles between A and B then
-            if (k == 0) gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, x, y, ca, sa, rec_off, live, lane) ? 1u : 0u;
+            if (k == 0) gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, x, y, ca, sa, rec_off, live, lane) ? 1u : 0u; // (parity 0)
             SSG_STAMP_K(1);
-            __syncthreads(); // barrier B(k)
+            tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
 
             // =================================================================================================
@@ -797,10 +830,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // previous frame of the next one, so the frame (sticky lidar readings included) never leaves registers
             // inside a fused launch.
             // =================================================================================================
-            const bool do_reset = auto_reset & ((gres[tl] | gdone[tl]) != 0u);
-            const double ang = pose[6 * EPW + tl];
-            const int rudder = poser[tl];
-            const double nf_gx = pose[7 * EPW + tl], nf_gy = pose[8 * EPW + tl];
+            const bool do_reset = auto_reset & ((gres[(k & 1) * EPW + tl] | gdone[(k & 1) * EPW + tl]) != 0u);
+            const double nf_gx = nfg[((k & 1) * 2 + 0) * EPW + tl], nf_gy = nfg[((k & 1) * 2 + 1) * EPW + tl];
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
             asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
@@ -925,8 +956,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
         ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
     }
-    // publish the post-step pose: role 2 collides it now and reports it in the observation, the lidar roles query from
-    // it for the next step
+    // publish the post-step pose (once its consumers are done with the previous one): roles 0 / 2 collide it now, role 2
+    // reports it in the observation, the lidar roles query from it for the next step
+    while (__hip_atomic_load(&sync_ack[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 3u * (unsigned)k)
+        __builtin_amdgcn_s_sleep(1);
     pose[0 * EPW + tl] = x; pose[1 * EPW + tl] = y; pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa;
     pose[4 * EPW + tl] = x + (sbr - sbl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
     pose[5 * EPW + tl] = y + (sbt - sbb) / 2;
@@ -934,7 +967,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     posem[tl] = map_id;
     poser[tl] = rudder;
     SSG_STAMP_K(1);
-    __syncthreads(); // barrier A(k)
+    if (lane == 0) __hip_atomic_store(&sync_ready[tile], (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     SSG_STAMP_K(2);
 
     const bool oob_x = (x < 0.0) | (x > c.width);
@@ -1006,19 +1039,19 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const int steps_after = steps;
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
-    gdone[tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1);
+    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1);
 
     // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position -> the observer (role 2)
     double nf_gx = 0, nf_gy = 0;
     if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, goff, gm, x, y, nf_gx, nf_gy);
-    pose[7 * EPW + tl] = nf_gx;
-    pose[8 * EPW + tl] = nf_gy;
+    nfg[((k & 1) * 2 + 0) * EPW + tl] = nf_gx;
+    nfg[((k & 1) * 2 + 1) * EPW + tl] = nf_gy;
 
     SSG_STAMP_K(3);
-    __syncthreads(); // barrier B(k): collide_ship (role 2) is in
+    tile_barrier(k); // rendezvous B(k): collide_ship (role 0 / 2) is in
     SSG_STAMP_K(4);
 
-    bool colliding = gres[tl] != 0u; // collide_ship result (role 2)
+    bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
     if constexpr (DYN) {
         colliding |= (dflag & 1u) != 0; // ... and against the traffic ships (dyn kernels)
         if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
