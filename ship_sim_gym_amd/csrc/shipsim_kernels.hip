@@ -174,11 +174,12 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //                           [0][6], [1][6]: the lidar origin of a ship standing at the spawn pose (a reset env)
 //   pose     [7][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y, angle (role 3 -> roles 0-2:
 //                           published under the tile's `ready` word, consumed under its `ack` word, see the kernel)
-//   nfg      [2][2][EPW] f64  the new frame's nearest goal x, y, by step parity (role 3 -> role 2, before barrier B)
 //   posem    [EPW] i32      the env's map id;   poser [EPW] i32  its rudder angle after this step's action
 //   gres     [2][EPW] u32   colliding with a bank, by step parity (role 0 / 2 -> role 3, role 2 and the lidar roles)
-//   gdone    [2][EPW] u32   role 3's share of is_done, by step parity: bit 0 = no goals left | out of bounds | max_steps,
-//                           bit 1 = the player touches a traffic ship (config 4)   (-> role 2 and the lidar roles)
+//   gdone    [2][EPW] u32   role 3's results of the step, by step parity: bit 0 = no goals left | out of bounds | max_steps,
+//                           bit 1 = the player touches a traffic ship (config 4), bit 7 = set (so the word is never 0 when
+//                           read as "done" only through bits 0-1), bits 8.. = goals still listed after this step
+//                           (-> role 2: reset decision and nearest goal; -> the lidar roles: reset decision)
 //   sync     [3][EPW/64] u32  per tile: `ready` = number of poses role 3 has published, `ack` = number of pose reads the
 //                           three consumer waves have completed, `bar` = arrivals at the tile's per-step rendezvous
 //   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
@@ -189,7 +190,7 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 __host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-constexpr int kPoseDoubles = 7 + 4; // pose + the parity-double-buffered nearest goal
+constexpr int kPoseDoubles = 7;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
@@ -660,7 +661,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
     double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [7][EPW]
-    double *nfg = pose + 7 * EPW;                                                            // [2 parities][2][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
     int *poser = posem + EPW;                                                                // [EPW]
     unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(1);
             if (k + 1 < K) {
                 // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
-                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | gdone[(k & 1) * EPW + tl]) != 0u);
+                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 3u)) != 0u);
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
                 map_id = rs ? next_map(c, nmap) : nmap;
@@ -830,8 +830,11 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // previous frame of the next one, so the frame (sticky lidar readings included) never leaves registers
             // inside a fused launch.
             // =================================================================================================
-            const bool do_reset = auto_reset & ((gres[(k & 1) * EPW + tl] | gdone[(k & 1) * EPW + tl]) != 0u);
-            const double nf_gx = nfg[((k & 1) * 2 + 0) * EPW + tl], nf_gy = nfg[((k & 1) * 2 + 1) * EPW + tl];
+            const unsigned gd = gdone[(k & 1) * EPW + tl];
+            const bool do_reset = auto_reset & ((gres[(k & 1) * EPW + tl] | (gd & 3u)) != 0u);
+            // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
+            double nf_gx = 0, nf_gy = 0;
+            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
             asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
@@ -846,6 +849,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             nv[3] = do_reset ? 0.0 : ang;
             nv[4] = do_reset ? rs_gx : nf_gx;
             nv[5] = do_reset ? rs_gy : nf_gy;
+            if constexpr (DYN) { // the newest frame's goal: the next observation's older frame (goals move: kept in two columns)
+                if (live) {
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = nv[4];
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = nv[5];
+                }
+            }
             {
                 const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(res_k);
 #pragma unroll
@@ -1039,13 +1048,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const int steps_after = steps;
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
-    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1);
-
-    // __add_states (ship_env.py:79-113): nearest remaining goal from the post-step position -> the observer (role 2)
-    double nf_gx = 0, nf_gy = 0;
-    if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, goff, gm, x, y, nf_gx, nf_gy);
-    nfg[((k & 1) * 2 + 0) * EPW + tl] = nf_gx;
-    nfg[((k & 1) * 2 + 1) * EPW + tl] = nf_gy;
+    // (the observer, role 2, finds the new frame's nearest goal among the goals this leaves listed)
+    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | 0x80u | (alive << 8);
 
     SSG_STAMP_K(3);
     tile_barrier(k); // rendezvous B(k): collide_ship (role 0 / 2) is in
@@ -1098,11 +1102,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         if (live) {
             // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
             c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
-            // the newest frame's goal: the next observation's older frame (goals move, so it cannot be recomputed)
-            const double rs_gx = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
-            const double rs_gy = bank_at<LDS_BANK>(c, map_id * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
-            c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = do_reset ? rs_gx : nf_gx;
-            c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = do_reset ? rs_gy : nf_gy;
         }
     }
     if (do_reset) {
