@@ -912,13 +912,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
 
+    int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
     for (int k = 0; k < K; ++k) {
     SSG_STAMP_K(0);
     // Launder the env index once per step: the per-lane addresses are loop-invariant, and hoisted out of the loop they
     // cost live 64-bit pointers; recomputing an address is one v_lshl_add_u64.
     int el = el_;
     asm volatile("" : "+v"(el));
-    const int act = actions_kn[(size_t)k * c.n_envs + el];
+    const int act = act_next;
     const int rec_off = map_id * SSG_MAP_STRIDE;
     const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
 
@@ -1050,6 +1051,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
     // (the observer, role 2, finds the new frame's nearest goal among the goals this leaves listed)
     gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | 0x80u | (alive << 8);
+    if (k + 1 < K) act_next = actions_kn[(size_t)(k + 1) * c.n_envs + el];
 
     SSG_STAMP_K(3);
     tile_barrier(k); // rendezvous B(k): collide_ship (role 0 / 2) is in
