@@ -177,9 +177,10 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //   posem    [EPW] i32      the env's map id;   poser [EPW] i32  its rudder angle after this step's action
 //   gres     [2][EPW] u32   colliding with a bank, by step parity (role 0 / 2 -> role 3, role 2 and the lidar roles)
 //   gdone    [2][EPW] u32   role 3's results of the step, by step parity: bit 0 = no goals left | out of bounds | max_steps,
-//                           bit 1 = the player touches a traffic ship (config 4), bit 7 = set (so the word is never 0 when
-//                           read as "done" only through bits 0-1), bits 8.. = goals still listed after this step
-//                           (-> role 2: reset decision and nearest goal; -> the lidar roles: reset decision)
+//                           bit 1 = the player touches a traffic ship (config 4), bits 2-5 = goal reached, out of bounds,
+//                           max_steps, no goals left, bits 8.. = goals still listed after this step
+//                           (-> role 2: reset decision, reward / done / flags outputs, nearest goal; -> the lidar roles:
+//                           reset decision)
 //   sync     [3][EPW/64] u32  per tile: `ready` = number of poses role 3 has published, `ack` = number of pose reads the
 //                           three consumer waves have completed, `bar` = arrivals at the tile's per-step rendezvous
 //   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
@@ -831,7 +832,25 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // inside a fused launch.
             // =================================================================================================
             const unsigned gd = gdone[(k & 1) * EPW + tl];
-            const bool do_reset = auto_reset & ((gres[(k & 1) * EPW + tl] | (gd & 3u)) != 0u);
+            const bool colliding = (gres[(k & 1) * EPW + tl] != 0u) | ((gd & 2u) != 0u); // collide_ship: a bank, or traffic
+            const bool do_reset = auto_reset & (colliding | ((gd & 1u) != 0u));
+            if (live) {
+                // determine_reward (ship_env.py:62-77) and is_done (ship_env.py:115-134) from role 3's bits, as role 3 does
+                const bool goal_reached = (gd & 4u) != 0u;
+                double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
+                if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;
+                reward_out[el_] = rew;
+                done_out[el_] = (colliding | ((gd & 1u) != 0u)) ? 1 : 0;
+                if (flags_out) {
+                    unsigned ev = 0;
+                    if (colliding) ev |= SSG_EV_COLLIDING;
+                    if (goal_reached) ev |= SSG_EV_GOAL_REACHED;
+                    if (gd & 8u) ev |= SSG_EV_OUT_OF_BOUNDS;
+                    if (gd & 16u) ev |= SSG_EV_MAX_STEPS;
+                    if (gd & 32u) ev |= SSG_EV_NO_GOALS_LEFT;
+                    flags_out[el_] = (uint8_t)ev;
+                }
+            }
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
             double nf_gx = 0, nf_gy = 0;
             if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy);
@@ -1050,7 +1069,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
     // (the observer, role 2, finds the new frame's nearest goal among the goals this leaves listed)
-    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | 0x80u | (alive << 8);
+    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
+                                ((steps_after >= c.max_steps) ? 16u : 0u) | ((alive == 0u) ? 32u : 0u) | (alive << 8);
     if (k + 1 < K) act_next = actions_kn[(size_t)(k + 1) * c.n_envs + el];
 
     SSG_STAMP_K(3);
@@ -1083,19 +1103,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         }
         if (goal_reached) atomicAdd(slot + 3, 1ull);
     }
-    if (live) {
-        reward_out[el] = rew;
-        done_out[el] = done ? 1 : 0;
-        if (flags_out) {
-            unsigned ev = 0;
-            if (colliding) ev |= SSG_EV_COLLIDING;
-            if (goal_reached) ev |= SSG_EV_GOAL_REACHED;
-            if (oob_x | oob_y) ev |= SSG_EV_OUT_OF_BOUNDS;
-            if (steps_after >= c.max_steps) ev |= SSG_EV_MAX_STEPS;
-            if (alive == 0u) ev |= SSG_EV_NO_GOALS_LEFT;
-            flags_out[el] = (uint8_t)ev;
-        }
-    }
+    // (reward / done / flags go to HBM from the observer, which holds the same bits)
     if (do_reset) { // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
         map_id = next_map(c, map_id);
         episodes += 1;
