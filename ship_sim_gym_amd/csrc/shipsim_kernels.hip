@@ -325,6 +325,19 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
     }
 }
 
+// Output stores.  The per-XCD L2s are write-back and not coherent with each other, so the end of a kernel writes every
+// line the kernel dirtied back to the fabric in one burst.  -DSSG_WT (experiment, not kept): write-through (sc1) stores
+// of the same 8 bytes per lane are slower both ways on gfx950: single-step launch 19.7 vs 17.9 us, fused step 8.7 vs 5.6.
+template <class T>
+__device__ __forceinline__ void st_out(T *p, T v)
+{
+#ifdef SSG_WT
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
+
 // Diagnostic stamps (-DSSG_STAMPS builds only; the product kernel executes none): s_memtime at section boundaries,
 // written by lane 0 of every wave to a buffer nothing else reads.
 #ifdef SSG_STAMPS
@@ -340,10 +353,10 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
     do {                                                                                          \
         if (c.dbg && lane == 0) {                                                                 \
             unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (4 * EPW / 64) + (threadIdx.x >> 6)); \
-            for (int k_ = 0; k_ < (n); ++k_) d_[k_] = stamp_[k_];                                 \
+            for (int k_ = 0; k_ < 12; ++k_) d_[k_] = stamp_[k_];  /* 8: kernel start, 9: after barrier 0, 10: role end */ \
         }                                                                                         \
     } while (0)
-#define SSG_STAMP_K(i) do { if (k == K - 2) SSG_STAMP(i); } while (0) /* the second-to-last step of a fused launch */
+#define SSG_STAMP_K(i) do { if (k == (K >= 2 ? K - 2 : 0)) SSG_STAMP(i); } while (0) /* the second-to-last step of a fused launch */
 #else
 #define SSG_STAMP(k) do { } while (0)
 #define SSG_STAMP_K(i) do { } while (0)
@@ -491,7 +504,7 @@ __device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *co
 #pragma unroll
             for (int jj = 0; jj < CP; ++jj) {
                 const double v = colbuf[lds_at[jj]];
-                if ((okmask >> jj) & 1u) obase[(unsigned)(gl_at[jj] + p0)] = v; // uniform base + 32-bit lane offset
+                if ((okmask >> jj) & 1u) st_out(&obase[(unsigned)(gl_at[jj] + p0)], v); // uniform base + 32-bit lane offset
             }
         } else { // a shorter last pass (row lengths that are no multiple of CP): positions computed on the spot
             int ln = lane;
@@ -502,7 +515,7 @@ __device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *co
                     const int t = ln + 64 * jj;
                     const int r = t / cpp, cc = t - r * cpp;
                     const double v = colbuf[cc * CS + r];
-                    if (r < rows_live) obase[(unsigned)(r * DH + p0 + cc)] = v;
+                    if (r < rows_live) st_out(&obase[(unsigned)(r * DH + p0 + cc)], v);
                 }
             }
         }
@@ -617,16 +630,22 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 //                      reward / done, statistics; its registers carry the body state from step to step
 // A lone wave on a SIMD issues FP64 at half rate and runs latency-bound, and 65 536 envs are only one wave per SIMD, so
 // each env's step is cut into four instruction streams on four co-resident waves per SIMD.  They are PIPELINED through
-// LDS with two workgroup barriers per step:
-//   role 3 integrates and publishes the post-step pose                                   -> barrier A(k)
-//   role 0 (role 2 in the first step) collides that pose with the banks while role 3 does the goals -> barrier B(k)
-//   after B(k) three things run side by side: role 3 closes the step (reward, done, statistics, reset) and starts the
-//   next one; role 2 builds and writes the observation rows of step k; roles 0/1 run step k+1's lidar query.
+// LDS.  The four waves of a 64-env TILE exchange data only among themselves, through two per-tile rendezvous words (no
+// workgroup barrier after barrier 0, which publishes the staged bank):
+//   pose hand-over: role 3 integrates and publishes the post-step pose of step k (`sync_ready` = k+1) once its three
+//     consumers have acknowledged pose k-1 (`sync_ack`);
+//   rendezvous B(k) (`sync_bar`): role 0 (role 2 in a launch's first step) has collided that pose with the banks, role 3
+//     has done the goals and its share of is_done, the lidar roles have delivered step k's readings.
+//   After B(k) three things run side by side: role 3 closes the step (statistics, reset) and starts the next one; role 2
+//   writes reward / done / flags and the observation rows of step k; roles 0/1 run step k+1's lidar query.
 //   LiDAR.query sees the pre-step pose, which is step k's post-step pose, or the spawn pose if the env is done — roles
-//   0-2 read role 2's and role 3's done bits after B(k) and decide that themselves.  Lidar results are handed over in
-//   LDS buffers indexed by the parity of the step.  (The first step's query runs between A(0) and B(0), from the state
+//   0-2 read role 0's and role 3's done bits after B(k) and decide that themselves.  Lidar results are handed over in
+//   LDS buffers indexed by the parity of the step.  (The first step's query runs right after barrier 0, from the state
 //   columns.)  Inside a fused launch the state lives in registers: the state columns in HBM are read by the first step
 //   and written back by the last one only; obs / reward / done / flags are written by every step.
+// A single-step launch (K = 1) runs the same code with nothing to overlap: ~6 k cycles of prologue (state columns,
+// 74 KB of bank by LDS-DMA), ~13 k cycles with the four roles sharing the SIMD, a ~10 k-cycle observer tail that is
+// bound by the CU's store path, and the write-back of the ~25 MB it dirtied at the end of the kernel.
 // ---------------------------------------------------------------------------------------------------------
 template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 #ifdef SSG_STAMPS
     unsigned long long stamp_[16] = {};
 #endif
-    SSG_STAMP(0);
+    SSG_STAMP(8);
 
     // small constant tables (written once per workgroup, read after the first barrier)
     if (threadIdx.x < 2 * SSG_MAX_BEAMS)
@@ -741,11 +760,15 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (role == 0) { pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa; } // -> role 3: the first step's thrust direction
             if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
             __syncthreads();                             // barrier 0: bank + tables visible
+            SSG_STAMP(9);
             double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], bl, br, bb, bt;
             ship_world(shiptab, ca, sa, x, y, swx, swy, bl, br, bb, bt);
             cx = x + (br - bl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
             cy = y + (bt - bb) / 2;
         }
+        // the first step's query needs nothing from role 3: it runs while role 3 integrates
+        lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first, b_count,
+                                         cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
         for (int k = 0; k < K; ++k) {
             wait_pose(k); // role 3 has published this step's post-step pose
             SSG_STAMP_K(0);
@@ -754,10 +777,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
             const int nmap = posem[tl];
             ack_pose();
-            if (k == 0)
-                lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first,
-                                                 b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
-            else if (role == 0) // collide_ship of this step (role 2 is still writing the previous step's observation rows)
+            if (k > 0 && role == 0) // collide_ship of this step (role 2 is still writing the previous step's observation rows)
                 gres[(k & 1) * EPW + tl] = bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane) ? 1u : 0u;
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
@@ -772,6 +792,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             }
             SSG_STAMP_K(2);
         }
+        SSG_STAMP(10);
         SSG_STAMP_FLUSH(3);
         return;
     }
@@ -799,10 +820,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el];
                 pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el];
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[i])); // (in registers before barrier 0, as role 3's state)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(pv[6 + i]));
+            if constexpr (DYN) asm volatile("" : "+v"(pv[4]), "+v"(pv[5]));
+            int map0_ = map0; unsigned gm0_ = gm0;
+            asm volatile("" : "+v"(map0_), "+v"(gm0_));
             if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
             __syncthreads(); // barrier 0
+            SSG_STAMP(9);
             if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
-                nearest_goal<LDS_BANK, false>(c, map0 * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0, x0, y0, pv[4], pv[5]);
+                nearest_goal<LDS_BANK, false>(c, map0_ * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0_, pv[0], pv[1], pv[4], pv[5]);
         }
         const bool hist2 = c.history >= 2;
         ObsTile<NB> ot;
@@ -839,8 +868,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 const bool goal_reached = (gd & 4u) != 0u;
                 double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
                 if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;
-                reward_out[el_] = rew;
-                done_out[el_] = (colliding | ((gd & 1u) != 0u)) ? 1 : 0;
+                st_out(&reward_out[el_], rew);
+                st_out(&done_out[el_], (uint8_t)((colliding | ((gd & 1u) != 0u)) ? 1 : 0));
                 if (flags_out) {
                     unsigned ev = 0;
                     if (colliding) ev |= SSG_EV_COLLIDING;
@@ -848,12 +877,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                     if (gd & 8u) ev |= SSG_EV_OUT_OF_BOUNDS;
                     if (gd & 16u) ev |= SSG_EV_MAX_STEPS;
                     if (gd & 32u) ev |= SSG_EV_NO_GOALS_LEFT;
-                    flags_out[el_] = (uint8_t)ev;
+                    st_out(&flags_out[el_], (uint8_t)ev);
                 }
             }
+            SSG_STAMP_K(4);
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
             double nf_gx = 0, nf_gy = 0;
             if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy);
+            SSG_STAMP_K(5);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
             asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
@@ -886,6 +917,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                     nv[6 + i] = do_reset ? -1.0 : v;
                 }
             }
+            SSG_STAMP_K(6);
             {
                 double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)(F * c.history); // tile start in HBM
                 const int rows_live = min(64, c.n_envs - tile_e0);                             // rows of this tile in range
@@ -899,14 +931,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                         write_obs_tile<NB, false, 0, kObsPasses>(ot, colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
                 }
             }
+            SSG_STAMP_K(7);
 #pragma unroll
             for (int i = 0; i < F; ++i) pv[i] = nv[i];
-            if (k == K - 1 && live) { // the sticky readings go back to the state columns with the last step
+            if (k == K - 1 && live && !SSG_ABL(9)) { // the sticky readings go back to the state columns with the last step
 #pragma unroll
-                for (int i = 0; i < NB; ++i) colLid[(size_t)i * np + el_] = pv[6 + i];
+                for (int i = 0; i < NB; ++i) st_out(&colLid[(size_t)i * np + el_], pv[6 + i]);
             }
             SSG_STAMP_K(3);
         }
+        SSG_STAMP(10);
         SSG_STAMP_FLUSH(4);
         return;
     }
@@ -926,12 +960,17 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         steps = colStep[el];
         episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
     }
+    int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
+    // (the state is wanted in registers BEFORE barrier 0, under the bank's staging: left to itself the compiler sinks the
+    // loads below the barrier and the first step starts a memory round trip late)
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(vx), "+v"(vy), "+v"(ang), "+v"(w), "+v"(cum));
+    asm volatile("" : "+v"(gm), "+v"(map_id), "+v"(rudder), "+v"(steps), "+v"(episodes), "+v"(act_next));
     if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
     __syncthreads();                             // barrier 0: bank + tables + role 0's initial rotation visible
+    SSG_STAMP(9);
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
 
-    int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
     for (int k = 0; k < K; ++k) {
     SSG_STAMP_K(0);
     // Launder the env index once per step: the per-lane addresses are loop-invariant, and hoisted out of the loop they
@@ -1121,14 +1160,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // the pre-step rotation the next step's thrust will read: cpvforangle(0)
         pose[2 * EPW + tl] = 1.0; pose[3 * EPW + tl] = 0.0;
     }
-    if (k == K - 1 && live) { // the state goes back to its columns with the last step of the launch
-        colX[el] = x; colY[el] = y; colVX[el] = vx; colVY[el] = vy; colA[el] = ang; colW[el] = w; colCum[el] = cum;
-        colRud[el] = rudder; colStep[el] = steps; colMap[el] = map_id;
-        c.i32cols[(size_t)ICOL_EPISODE * np + el] = episodes;
-        c.mask[el] = (uint8_t)gm;
+    if (k == K - 1 && live && !SSG_ABL(9)) { // the state goes back to its columns with the last step of the launch
+        st_out(&colX[el], x); st_out(&colY[el], y); st_out(&colVX[el], vx); st_out(&colVY[el], vy); st_out(&colA[el], ang);
+        st_out(&colW[el], w); st_out(&colCum[el], cum);
+        st_out(&colRud[el], rudder); st_out(&colStep[el], steps); st_out(&colMap[el], map_id);
+        st_out(&c.i32cols[(size_t)ICOL_EPISODE * np + el], episodes);
+        st_out(&c.mask[el], (uint8_t)gm);
     }
     SSG_STAMP_K(5);
     } // k
+    SSG_STAMP(10);
     SSG_STAMP_FLUSH(6);
 }
 
