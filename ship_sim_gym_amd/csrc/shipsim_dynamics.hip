@@ -576,13 +576,33 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
         const size_t np = col.np;
         const int ng = c.n_goals;
-        const int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
+        // Everything this pass can need is requested at once (one memory round trip instead of five dependent ones:
+        // flag -> masks -> hash -> positions -> angles; the pass was latency-bound at 12.8 us for 65 536 envs).
+        int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
+        unsigned flag = col.flag[e];
+        unsigned gm_raw = c.mask[e];
+        unsigned long long live0 = col.live[e];
+        unsigned long long hash0 = c.dyn_hash[e];
+        double px = c.f64cols[(size_t)COL_X * np + e], py = c.f64cols[(size_t)COL_Y * np + e];
+        double pvx = c.f64cols[(size_t)COL_VX * np + e], pvy = c.f64cols[(size_t)COL_VY * np + e];
+        double pang = c.f64cols[(size_t)COL_A * np + e], pw = c.f64cols[(size_t)COL_W * np + e];
+        double tp[SSG_N_TRAFFIC][3];
+#pragma unroll
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+            const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+            tp[k][0] = t[0]; tp[k][1] = t[np]; tp[k][2] = t[2 * np];
+        }
+        asm volatile("" : "+v"(map_id), "+v"(flag), "+v"(gm_raw), "+v"(live0), "+v"(hash0));
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pvx), "+v"(pvy), "+v"(pang), "+v"(pw));
+#pragma unroll
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]));
         const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
-        const unsigned flag = col.flag[e];
-        if (flag & 2u) dyn_init(c, d, col, e, rec); // the step kernel auto-reset this env at the end of the last step
-        const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
+        if (flag & 2u) { // the step kernel auto-reset this env at the end of the last step
+            dyn_init(c, d, col, e, rec);
+            live0 = 0ull; // (what dyn_init has just written)
+        }
+        const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
         // deferred space.remove of goals the player reached last step (game.py:252): their cached arbiters go too
-        const unsigned long long live0 = col.live[e];
         unsigned long long live = live0;
         for (int g = 0; g < ng; ++g) {
             if ((gmask >> g) & 1u) continue;
@@ -593,31 +613,33 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         }
         if (live != live0) col.live[e] = live;
         // rest bit still valid?  It was established for this bank generation; callers that write the body columns
-        // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).
-        bool rest = ((flag & 6u) == 4u) && (c.dyn_hash[e] == (unsigned long long)d.bank_epoch);
+        // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).  A cached arbiter that left with its goal
+        // was part of the fixed point: the bodies it touched are stepped again.
+        bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) && (live == live0);
         bool hit = false;
         if (rest) {
             // the player's position after its own cpBodyUpdatePosition; its rotation only if some ship is in reach
-            const double ppx = c.f64cols[(size_t)COL_X * np + e] + c.f64cols[(size_t)COL_VX * np + e] * c.dt;
-            const double ppy = c.f64cols[(size_t)COL_Y * np + e] + c.f64cols[(size_t)COL_VY * np + e] * c.dt;
+            const double ppx = px + pvx * c.dt;
+            const double ppy = py + pvy * c.dt;
             bool reach = false;
-            double tp[SSG_N_TRAFFIC][2];
 #pragma unroll
             for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-                const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-                tp[k][0] = t[0]; tp[k][1] = t[np];
                 // No vertex of either hull is further than its hull radius from its body position: beyond the sum the
                 // AABBs cannot meet, whatever the rotations (a conservative pre-reject of cpBBIntersects' exact one)
                 const double dx = tp[k][0] - ppx, dy = tp[k][1] - ppy;
                 reach |= (dx * dx + dy * dy) <= d.reach2[k];
             }
             if (reach) {
-                const ShipShape pl = player_shape(c, e, 0);
+                ShipShape pl; // (same expressions as player_shape())
+                pl.hoff = 0; pl.hashid = 0;
+                pl.p = mk(ppx, ppy);
+                sincos(pang + pw * c.dt, &pl.sa, &pl.ca);
+                pl.cache();
                 for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
                     ShipShape sk;
                     sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
                     sk.p = mk(tp[k][0], tp[k][1]);
-                    sincos(col.f64[(size_t)(DC_TRAFFIC + 9 * k + 2) * np + e], &sk.sa, &sk.ca);
+                    sincos(tp[k][2], &sk.sa, &sk.ca);
                     sk.cache();
                     hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
                 }
