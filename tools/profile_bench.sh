@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2000 --warmup 200 --no-cpu-baseline --no-single-step $*"
+ARGS="--steps 2000 --warmup 200 --no-cpu-baseline --no-single-step --no-other-configs $*"  # every step_kernel dispatch is a 100-step launch of the headline kernel
 # 1. kernel trace + stats (no counters): the same command as the bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 # 2..n: PMC passes, each in its own run, kernel-trace only alongside
