@@ -29,14 +29,14 @@ for r in range(R):
     t0 = b[:, 3, :, 0][:, None, :, None]                             # role 3's loop-top stamp of the same tile
     acc += (b[..., :8] - t0).mean(axis=(0, 2))
 acc /= R
-names3 = ["iter start", "pose published (before A)", "after A", "goals+nearest done (before B)", "after B",
-          "reward/done/outputs/reset done (iteration end)"]
+names3 = ["iter start", "pose ready (acks of pose k-1 in)", "pose published", "goals done, done word written (arrives at B)",
+          "B complete", "statistics / reset done (iteration end)"]
 print("all times in cycles after role 3's iteration start (mean over tiles / workgroups / %d launches)" % R)
 print("role 3 (body):")
 for i, nme in enumerate(names3):
     print("   %-46s %8.0f   (+%.0f)" % (nme, acc[3, i], acc[3, i] - (acc[3, i - 1] if i else 0)))
 for role, nm in ((0, "lidar lo"), (1, "lidar hi")):
-    print("role %d (%s): after A %.0f | after B %.0f | next step's query done %.0f  (query = %.0f cycles)" % (
+    print("role %d (%s): pose copied %.0f | B complete %.0f | next step's query done %.0f  (query = %.0f cycles)" % (
         role, nm, acc[role, 0], acc[role, 1], acc[role, 2], acc[role, 2] - acc[role, 1]))
-print("role 2 (banks + observer): after A %.0f | narrowphase done %.0f (= %.0f cycles) | after B %.0f | obs rows written %.0f (= %.0f cycles)" % (
+print("role 2 (observer): pose copied %.0f | first-step narrowphase slot %.0f (= %.0f cycles) | B complete %.0f | outputs + obs rows written %.0f (= %.0f cycles)" % (
     acc[2, 0], acc[2, 1], acc[2, 1] - acc[2, 0], acc[2, 2], acc[2, 3], acc[2, 3] - acc[2, 2]))
