@@ -353,10 +353,14 @@ __device__ __forceinline__ void st_out(T *p, T v)
     do {                                                                                          \
         if (c.dbg && lane == 0) {                                                                 \
             unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (4 * EPW / 64) + (threadIdx.x >> 6)); \
-            for (int k_ = 0; k_ < 12; ++k_) d_[k_] = stamp_[k_];  /* 8: kernel start, 9: after barrier 0, 10: role end */ \
+            for (int k_ = 0; k_ < 16; ++k_) d_[k_] = stamp_[k_];  /* 8: kernel start, 9: after barrier 0, 10: role end */ \
         }                                                                                         \
     } while (0)
+#ifdef SSG_STAMPS_ITER
+#define SSG_STAMP_K(i) do { } while (0)
+#else
 #define SSG_STAMP_K(i) do { if (k == (K >= 2 ? K - 2 : 0)) SSG_STAMP(i); } while (0) /* the second-to-last step of a fused launch */
+#endif
 #else
 #define SSG_STAMP(k) do { } while (0)
 #define SSG_STAMP_K(i) do { } while (0)
@@ -972,7 +976,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
 
     for (int k = 0; k < K; ++k) {
+#ifdef SSG_STAMPS_ITER
+    if (k < 8) SSG_STAMP(k); // (diagnostic: when does each of a launch's first 8 steps start, and the last one?)
+    if (k == K - 1) SSG_STAMP(11);
+    if (k == 12) SSG_STAMP(12);
+    if (k == 16) SSG_STAMP(13);
+#else
     SSG_STAMP_K(0);
+#endif
     // Launder the env index once per step: the per-lane addresses are loop-invariant, and hoisted out of the loop they
     // cost live 64-bit pointers; recomputing an address is one v_lshl_add_u64.
     int el = el_;
