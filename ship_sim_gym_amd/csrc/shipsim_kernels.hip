@@ -57,11 +57,41 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) // src_la
 // cpvforangle(a) = (cos a, sin a).  Deliberately NOT inlined: inside the fused K-step loop the compiler otherwise hoists
 // the polynomial coefficients of the inlined sincos out of the loop as live VGPR constants and, at the 128-VGPR
 // budget of a 1024-thread workgroup, spills them to scratch and reloads them on the critical path every step.
+//
+// The arithmetic: the library's sincos is ~190 instructions on role 3's chain every step (full-range Payne-Hanek
+// machinery); body angles stay within a few turns, so for |a| <= 2^18 this is a three-term Cody-Waite reduction by pi/2
+// with FMAs (error < 2^-100 |a|) followed by the fdlibm / musl kernels on [-pi/4, pi/4] with the reduction's tail:
+// within 1 ulp of a correctly rounded sin / cos (checked against glibc on 2e7 arguments: 97.6 % identical, the rest
+// 1 ulp), the same class as the library's own result; sincos_call(0) = (0, 1) exactly (cpvforangle(0)).
 __device__ __attribute__((noinline)) double2 sincos_call(double a) // returns (sin a, cos a) in registers
 {
-    double2 r;
-    sincos(a, &r.x, &r.y);
-    return r;
+    double2 o;
+    if (!(fabs(a) <= 262144.0)) { // (also NaN / inf)
+        sincos(a, &o.x, &o.y);
+        return o;
+    }
+    const double k = rint(a * 6.36619772367581382433e-01);
+    const double r1 = fma(-k, 1.57079632679489655800e+00, a);
+    const double r = fma(-k, 6.12323399573676603587e-17, r1);
+    double y = fma(-k, 6.12323399573676603587e-17, r1 - r); // the tail of the reduced argument
+    y = fma(k, 1.4973849048591698e-33, y);                  // pi/2 = HI + MID - 1.497e-33
+    const int n = (int)k;
+    const double z = r * r, w = z * z;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rs = fma(z, fma(z, S4, S3), S2) + z * w * fma(z, S6, S5);
+    const double v = z * r;
+    const double s0 = r - ((z * (0.5 * y - v * rs) - y) - v * S1);
+    const double rc = z * fma(z, fma(z, C3, C2), C1) + w * w * fma(z, fma(z, C6, C5), C4);
+    const double hz = 0.5 * z, ww = 1.0 - hz;
+    const double c0 = ww + (((1.0 - ww) - hz) + (z * rc - r * y));
+    double sn = (n & 1) ? c0 : s0, cs = (n & 1) ? s0 : c0;
+    sn = (n & 2) ? -sn : sn;
+    cs = ((n + 1) & 2) ? -cs : cs;
+    o.x = sn; o.y = cs;
+    return o;
 }
 
 // State loads.  In the fused multi-step loop the columns were rewritten by another wave of this workgroup one
@@ -175,7 +205,8 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //   pose     [7][EPW] f64   this step's post-step pose: x, y, cos a, sin a, lidar origin x, y, angle (role 3 -> roles 0-2:
 //                           published under the tile's `ready` word, consumed under its `ack` word, see the kernel)
 //   posem    [EPW] i32      the env's map id;   poser [EPW] i32  its rudder angle after this step's action
-//   gres     [2][EPW] u32   colliding with a bank, by step parity (role 0 / 2 -> role 3, role 2 and the lidar roles)
+//   gres     [2][EPW] u32   colliding with a bank, by step parity: low half-word = the left bank (role 0), high = the right
+//                           one (role 1); role 2 writes the word in a launch's first step (-> role 3, role 2, the lidar roles)
 //   gdone    [2][EPW] u32   role 3's results of the step, by step parity: bit 0 = no goals left | out of bounds | max_steps,
 //                           bit 1 = the player touches a traffic ship (config 4), bits 2-5 = goal reached, out of bounds,
 //                           max_steps, no goals left, bits 8.. = goals still listed after this step
@@ -245,6 +276,8 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         const int cnt = (int)bank_at<LDS_BANK>(c, woff + SSG_MAP_OFF_COUNTS + s);
         const int pb = woff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
         bool outside = false; // cpPolyShapePointQuery(a): some plane has a strictly in front
+        bool out_sure = false, maybe = false;
+        constexpr double kSignEps = 1e-9;
         bool ok = false;
         double ptx = ex, pty = ey;
         double bd = -1.0, bden = 1.0;
@@ -256,7 +289,7 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             for (int u = 0; u < kPlaneChunk; ++u) { // all LDS reads of the chunk first: one latency per chunk
                 const int j = j0 + u;
                 const int q = pb + SSG_PLANE_DOUBLES * ((j < SSG_MAX_HULL) ? j : 0); // independent of cnt: no LDS round trip in between
-                pv0x[u] = bank_at<LDS_BANK>(c, q + 0); pv0y[u] = bank_at<LDS_BANK>(c, q + 1);
+                if (EXACT) { pv0x[u] = bank_at<LDS_BANK>(c, q + 0); pv0y[u] = bank_at<LDS_BANK>(c, q + 1); }
                 pnx[u] = bank_at<LDS_BANK>(c, q + 2); pny[u] = bank_at<LDS_BANK>(c, q + 3);
                 pv0n[u] = bank_at<LDS_BANK>(c, q + 4);
                 if (EXACT) {
@@ -273,10 +306,18 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             for (int u = 0; u < kPlaneChunk; ++u) {
                 const int j = j0 + u;
                 const bool valid = act & (j < cnt);
-                const double v0x = pv0x[u], v0y = pv0y[u], nx = pnx[u], ny = pny[u], v0n = pv0n[u];
-                outside = outside | (valid & ((nx * (wcx - v0x) + ny * (wcy - v0y)) > 0.0));
+                const double nx = pnx[u], ny = pny[u], v0n = pv0n[u];
                 const double an = wcx * nx + wcy * ny;
                 const double d = an - v0n;
+                if (EXACT) {
+                    outside = outside | (valid & ((nx * (wcx - pv0x[u]) + ny * (wcy - pv0y[u])) > 0.0));
+                } else {
+                    // cpPolyShapePointQuery's sign test cpvdot(n, a - v0) > 0 differs from d = a.n - v0.n by rounding only
+                    // (< 1e-12 at these magnitudes): beyond kSignEps it is decided by d; closer, by the exact expression
+                    // in the rare pass below (two fewer LDS gathers per plane)
+                    out_sure = out_sure | (valid & (d > kSignEps));
+                    maybe = maybe | (valid & !(d < -kSignEps));
+                }
                 const bool front = valid & !(d < 0.0);
                 const double bn = ex * nx + ey * ny;
                 const double den = dmax(an - bn, DBL_MIN);
@@ -299,6 +340,18 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             }
         }
         if (!EXACT) {
+            outside = out_sure;
+            const bool need_exact = act & !out_sure & maybe; // the origin is within kSignEps of a plane and clearly in front of none
+            if (__any(need_exact)) {
+                bool o = false;
+                for (int j = 0; __any(need_exact & (j < cnt)); ++j) {
+                    const int qq = pb + SSG_PLANE_DOUBLES * ((j < SSG_MAX_HULL) ? j : 0);
+                    const double v0x = bank_at<LDS_BANK>(c, qq + 0), v0y = bank_at<LDS_BANK>(c, qq + 1);
+                    const double nx = bank_at<LDS_BANK>(c, qq + 2), ny = bank_at<LDS_BANK>(c, qq + 3);
+                    o = o | ((j < cnt) & ((nx * (wcx - v0x) + ny * (wcy - v0y)) > 0.0));
+                }
+                outside = need_exact ? o : outside;
+            }
             const int q = pb + SSG_PLANE_DOUBLES * bj;
             const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
             // the entry edge's extent: cpvcross(n, v[bj-1]) .. cpvcross(n, v[bj])
@@ -539,7 +592,7 @@ __device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *co
 template <bool LDS_BANK>
 __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *shiptab, const double x, const double y,
                                                  const double ca, const double sa, const int rec_off, const bool live,
-                                                 const int lane)
+                                                 const int lane, const int only /* wave-uniform: hull 0 or 1, or -1 = both */)
 {
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative stage: lane L = 5*q + i
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
@@ -555,7 +608,7 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
         const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
         const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
         const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
-        const bool near = live & !SSG_ABL(4) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
+        const bool near = live & !SSG_ABL(4) & ((only < 0) | (only == s)) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
         nearbits |= near ? (1u << s) : 0u;
         cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
     }
@@ -781,8 +834,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
             const int nmap = posem[tl];
             ack_pose();
-            if (k > 0 && role == 0) // collide_ship of this step (role 2 is still writing the previous step's observation rows)
-                gres[(k & 1) * EPW + tl] = bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane) ? 1u : 0u;
+            if (k > 0) // collide_ship of this step, one bank hull per lidar role (role 2 is still writing the previous step's rows)
+                reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
+                    bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role) ? 1 : 0;
+            SSG_STAMP_K(3);
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
             if (k + 1 < K) {
@@ -852,7 +907,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const int rec_off = map_id * SSG_MAP_STRIDE;
             // collide_ship: the first step of a launch is collided here (role 0 is busy with that step's lidar query, and
             // there is no observation backlog yet); every later step by role 0, which idles between A and B then
-            if (k == 0) gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, x, y, ca, sa, rec_off, live, lane) ? 1u : 0u; // (parity 0)
+            if (k == 0) gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, x, y, ca, sa, rec_off, live, lane, -1) ? 1u : 0u; // (parity 0)
             SSG_STAMP_K(1);
             tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
@@ -974,6 +1029,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     SSG_STAMP(9);
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
+#ifdef SSG_PRIO
+    __builtin_amdgcn_s_setprio(SSG_PRIO);
+#endif
 
     for (int k = 0; k < K; ++k) {
 #ifdef SSG_STAMPS_ITER

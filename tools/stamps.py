@@ -36,7 +36,7 @@ print("role 3 (body):")
 for i, nme in enumerate(names3):
     print("   %-46s %8.0f   (+%.0f)" % (nme, acc[3, i], acc[3, i] - (acc[3, i - 1] if i else 0)))
 for role, nm in ((0, "lidar lo"), (1, "lidar hi")):
-    print("role %d (%s): pose copied %.0f | B complete %.0f | next step's query done %.0f  (query = %.0f cycles)" % (
-        role, nm, acc[role, 0], acc[role, 1], acc[role, 2], acc[role, 2] - acc[role, 1]))
+    print("role %d (%s): pose copied %.0f | arrives at B %.0f | B complete %.0f | next step's query done %.0f  (query = %.0f cycles)" % (
+        role, nm, acc[role, 0], acc[role, 3], acc[role, 1], acc[role, 2], acc[role, 2] - acc[role, 1]))
 print("role 2 (observer): pose copied %.0f | first-step narrowphase slot %.0f (= %.0f cycles) | B complete %.0f | outputs + obs rows written %.0f (= %.0f cycles)" % (
     acc[2, 0], acc[2, 1], acc[2, 1] - acc[2, 0], acc[2, 2], acc[2, 3], acc[2, 3] - acc[2, 2]))
