@@ -112,6 +112,7 @@ class ShipVecEnv(*_BASES):
             raise ValueError("history_size must be greater than zero")
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.map_mode = map_mode
         self.bounds = tuple(game_config.BOUNDS)
         self.width_frac = float(width_frac)
@@ -351,23 +352,41 @@ class ShipVecEnv(*_BASES):
                 torch.cuda.current_stream(self.device).synchronize()  # keep `ids` alive until the kernel ran
         return self.obs
 
+    def _out_ptrs(self):
+        """The four output buffers as C pointers (they are allocated once; cached: these calls sit on the launch path)."""
+        p = self.__dict__.get("_out_ptr_cache")
+        if p is None or p[0] != (self.obs.data_ptr(), self.reward.data_ptr()):
+            p = ((self.obs.data_ptr(), self.reward.data_ptr()),
+                 C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                 C.c_void_p(self.flags.data_ptr()))
+            self._out_ptr_cache = p
+        return p[1:]
+
     def step_tensor(self, actions):
         """actions: int32 device tensor [N].  Returns (obs, reward, done, flags) device tensors (reused buffers)."""
         torch = _torch()
-        with torch.cuda.device(self.device):
-            N.check(N.lib().ssg_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-                                     C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
-                                     C.c_void_p(self.flags.data_ptr()), self._stream()), self._h, "ssg_step")
+        o, r, d, f = self._out_ptrs()
+        if torch.cuda.current_device() == self._dev_index:  # (the usual case: no device switch around the launch)
+            rc = N.lib().ssg_step(self._h, C.c_void_p(actions.data_ptr()), o, r, d, f, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                rc = N.lib().ssg_step(self._h, C.c_void_p(actions.data_ptr()), o, r, d, f, self._stream())
+        if rc:
+            N.check(rc, self._h, "ssg_step")
         return self.obs, self.reward, self.done, self.flags
 
     def rollout_tensor(self, actions_kn):
         """K back-to-back steps from a pre-generated int32 [K, N] action tensor (random-action throughput run)."""
         torch = _torch()
         K = int(actions_kn.shape[0])
-        with torch.cuda.device(self.device):
-            N.check(N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, C.c_void_p(self.obs.data_ptr()),
-                                        C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
-                                        C.c_void_p(self.flags.data_ptr()), self._stream()), self._h, "ssg_rollout")
+        o, r, d, f = self._out_ptrs()
+        if torch.cuda.current_device() == self._dev_index:
+            rc = N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, o, r, d, f, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                rc = N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, o, r, d, f, self._stream())
+        if rc:
+            N.check(rc, self._h, "ssg_rollout")
         return self.obs, self.reward, self.done, self.flags
 
     def random_actions(self, seed, step0, K):
