@@ -704,9 +704,6 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 // 74 KB of bank by LDS-DMA), ~13 k cycles with the four roles sharing the SIMD, a ~10 k-cycle observer tail that is
 // bound by the CU's store path, and the write-back of the ~25 MB it dirtied at the end of the kernel.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef SSG_SLEEP_LONG
-#define SSG_SLEEP_LONG 4 /* x 64 cycles between the polls of a waiting wave */
-#endif
 template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
@@ -787,12 +784,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // once the three consumers have acknowledged pose k-1, and raises `ready` to k+1; a consumer waits for that, copies what it
     // needs into registers and acknowledges.  Replaces a second workgroup barrier per step, at which role 3 waited ~1.5 k
     // cycles for the slowest of twelve waves it has no business with.
-    // Waiters sleep long between polls (each poll is an LDS instruction, and the LDS pipe is ~70 % busy); whoever completes
-    // a rendezvous pings the workgroup's sleeping waves with s_wakeup, so a long sleep costs no latency (a ping that
-    // arrives between a waiter's poll and its s_sleep is lost: that waiter then sleeps its full 256 cycles, once).
     auto wait_pose = [&](int k) {
         while (__hip_atomic_load(&sync_ready[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(k + 1))
-            __builtin_amdgcn_s_sleep(SSG_SLEEP_LONG);
+            __builtin_amdgcn_s_sleep(2);
     };
     auto ack_pose = [&]() {
         if (lane == 0) __hip_atomic_fetch_add(&sync_ack[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -801,16 +795,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // step's lidar results are in; the result buffer of the other parity is free): an arrival counter in LDS instead of a
     // workgroup barrier — the four tiles of a workgroup share nothing but the staged bank, and at s_barrier each waited for
     // the slowest of the other three twice per step (~2.4 k of a step's 15 k cycles).
+    // (s_wakeup by whoever completes a rendezvous, with longer sleeps between the waiters' polls, measured 0.6 % faster — and
+    // raised GPU memory-access faults in the diagnostic builds that also execute s_memtime: not used.)
     auto tile_barrier = [&](int k) {
-        unsigned before = 0u;
-        if (lane == 0) before = __hip_atomic_fetch_add(&sync_bar[tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
-        if (before + 1u == 4u * (unsigned)(k + 1)) { // the last of the tile's four waves: the rendezvous is complete
-            asm volatile("s_wakeup" ::: "memory");
-            return;
-        }
+        if (lane == 0) __hip_atomic_fetch_add(&sync_bar[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (__hip_atomic_load(&sync_bar[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(k + 1))
-            __builtin_amdgcn_s_sleep(SSG_SLEEP_LONG);
+            __builtin_amdgcn_s_sleep(1);
     };
 
     if (role < 2) {
@@ -1117,7 +1107,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     poser[tl] = rudder;
     SSG_STAMP_K(1);
     if (lane == 0) __hip_atomic_store(&sync_ready[tile], (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory"); // (the store has reached the LDS before the ping)
     SSG_STAMP_K(2);
 
     const bool oob_x = (x < 0.0) | (x > c.width);
