@@ -622,13 +622,15 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
         const int cnt = (cnts >> (8 * s)) & 0xFF;
         bool sep = false;
         for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
-            const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
-            const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
-            const double v0n = bank_at<LDS_BANK>(c, q + 4);
-            bool allfront = j < cnt;
+            if (near_s & !sep & (j < cnt)) { // (only the lanes still looking gather a plane: the LDS pipe is the busiest unit)
+                const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
+                const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+                const double v0n = bank_at<LDS_BANK>(c, q + 4);
+                bool allfront = true;
 #pragma unroll
-            for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
-            sep = sep | allfront;
+                for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
+                sep = allfront;
+            }
         }
         nearbits = sep ? (nearbits & ~(1u << s)) : nearbits;
     }
