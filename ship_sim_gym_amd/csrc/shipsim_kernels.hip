@@ -681,8 +681,8 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 
 // ---------------------------------------------------------------------------------------------------------
 // The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
-//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0); bank-hull narrowphase (collide_ship) of every step but the first
-//   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB)
+//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0); narrowphase (collide_ship) against the left bank, every step but the first
+//   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB); narrowphase against the right bank, every step but the first
 //   role 2  OBSERVER : sticky-lidar merge and the observation rows (__add_states); its registers carry the previous
 //                      frame from step to step; bank-hull narrowphase of the launch's first step
 //   role 3  BODY     : handle_discrete_action, integrator, ship transform, goal-circle narrowphase, nearest goals,
@@ -693,7 +693,7 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 // workgroup barrier after barrier 0, which publishes the staged bank):
 //   pose hand-over: role 3 integrates and publishes the post-step pose of step k (`sync_ready` = k+1) once its three
 //     consumers have acknowledged pose k-1 (`sync_ack`);
-//   rendezvous B(k) (`sync_bar`): role 0 (role 2 in a launch's first step) has collided that pose with the banks, role 3
+//   rendezvous B(k) (`sync_bar`): roles 0 / 1 (role 2 in a launch's first step) have collided that pose with the banks, role 3
 //     has done the goals and its share of is_done, the lidar roles have delivered step k's readings.
 //   After B(k) three things run side by side: role 3 closes the step (statistics, reset) and starts the next one; role 2
 //   writes reward / done / flags and the observation rows of step k; roles 0/1 run step k+1's lidar query.
