@@ -197,8 +197,8 @@ struct BankShape {
     __device__ __forceinline__ Edge support_edge(V2 nn) const
     {
         const int i1 = support(nn).i;
-        const int i0 = (i1 - 1 + n) % n;
-        const int i2 = (i1 + 1) % n;
+        const int i0 = (i1 == 0) ? n - 1 : i1 - 1;
+        const int i2 = (i1 + 1 == n) ? 0 : i1 + 1;
         Edge e;
         if (dot(nn, normal(i1)) > dot(nn, normal(i2))) {
             e.ap = vert(i0); e.ah = edge_hash(hashid, i0); e.bp = vert(i1); e.bh = edge_hash(hashid, i1); e.n = normal(i1);
@@ -312,19 +312,22 @@ __device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v
                 hi = hj;
             }
         }
-        const Mink e0 = mem.get(cur, mini), e1 = mem.get(cur, (mini + 1) % count);
+        const int mini1 = (mini + 1 == count) ? 0 : mini + 1; // (mini + 1) % count
+        const Mink e0 = mem.get(cur, mini), e1 = mem.get(cur, mini1);
         const Mink p = support(s1, s2, perp(e1.ab - e0.ab));
         const double area2x = cross(e1.ab - e0.ab, (p.ab - e0.ab) + (p.ab - e1.ab));
         if (area2x > 0.0 && iteration < kMaxEpa) {
             int count2 = 1;
             mem.set(cur ^ 1, 0, p);
             V2 h0 = p.ab; // ab of the last entry written to the new hull
+            int index = mini1; // (mini + 1 + i) % count, stepped
             for (int i = 0; i < count; ++i) {
-                const int index = (mini + 1 + i) % count;
+                const int next = (index + 1 == count) ? 0 : index + 1;
                 const Mink hm = mem.get(cur, index);
                 const V2 h1 = hm.ab;
-                const V2 h2 = (i + 1 < count) ? mem.get(cur, (index + 1) % count).ab : p.ab;
+                const V2 h2 = (i + 1 < count) ? mem.get(cur, next).ab : p.ab;
                 if (cross(h2 - h0, h1 - h0) > 0.0) { mem.set(cur ^ 1, count2++, hm); h0 = h1; }
+                index = next;
             }
             cur ^= 1;
             count = count2;
@@ -545,7 +548,7 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
     ShipShape pl;
     pl.hoff = hoff; pl.hashid = 0;
     pl.p = mk(x + vx * c.dt, y + vy * c.dt);
-    sincos(ang + w * c.dt, &pl.sa, &pl.ca);
+    sincos_body(ang + w * c.dt, &pl.sa, &pl.ca);
     pl.cache();
     return pl;
 }
@@ -633,13 +636,13 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
                 ShipShape pl; // (same expressions as player_shape())
                 pl.hoff = 0; pl.hashid = 0;
                 pl.p = mk(ppx, ppy);
-                sincos(pang + pw * c.dt, &pl.sa, &pl.ca);
+                sincos_body(pang + pw * c.dt, &pl.sa, &pl.ca);
                 pl.cache();
                 for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
                     ShipShape sk;
                     sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
                     sk.p = mk(tp[k][0], tp[k][1]);
-                    sincos(tp[k][2], &sk.sa, &sk.ca);
+                    sincos_body(tp[k][2], &sk.sa, &sk.ca);
                     sk.cache();
                     hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
                 }
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const V2 pn = p + (v + vb) * dt;
         const double an = a + (w + wb) * dt;
         double sa, ca;
-        sincos(an, &sa, &ca);
+        sincos_body(an, &sa, &ca);
         const int s = slot_ship0 + k;
         BF(s, B_PX) = pn.x; BF(s, B_PY) = pn.y; BF(s, B_VX) = v.x; BF(s, B_VY) = v.y; BF(s, B_W) = w;
         BF(s, B_VBX) = 0.0; BF(s, B_VBY) = 0.0; BF(s, B_WB) = 0.0;

@@ -66,31 +66,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) // src_la
 __device__ __attribute__((noinline)) double2 sincos_call(double a) // returns (sin a, cos a) in registers
 {
     double2 o;
-    if (!(fabs(a) <= 262144.0)) { // (also NaN / inf)
-        sincos(a, &o.x, &o.y);
-        return o;
-    }
-    const double k = rint(a * 6.36619772367581382433e-01);
-    const double r1 = fma(-k, 1.57079632679489655800e+00, a);
-    const double r = fma(-k, 6.12323399573676603587e-17, r1);
-    double y = fma(-k, 6.12323399573676603587e-17, r1 - r); // the tail of the reduced argument
-    y = fma(k, 1.4973849048591698e-33, y);                  // pi/2 = HI + MID - 1.497e-33
-    const int n = (int)k;
-    const double z = r * r, w = z * z;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double rs = fma(z, fma(z, S4, S3), S2) + z * w * fma(z, S6, S5);
-    const double v = z * r;
-    const double s0 = r - ((z * (0.5 * y - v * rs) - y) - v * S1);
-    const double rc = z * fma(z, fma(z, C3, C2), C1) + w * w * fma(z, fma(z, C6, C5), C4);
-    const double hz = 0.5 * z, ww = 1.0 - hz;
-    const double c0 = ww + (((1.0 - ww) - hz) + (z * rc - r * y));
-    double sn = (n & 1) ? c0 : s0, cs = (n & 1) ? s0 : c0;
-    sn = (n & 2) ? -sn : sn;
-    cs = ((n + 1) & 2) ? -cs : cs;
-    o.x = sn; o.y = cs;
+    sincos_body(a, &o.x, &o.y);
     return o;
 }
 

@@ -32,3 +32,15 @@ print("per env: gjk iterations mean %.2f max %d | epa iterations mean %.2f max %
 w = st[7:10, :n].reshape(3, -1, 64)
 print("per wave (sum over the sites a wave enters is what it pays): max-lane gjk it %.1f, epa it %.1f, queries %.1f" % (
     w[0].max(axis=1).mean(), w[1].max(axis=1).mean(), w[2].max(axis=1).mean()))
+
+# do the iteration counts depend on the episode's age (would age-binned waves be more homogeneous)?
+age = vec.field(N.F_STEP_COUNT).cpu().numpy()
+tot = st[7] + 2.5 * st[8]  # rough cost: an EPA iteration ~2.5 GJK iterations
+for lo, hi in ((0, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 2000)):
+    m = sel & (age >= lo) & (age < hi)
+    if m.sum():
+        print("age [%3d,%4d): %6d envs | gjk mean %.2f p90 %.0f max %d | epa mean %.2f p90 %.0f max %d | queries mean %.2f" % (
+            lo, hi, m.sum(), st[7][m].mean(), np.percentile(st[7][m], 90), st[7][m].max(), st[8][m].mean(),
+            np.percentile(st[8][m], 90), st[8][m].max(), st[9][m].mean()))
+q = fl & 4
+print("resting %.3f of envs; resting by age:" % (q != 0).mean(), [round(float(((q != 0) & (age >= lo) & (age < hi)).sum() / max(1, ((age >= lo) & (age < hi)).sum())), 2) for lo, hi in ((0, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 2000))])
