@@ -902,7 +902,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const unsigned gd = gdone[(k & 1) * EPW + tl];
             const bool colliding = (gres[(k & 1) * EPW + tl] != 0u) | ((gd & 2u) != 0u); // collide_ship: a bank, or traffic
             const bool do_reset = auto_reset & (colliding | ((gd & 1u) != 0u));
-            if (live) {
+            // (a launch's last step: role 3, idle by then, writes these after its loop — the observer's tail is what the
+            // launch waits for)
+            if (live && k < K - 1) {
                 // determine_reward (ship_env.py:62-77) and is_done (ship_env.py:115-134) from role 3's bits, as role 3 does
                 const bool goal_reached = (gd & 4u) != 0u;
                 double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
@@ -1000,6 +1002,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
     }
     int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
+    unsigned last_ev = 0u; // the last step's reward / done / flags, written by this role after the loop
     // (the state is wanted in registers BEFORE barrier 0, under the bank's staging: left to itself the compiler sinks the
     // loads below the barrier and the first step starts a memory round trip late)
     asm volatile("" : "+v"(x), "+v"(y), "+v"(vx), "+v"(vy), "+v"(ang), "+v"(w), "+v"(cum));
@@ -1178,6 +1181,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool done = colliding | done3;
     const bool do_reset = done & auto_reset;
+    // bits 0-4: the SSG_EV_* flags, bit 8: done, bits 9-10: reward (0: -0.01, 1: +1, 2: -1)
+    last_ev = (colliding ? SSG_EV_COLLIDING : 0u) | (goal_reached ? SSG_EV_GOAL_REACHED : 0u) | ((oob_x | oob_y) ? SSG_EV_OUT_OF_BOUNDS : 0u) |
+              ((steps_after >= c.max_steps) ? SSG_EV_MAX_STEPS : 0u) | ((alive == 0u) ? SSG_EV_NO_GOALS_LEFT : 0u) | (done ? 256u : 0u) |
+              ((rew == 1.0) ? 512u : ((rew == -1.0) ? 1024u : 0u));
 
     if (live && !SSG_ABL(6)) {
         // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
@@ -1218,6 +1225,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     SSG_STAMP_K(5);
     } // k
+    if (live) { // the last step's outputs (the observer wrote those of the steps before)
+        const int el = el_;
+        st_out(&reward_out[el], (last_ev & 512u) ? 1.0 : ((last_ev & 1024u) ? -1.0 : -0.01));
+        st_out(&done_out[el], (uint8_t)((last_ev >> 8) & 1u));
+        if (flags_out) st_out(&flags_out[el], (uint8_t)(last_ev & 0xFFu));
+    }
     SSG_STAMP(10);
     SSG_STAMP_FLUSH(6);
 }
