@@ -831,6 +831,19 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             }
             SSG_STAMP_K(2);
         }
+        if (K == 1 && live) {
+            // A single-step launch: the sticky readings' columns hold exactly the previous frame's values, so "a miss keeps
+            // the previous reading" (models.py:68-72) is "a miss stores nothing".  The lidar waves, idle after the step's only
+            // rendezvous, store their own beams' hits (or the -1 of a fresh episode) while the observer builds the rows.
+            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 3u)) != 0u);
+            const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(tile_base); // parity 0
+            for (int kb = 0; kb < b_count; ++kb) {
+                const int i = b_first + kb;
+                const unsigned long long key = rk[i * 64 + lane];
+                const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
+                if (rs | (key != kLidarMiss)) st_out(&colLid[(size_t)i * np + el_], rs ? -1.0 : hitd);
+            }
+        }
         SSG_STAMP(10);
         SSG_STAMP_FLUSH(3);
         return;
@@ -963,7 +976,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)(F * c.history); // tile start in HBM
                 const int rows_live = min(64, c.n_envs - tile_e0);                             // rows of this tile in range
                 if (!SSG_ABL(7)) {
-                    double *colbuf = reinterpret_cast<double *>(res_k); // (the result keys are in registers by now)
+                    // (the result keys are in registers by now; in a single-step launch the lidar waves still read them for
+                    // the sticky columns, and the other parity's buffer is free)
+                    double *colbuf = reinterpret_cast<double *>((K == 1) ? res_k + lds_res_bytes(NB) : res_k);
                     if (hist2)
                         write_obs_tile<NB, true, 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
                             return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
@@ -975,7 +990,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(7);
 #pragma unroll
             for (int i = 0; i < F; ++i) pv[i] = nv[i];
-            if (k == K - 1 && live && !SSG_ABL(9)) { // the sticky readings go back to the state columns with the last step
+            if (k == K - 1 && K > 1 && live && !SSG_ABL(9)) { // the sticky readings go back to the state columns with the last step
 #pragma unroll
                 for (int i = 0; i < NB; ++i) st_out(&colLid[(size_t)i * np + el_], pv[6 + i]);
             }
