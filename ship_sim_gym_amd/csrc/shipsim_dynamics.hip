@@ -700,10 +700,11 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
     unsigned long long live = col.live[e]; // (pass 1 rebuilt the bodies after a reset and dropped removed goals' arbiters)
     const unsigned long long live0 = live;
-    // Did this step write back anything but the bits it read?  Compared through 64-bit hashes of what is read and of
-    // what is written (re-reading the columns at write-back would put ~80 dependent round trips on the chain).
+    // Did this step write back anything but the bits it read?  The body columns are compared directly: what was read stays
+    // in registers until the write-back (this kernel runs one wave per SIMD, 512 VGPRs to spare; hashing both sides cost
+    // ~150 64-bit multiplies per step).  The arbiters' accumulated impulses, touched for a few pairs only, go through
+    // 64-bit hashes.
     bool changed = false;
-    unsigned long long hin = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live0);
     unsigned long long ain = 0ull, aout = 0ull; // order-independent (xor) over the touched arbiters
     auto arb_hash = [&](int pid, unsigned meta, unsigned hh, double j0, double j1, double t0, double t1) -> unsigned long long {
         return mixd(mixd(mixd(mixd(mix(mix(mix(0x7F4A7C15ull, (unsigned)pid), meta), hh), j0), j1), t0), t1);
@@ -723,27 +724,34 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     };
 
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
-    unsigned long long gin[SSG_MAX_GOALS] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // per-goal input hashes (unrolled: registers)
+    // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
+    double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
+#pragma unroll
+    for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+        const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * (g < ng ? g : 0)) * np + e; // (a goal past n_goals: goal 0 again, unused)
+#pragma unroll
+        for (int f = 0; f < DC_GOAL_COLS; ++f) gin[g][f] = q[(size_t)f * np];
+    }
+#pragma unroll
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) tin[k][f] = t[(size_t)f * np];
+    }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
         if (g >= ng) continue;
         if (!((gmask >> g) & 1u)) continue;
-        const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
-        const V2 p = mk(q[0 * np], q[1 * np]), v = mk(q[2 * np], q[3 * np]), vb = mk(q[4 * np], q[5 * np]);
-        const double w = q[6 * np], wb = q[7 * np];
-        gin[g] = mixd(mixd(mixd(mixd(mixd(mixd(mixd(mixd(0ull, p.x), p.y), v.x), v.y), vb.x), vb.y), w), wb);
+        const V2 p = mk(gin[g][0], gin[g][1]), v = mk(gin[g][2], gin[g][3]), vb = mk(gin[g][4], gin[g][5]);
+        const double w = gin[g][6];
         const V2 pn = p + (v + vb) * dt; // (the angle of a circle body is never read)
         BF(g, B_PX) = pn.x; BF(g, B_PY) = pn.y; BF(g, B_VX) = v.x; BF(g, B_VY) = v.y; BF(g, B_W) = w;
         BF(g, B_VBX) = 0.0; BF(g, B_VBY) = 0.0; BF(g, B_WB) = 0.0;
     }
 #pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-        const V2 p = mk(t[0 * np], t[1 * np]), v = mk(t[3 * np], t[4 * np]), vb = mk(t[6 * np], t[7 * np]);
-        const double a = t[2 * np], w = t[5 * np], wb = t[8 * np];
-        { const double v9[9] = {p.x, p.y, a, v.x, v.y, w, vb.x, vb.y, wb};
-#pragma unroll
-          for (int f = 0; f < 9; ++f) hin = mixd(hin, v9[f]); }
+        const V2 p = mk(tin[k][0], tin[k][1]), v = mk(tin[k][3], tin[k][4]), vb = mk(tin[k][6], tin[k][7]);
+        const double a = tin[k][2], w = tin[k][5], wb = tin[k][8];
         const V2 pn = p + (v + vb) * dt;
         const double an = a + (w + wb) * dt;
         double sa, ca;
@@ -1151,14 +1159,15 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
         acc[0 * np] = j0; acc[1 * np] = j1; acc[2 * np] = t0; acc[3 * np] = t1;
     }
-    unsigned long long hsh = mix(mix(mix(mix(0x51ED270B1ull, d.bank_epoch), (unsigned)map_id), gmask), live);
+    auto differs = [](double a, double b) -> bool { return __double_as_longlong(a) != __double_as_longlong(b); };
+#pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
         const int s = slot_ship0 + k;
         const double v[9] = {BF(s, B_PX), BF(s, B_PY), L(xbase + X_STRIDE * k + X_A), BF(s, B_VX), BF(s, B_VY), BF(s, B_W),
                              BF(s, B_VBX), BF(s, B_VBY), BF(s, B_WB)};
 #pragma unroll
-        for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; hsh = mixd(hsh, v[f]); }
+        for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; changed |= differs(v[f], tin[k][f]); }
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -1166,13 +1175,10 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
         const double v[DC_GOAL_COLS] = {BF(g, B_PX), BF(g, B_PY), BF(g, B_VX), BF(g, B_VY), BF(g, B_VBX), BF(g, B_VBY),
                                         BF(g, B_W), BF(g, B_WB)};
-        unsigned long long go = 0ull;
 #pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; go = mixd(go, v[f]); }
-        hin = mix(hin, gin[g]);
-        hsh = mix(hsh, go);
+        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; changed |= differs(v[f], gin[g][f]); }
     }
-    changed |= (hin != hsh) | (ain != aout);
+    changed |= (live != live0) | (ain != aout);
     stamp(5);
     if (d.stop_after == -1) {
         col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + e] = (double)n_act;
