@@ -267,10 +267,18 @@ __device__ __forceinline__ Closest closest_new(const Mink &v0, const Mink &v1)
 // expression that produced it), entries beyond that (practically never) in scratch.
 constexpr int kEpaLds = 7;
 constexpr int kEpaDoubles = 2 * kEpaLds * 4;
+// Development aid (-DSSG_DYN_PROFILE variant builds, tools/c4_stamps.py): cycles of the collide phase by what the wave was
+// doing when each interval ENDED, accumulated per wave (the ticks themselves cost ~100 cycles each).
+#ifdef SSG_DYN_PROFILE
+#define SSG_TICK(mem, cat) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (mem).prof[cat] += n_ - *(mem).last; *(mem).last = n_; } while (0)
+#else
+#define SSG_TICK(mem, cat) do { } while (0)
+#endif
 struct EpaMem {
     int base; // index in lds[] of this lane's buffer 0 entry 0 field 0 (field stride 64)
     Mink *ov; // [2][kMaxEpa + 4 - kEpaLds]
     int *cnt; // development counters: [0] gjk iterations [1] epa iterations [2] queries
+    unsigned long long *prof, *last; // SSG_DYN_PROFILE: [0] other [1] gjk [2] epa [3] closest/edges/clip [4] push [5] bank staging
     __device__ __forceinline__ Mink get(int buf, int i) const
     {
         if (i < kEpaLds) {
@@ -332,7 +340,9 @@ __device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v
             cur ^= 1;
             count = count2;
         } else {
-            return closest_new(e0, e1);
+            SSG_TICK(mem, 2);
+            const Closest r_ = closest_new(e0, e1);
+            return r_;
         }
     }
 }
@@ -340,6 +350,7 @@ __device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v
 template <class SA, class SB>
 __device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2, const EpaMem &mem)
 {
+    SSG_TICK(mem, 0);
     const V2 axis = perp(bb_center(s1.bb()) - bb_center(s2.bb())); // cold start (no cached collision id)
     Mink v0 = support(s1, s2, axis);
     Mink v1 = support(s1, s2, neg(axis));
@@ -347,7 +358,7 @@ __device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2, const EpaMem 
     mem.cnt[2]++;
     for (;;) {
         mem.cnt[0]++;
-        if (iteration > kMaxGjk) return closest_new(v0, v1);
+        if (iteration > kMaxGjk) { SSG_TICK(mem, 1); return closest_new(v0, v1); }
         const V2 delta = v1.ab - v0.ab;
         if (cross(delta, v0.ab + v1.ab) > 0.0) {
             const Mink tmp = v0; v0 = v1; v1 = tmp; // origin behind the axis: flip, same iteration
@@ -356,9 +367,11 @@ __device__ __forceinline__ Closest gjk(const SA &s1, const SB &s2, const EpaMem 
         const double t = closest_t(v0.ab, v1.ab);
         const V2 n = (-1.0 < t && t < 1.0) ? perp(delta) : neg(lerp_t(v0.ab, v1.ab, t));
         const Mink p = support(s1, s2, n);
-        if (cross(v1.ab - p.ab, v1.ab + p.ab) > 0.0 && cross(v0.ab - p.ab, v0.ab + p.ab) < 0.0)
+        if (cross(v1.ab - p.ab, v1.ab + p.ab) > 0.0 && cross(v0.ab - p.ab, v0.ab + p.ab) < 0.0) {
+            SSG_TICK(mem, 1);
             return epa(s1, s2, v0, p, v1, mem);
-        if (dot(p.ab, n) <= cmax(dot(v0.ab, n), dot(v1.ab, n))) return closest_new(v0, v1);
+        }
+        if (dot(p.ab, n) <= cmax(dot(v0.ab, n), dot(v1.ab, n))) { SSG_TICK(mem, 1); return closest_new(v0, v1); }
         if (closest_dist(v0.ab, p.ab) < closest_dist(p.ab, v1.ab)) v1 = p; else v0 = p;
         ++iteration;
     }
@@ -778,7 +791,12 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
         for (int f = 0; f < 4; ++f) bk[s][1 + f] = rec[SSG_MAP_OFF_AABB + 4 * s + f];
     }
-    const int bbase = (abase + A_STRIDE * kLdsArb) * kGrp + lane, ebase = bbase + kBankDoubles * kGrp;
+    const int bbase = (abase + A_STRIDE * kLdsArb) * kGrp + lane; // this lane's staged bank planes; EPA's hull follows
+    Mink epa_ov[2 * (kMaxEpa + 4 - kEpaLds)];
+    EpaMem emem;
+    int dbg_cnt[3] = {0, 0, 0};
+    unsigned long long prof_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, prof_last = 0ull;
+    emem.base = (abase + A_STRIDE * kLdsArb) * kGrp + lane + kBankDoubles * kGrp; emem.ov = epa_ov; emem.cnt = dbg_cnt; emem.prof = prof_acc; emem.last = &prof_last;
     int staged = -1;
     auto bank_box = [&](int s) -> BB {
         BB o;
@@ -796,6 +814,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
             for (int q = 0; q < kBankDoubles; ++q) lds[bbase + q * kGrp] = tmp[q];
             staged = s;
+            SSG_TICK(emem, 5);
         }
         BankShape b;
         b.base = bbase;
@@ -804,10 +823,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         b.hashid = (unsigned)s;
         return b;
     };
-    Mink epa_ov[2 * (kMaxEpa + 4 - kEpaLds)];
-    EpaMem emem;
-    int dbg_cnt[3] = {0, 0, 0};
-    emem.base = ebase; emem.ov = epa_ov; emem.cnt = dbg_cnt;
     auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
 
     stamp(0);
@@ -821,6 +836,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 
     stamp(1);
     if (d.stop_after == 2) return;
+    prof_last = __builtin_amdgcn_s_memtime();
     // ---- (3) collide, canonical order ---------------------------------------------------------------------------
     double ovf[(kMaxActive - kLdsArb) * A_STRIDE]; // records beyond the LDS ones: scratch, touched only when used
     auto arb = [&](int i) -> ArbRef {
@@ -834,6 +850,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 
     // cpSpaceCollideShapes after the narrowphase found contacts: fetch / create the cached arbiter, cpArbiterUpdate
     auto push = [&](const Info &info, int a, int b, int pid, double u) {
+        SSG_TICK(emem, 3);
         if (info.count == 0 || n_act >= kMaxActive) return;
         int state = ST_NONE, old_count = 0;
         unsigned old_hash[2] = {0u, 0u};
@@ -873,6 +890,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         A.set(A_HASH, __longlong_as_double((long long)(((unsigned long long)hh[1] << 32) | hh[0])));
         touched |= 1ull << pid;
         live |= 1ull << pid;
+        SSG_TICK(emem, 4);
     };
 
     Info info;
@@ -918,6 +936,11 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
     }
 
+    SSG_TICK(emem, 0);
+#ifdef SSG_DYN_PROFILE
+    if (d.stop_after == -1)
+        for (int i = 0; i < 6; ++i) col.f64[(size_t)(DC_ARB + 4 * 45 + i) * np + e] = (double)prof_acc[i]; // unused arbiter rows of pairs 45, 46
+#endif
     stamp(2);
     if (d.stop_after == 3) return;
     // ---- cpSpaceArbiterSetFilter for the cached arbiters that were not touched this step -------------------------

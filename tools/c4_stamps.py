@@ -33,6 +33,12 @@ w = st[7:10, :n].reshape(3, -1, 64)
 print("per wave (sum over the sites a wave enters is what it pays): max-lane gjk it %.1f, epa it %.1f, queries %.1f" % (
     w[0].max(axis=1).mean(), w[1].max(axis=1).mean(), w[2].max(axis=1).mean()))
 
+pr = cols[DC_ARB + 180: DC_ARB + 186, :n].cpu().numpy()
+if pr[1][sel].max() > 0:
+    names_p = ["loops / rejects / shapes", "gjk", "epa", "closest + edges + clip", "push", "bank staging"]
+    print("collide phase by category (SSG_DYN_PROFILE build), median cycles per wave:")
+    for i, nm in enumerate(names_p):
+        print("   %-26s %8.0f" % (nm, np.median(pr[i][sel])))
 # do the iteration counts depend on the episode's age (would age-binned waves be more homogeneous)?
 age = vec.field(N.F_STEP_COUNT).cpu().numpy()
 tot = st[7] + 2.5 * st[8]  # rough cost: an EPA iteration ~2.5 GJK iterations
