@@ -98,6 +98,19 @@ __device__ __forceinline__ double bank_at(const DevCfg &c, int i)
     if constexpr (LDS_BANK) return lds_base()[i];
     else return c.bank[i];
 }
+// Two neighbouring doubles of a record.  When the bank is gathered from L2 / HBM (per-env records of the `fresh` /
+// `fresh_device` modes, banks too large for the LDS) a gather instruction costs its 64 addresses, not its bytes: one
+// 16-byte load per lane instead of two 8-byte ones (records are 8-byte aligned: gfx950 serves the unaligned dwordx4).
+template <bool LDS_BANK>
+__device__ __forceinline__ double2 bank_at2(const DevCfg &c, int i)
+{
+    if constexpr (LDS_BANK) { double2 r; r.x = lds_base()[i]; r.y = lds_base()[i + 1]; return r; }
+    else {
+        typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+        const double2_a8 v = *reinterpret_cast<const double2_a8 *>(c.bank + i);
+        double2 r; r.x = v.x; r.y = v.y; return r;
+    }
+}
 
 // Stage `bytes` (multiple of 8) from global memory into LDS at offset 0 with LDS-DMA (global_load_lds_dwordx4:
 // 1 KiB per wave-instruction, no VGPR round trip, all requests in flight at once), tail < 1 KiB through registers.
@@ -265,8 +278,8 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             for (int u = 0; u < kPlaneChunk; ++u) { // all LDS reads of the chunk first: one latency per chunk
                 const int j = j0 + u;
                 const int q = pb + SSG_PLANE_DOUBLES * ((j < SSG_MAX_HULL) ? j : 0); // independent of cnt: no LDS round trip in between
-                if (EXACT) { pv0x[u] = bank_at<LDS_BANK>(c, q + 0); pv0y[u] = bank_at<LDS_BANK>(c, q + 1); }
-                pnx[u] = bank_at<LDS_BANK>(c, q + 2); pny[u] = bank_at<LDS_BANK>(c, q + 3);
+                if (EXACT) { const double2 vv = bank_at2<LDS_BANK>(c, q + 0); pv0x[u] = vv.x; pv0y[u] = vv.y; }
+                { const double2 nn = bank_at2<LDS_BANK>(c, q + 2); pnx[u] = nn.x; pny[u] = nn.y; }
                 pv0n[u] = bank_at<LDS_BANK>(c, q + 4);
                 if (EXACT) {
                     // the edge's extent along the plane: cpvcross(n, v[j-1]) .. cpvcross(n, v[j]); v[j-1] is the
@@ -437,10 +450,12 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
     double al[2], ab[2], ar[2], at[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        al[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0) - eps;
-        ab[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1) - eps;
-        ar[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2) + eps;
-        at[s] = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3) + eps;
+        const double2 lb = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+        const double2 rt = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+        al[s] = lb.x - eps;
+        ab[s] = lb.y - eps;
+        ar[s] = rt.x + eps;
+        at[s] = rt.y + eps;
     }
 #pragma unroll
     for (int k = 0; k < NB0; ++k) {
@@ -580,10 +595,9 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
     int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const double al = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
-        const double ab = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 1);
-        const double ar = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
-        const double at = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 3);
+        const double2 lb = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+        const double2 rt = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+        const double al = lb.x, ab = lb.y, ar = rt.x, at = rt.y;
         const bool near = live & !SSG_ABL(4) & ((only < 0) | (only == s)) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
         nearbits |= near ? (1u << s) : 0u;
         cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
@@ -600,7 +614,8 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
         for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
             if (near_s & !sep & (j < cnt)) { // (only the lanes still looking gather a plane: the LDS pipe is the busiest unit)
                 const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
-                const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
+                const double2 nn = bank_at2<LDS_BANK>(c, q + 2);
+                const double nx = nn.x, ny = nn.y;
                 const double v0n = bank_at<LDS_BANK>(c, q + 4);
                 bool allfront = true;
 #pragma unroll
