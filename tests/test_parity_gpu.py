@@ -128,9 +128,14 @@ def test_state_columns_match_oracle(torch_cuda, oracle, native):
     acts = vec.random_actions(5, 0, 150)
     acts_h = acts.cpu().numpy()
     for k in range(150):
-        vec.step_tensor(acts[k]); ob.step(acts_h[k])
+        vec.step_tensor(acts[k]); r_obs = ob.step(acts_h[k])[0]
     pk = ob.peek_all()
     N = native
+    # the sticky lidar readings kept between launches (single-step launches store them from the lidar waves: hits and
+    # fresh episodes only) are the newest frame's readings
+    F = r_obs.shape[1] // 2
+    lid = vec.field(N.F_LIDAR).cpu().numpy()  # [n_beams, n]
+    np.testing.assert_allclose(lid.T, r_obs[:, F + 6:], rtol=0, atol=ATOL)
     for fid, col in ((N.F_X, 0), (N.F_Y, 1), (N.F_VX, 2), (N.F_VY, 3), (N.F_ANGLE, 4), (N.F_W, 5), (N.F_CUM_REWARD, 12)):
         np.testing.assert_allclose(vec.field(fid).cpu().numpy(), pk[:, col], rtol=0, atol=ATOL)
     np.testing.assert_array_equal(vec.field(N.F_RUDDER).cpu().numpy(), pk[:, 6].astype(np.int32))
