@@ -505,18 +505,26 @@ struct ObsTile {
     // Read-back position of this lane's jj-th element of a full pass (element t = lane + 64*jj of the 64 x CP chunk,
     // row-major): where it sits in the column buffer and where it goes in the tile's rows.  The same for every full pass
     // and every step, so it is computed once per launch and kept in registers (the pass offset is an immediate).
-    int lds_at[CP]; // (column * CS + row) * 8 bytes... in doubles
-    int row[CP], col[CP];
+    // (a power-of-two chunk width, e.g. 8 columns at 10 beams: the positions are a shift and a mask of the lane id, computed
+    // where they are used instead of held in 3*CP registers the 10-beam observer does not have)
+    static constexpr bool kOnTheFly = (CP & (CP - 1)) == 0;
+    int lds_at[kOnTheFly ? 1 : CP]; // (column * CS + row) * 8 bytes... in doubles
+    int row[kOnTheFly ? 1 : CP], col[kOnTheFly ? 1 : CP];
     __device__ __forceinline__ void init(int lane)
     {
+        if constexpr (!kOnTheFly) {
 #pragma unroll
-        for (int jj = 0; jj < CP; ++jj) {
-            const int t = lane + 64 * jj;
-            row[jj] = t / CP;
-            col[jj] = t - row[jj] * CP;
-            lds_at[jj] = col[jj] * CS + row[jj];
+            for (int jj = 0; jj < CP; ++jj) {
+                const int t = lane + 64 * jj;
+                row[jj] = t / CP;
+                col[jj] = t - row[jj] * CP;
+                lds_at[jj] = col[jj] * CS + row[jj];
+            }
         }
     }
+    __device__ __forceinline__ int row_of(int jj, int lane) const { if constexpr (kOnTheFly) return (lane + 64 * jj) / CP; else return row[jj]; }
+    __device__ __forceinline__ int col_of(int jj, int lane) const { if constexpr (kOnTheFly) return (lane + 64 * jj) % CP; else return col[jj]; }
+    __device__ __forceinline__ int lds_of(int jj, int lane) const { if constexpr (kOnTheFly) return col_of(jj, lane) * CS + row_of(jj, lane); else return lds_at[jj]; }
 };
 
 // One range [P_BEGIN, P_END) of the passes of a tile (the observer splits a tile's passes around a workgroup barrier).
@@ -531,12 +539,14 @@ __device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *co
     // pass) is loop-invariant across the fused steps too, and hoisted out of the step loop it is spilled to scratch.
     int lds_at[CP], gl_at[CP];
     unsigned okmask = 0;
+    int ln_ = lane;
+    asm volatile("" : "+v"(ln_)); // (positions derived from the lane id are not hoisted out of the step loop either)
 #pragma unroll
     for (int jj = 0; jj < CP; ++jj) {
-        lds_at[jj] = ot.lds_at[jj];
-        gl_at[jj] = ot.row[jj] * DH + ot.col[jj];
-        okmask |= (ot.row[jj] < rows_live) ? (1u << jj) : 0u;
-        asm volatile("" : "+v"(lds_at[jj]), "+v"(gl_at[jj]));
+        lds_at[jj] = ot.lds_of(jj, ln_);
+        gl_at[jj] = ot.row_of(jj, ln_) * DH + ot.col_of(jj, ln_);
+        okmask |= (ot.row_of(jj, ln_) < rows_live) ? (1u << jj) : 0u;
+        if constexpr (!ObsTile<NB>::kOnTheFly) asm volatile("" : "+v"(lds_at[jj]), "+v"(gl_at[jj]));
     }
     asm volatile("" : "+v"(okmask));
 #pragma unroll
