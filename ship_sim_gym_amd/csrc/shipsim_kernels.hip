@@ -364,6 +364,13 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             const unsigned long long key = ((unsigned long long)s << 63) | (unsigned long long)__double_as_longlong(dist);
             atomicMin(&res[bi * 64 + src], key); // ds_min_u64: hull 0's hit beats hull 1's
         }
+#ifdef SSG_LIDAR_COUNT /* diagnostic builds: how many of the pairs that survive the cull are hits? */
+        if (c.dbg) {
+            const unsigned long long ma = __ballot(act), mh = __ballot(hit), mo = __ballot(act & !outside);
+            if (lane == 0) { atomicAdd(c.dbg + 65536 + 0, (unsigned long long)__popcll(ma)); atomicAdd(c.dbg + 65536 + 1, (unsigned long long)__popcll(mh));
+                             atomicAdd(c.dbg + 65536 + 2, 1ull); atomicAdd(c.dbg + 65536 + 3, (unsigned long long)__popcll(mo)); }
+        }
+#endif
     }
 }
 
