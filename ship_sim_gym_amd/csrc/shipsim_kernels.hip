@@ -195,7 +195,7 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //                           published under the tile's `ready` word, consumed under its `ack` word, see the kernel)
 //   posem    [EPW] i32      the env's map id;   poser [EPW] i32  its rudder angle after this step's action
 //   gres     [2][EPW] u32   colliding with a bank, by step parity: low half-word = the left bank (role 0), high = the right
-//                           one (role 1); role 2 writes the word in a launch's first step (-> role 3, role 2, the lidar roles)
+//                           one (role 1) (-> role 3, role 2, the lidar roles)
 //   gdone    [2][EPW] u32   role 3's results of the step, by step parity: bit 0 = no goals left | out of bounds | max_steps,
 //                           bit 1 = the player touches a traffic ship (config 4), bits 2-5 = goal reached, out of bounds,
 //                           max_steps, no goals left, bits 8.. = goals still listed after this step
@@ -689,10 +689,10 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 
 // ---------------------------------------------------------------------------------------------------------
 // The step kernel.  A workgroup of 4*EPW threads serves EPW envs with four wave ROLES (role = wave / (EPW/64)):
-//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0); narrowphase (collide_ship) against the left bank, every step but the first
-//   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB); narrowphase against the right bank, every step but the first
+//   role 0  LIDAR-lo : LiDAR.query beams [0, NB0); narrowphase (collide_ship) against the left bank
+//   role 1  LIDAR-hi : LiDAR.query beams [NB0, NB); narrowphase against the right bank
 //   role 2  OBSERVER : sticky-lidar merge and the observation rows (__add_states); its registers carry the previous
-//                      frame from step to step; bank-hull narrowphase of the launch's first step
+//                      frame from step to step
 //   role 3  BODY     : handle_discrete_action, integrator, ship transform, goal-circle narrowphase, nearest goals,
 //                      reward / done, statistics; its registers carry the body state from step to step
 // A lone wave on a SIMD issues FP64 at half rate and runs latency-bound, and 65 536 envs are only one wave per SIMD, so
@@ -701,7 +701,7 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 // workgroup barrier after barrier 0, which publishes the staged bank):
 //   pose hand-over: role 3 integrates and publishes the post-step pose of step k (`sync_ready` = k+1) once its three
 //     consumers have acknowledged pose k-1 (`sync_ack`);
-//   rendezvous B(k) (`sync_bar`): roles 0 / 1 (role 2 in a launch's first step) have collided that pose with the banks, role 3
+//   rendezvous B(k) (`sync_bar`): roles 0 / 1 have collided that pose with the banks, role 3
 //     has done the goals and its share of is_done, the lidar roles have delivered step k's readings.
 //   After B(k) three things run side by side: role 3 closes the step (statistics, reset) and starts the next one; role 2
 //   writes reward / done / flags and the observation rows of step k; roles 0/1 run step k+1's lidar query.
@@ -847,8 +847,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
             const int nmap = posem[tl];
             ack_pose();
-            if (k > 0) // collide_ship of this step, one bank hull per lidar role (role 2 is still writing the previous step's rows)
-                reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
+            // collide_ship of this step, one bank hull per lidar role (role 2 is writing the previous step's rows; in a launch's
+            // first step the lidar waves have just finished the first query and would idle until B)
+            reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
                     bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role) ? 1 : 0;
             SSG_STAMP_K(3);
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     if (role == 2) {
         // =====================================================================================================
-        // ROLE 2: collide_ship for the first step of the launch (bank_narrowphase), then the OBSERVER of every step
+        // ROLE 2: the OBSERVER of every step
         // =====================================================================================================
         // The observer's previous frame (ship_env.py:79-113: [x, y, rudder, angle, goal x, goal y, L...]) of the first step =
         // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
@@ -925,15 +926,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         for (int k = 0; k < K; ++k) {
             wait_pose(k);
             SSG_STAMP_K(0);
-            const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl], ca = pose[2 * EPW + tl], sa = pose[3 * EPW + tl];
+            const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl];
             const double ang = pose[6 * EPW + tl];
             const int rudder = poser[tl];
             const int map_id = posem[tl];
             ack_pose();
             const int rec_off = map_id * SSG_MAP_STRIDE;
-            // collide_ship: the first step of a launch is collided here (role 0 is busy with that step's lidar query, and
-            // there is no observation backlog yet); every later step by role 0, which idles between A and B then
-            if (k == 0) gres[tl] = bank_narrowphase<LDS_BANK>(c, shiptab, x, y, ca, sa, rec_off, live, lane, -1) ? 1u : 0u; // (parity 0)
             SSG_STAMP_K(1);
             tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
