@@ -711,7 +711,7 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 //   columns.)  Inside a fused launch the state lives in registers: the state columns in HBM are read by the first step
 //   and written back by the last one only; obs / reward / done / flags are written by every step.
 // A single-step launch (K = 1) runs the same code with nothing to overlap: ~6 k cycles of prologue (state columns,
-// 74 KB of bank by LDS-DMA), ~13 k cycles with the four roles sharing the SIMD, a ~6 k-cycle observer tail (role 3 writes
+// 74 KB of bank by LDS-DMA), ~12 k cycles with the four roles sharing the SIMD, a ~6 k-cycle observer tail (role 3 writes
 // the outputs and the lidar waves the sticky columns beside it), and the write-back of the ~25 MB it dirtied at the
 // end of the kernel.
 // ---------------------------------------------------------------------------------------------------------
