@@ -1048,7 +1048,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
     }
     int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
-    unsigned last_ev = 0u; // the last step's reward / done / flags, written by this role after the loop
     // (the state is wanted in registers BEFORE barrier 0, under the bank's staging: left to itself the compiler sinks the
     // loads below the barrier and the first step starts a memory round trip late)
     asm volatile("" : "+v"(x), "+v"(y), "+v"(vx), "+v"(vy), "+v"(ang), "+v"(w), "+v"(cum));
@@ -1227,10 +1226,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool done = colliding | done3;
     const bool do_reset = done & auto_reset;
-    // bits 0-4: the SSG_EV_* flags, bit 8: done, bits 9-10: reward (0: -0.01, 1: +1, 2: -1)
-    last_ev = (colliding ? SSG_EV_COLLIDING : 0u) | (goal_reached ? SSG_EV_GOAL_REACHED : 0u) | ((oob_x | oob_y) ? SSG_EV_OUT_OF_BOUNDS : 0u) |
-              ((steps_after >= c.max_steps) ? SSG_EV_MAX_STEPS : 0u) | ((alive == 0u) ? SSG_EV_NO_GOALS_LEFT : 0u) | (done ? 256u : 0u) |
-              ((rew == 1.0) ? 512u : ((rew == -1.0) ? 1024u : 0u));
 
     if (live && !SSG_ABL(6)) {
         // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
@@ -1271,11 +1266,26 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     SSG_STAMP_K(5);
     } // k
-    if (live) { // the last step's outputs (the observer wrote those of the steps before)
-        const int el = el_;
-        st_out(&reward_out[el], (last_ev & 512u) ? 1.0 : ((last_ev & 1024u) ? -1.0 : -0.01));
-        st_out(&done_out[el], (uint8_t)((last_ev >> 8) & 1u));
-        if (flags_out) st_out(&flags_out[el], (uint8_t)(last_ev & 0xFFu));
+    if (live) {
+        // The last step's outputs (the observer wrote those of the steps before), from the same LDS words the observer
+        // reads: determine_reward (ship_env.py:62-77) and is_done (ship_env.py:115-134).
+        const int el = el_, par = (K - 1) & 1;
+        const unsigned gd = gdone[par * EPW + tl];
+        const bool colliding = (gres[par * EPW + tl] != 0u) | ((gd & 2u) != 0u);
+        const bool goal_reached = (gd & 4u) != 0u;
+        double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
+        if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;
+        st_out(&reward_out[el], rew);
+        st_out(&done_out[el], (uint8_t)((colliding | ((gd & 1u) != 0u)) ? 1 : 0));
+        if (flags_out) {
+            unsigned ev = 0;
+            if (colliding) ev |= SSG_EV_COLLIDING;
+            if (goal_reached) ev |= SSG_EV_GOAL_REACHED;
+            if (gd & 8u) ev |= SSG_EV_OUT_OF_BOUNDS;
+            if (gd & 16u) ev |= SSG_EV_MAX_STEPS;
+            if (gd & 32u) ev |= SSG_EV_NO_GOALS_LEFT;
+            st_out(&flags_out[el], (uint8_t)ev);
+        }
     }
     SSG_STAMP(10);
     SSG_STAMP_FLUSH(6);
