@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 5 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
+#define SSG_ABI_VERSION 6 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
                              4: map record without dtMin/dtMax (SSG_MAP_STRIDE 145, SSG_PLANE_DOUBLES 5);
-                             5: ssg_config.map_ring, ssg_refill_worlds (a brand-new world per episode, generated on the device) */
+                             5: ssg_config.map_ring, ssg_refill_worlds (a brand-new world per episode, generated on the device);
+                             6: ssg_rollout_traj (every step of a fused rollout lands in its own slot of a trajectory buffer) */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -223,6 +224,17 @@ int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double 
 #define SSG_ROLLOUT_STEPS_PER_LAUNCH 100 /* steps fused into one launch of the step kernel by ssg_rollout */
 int ssg_rollout(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev_obs, double *dev_reward,
                 uint8_t *dev_done, uint8_t *dev_flags /* nullable */, void *stream);
+
+/* The same K steps, with EVERY step's outputs kept: step k writes its observation rows at dev_obs + k * step_stride_envs * D
+ * doubles (D = history*(6+n_beams)) and its reward / done / flags at element k * step_stride_envs of their buffers — the
+ * (obs, reward, done) of every step that the reference's rollout loop consumes (train/random.py:14-27: `obs, reward, done, _ =
+ * env.step(action)` inside the loop), as trajectory tensors [K][step_stride_envs][...].  step_stride_envs = n_envs gives
+ * contiguous [K][n_envs] tensors; a larger stride interleaves this handle's shard into a wider [K][total_envs] layout;
+ * 0 = ssg_rollout (every step rewrites the same rows).  Must be 0 or >= n_envs.  Same launches, same fusion, same results
+ * per step as K ssg_step calls — a fused step's outputs just no longer overwrite the previous step's, so all of them reach
+ * HBM (233 B per env-step at 8 beams, history 2) and every fused step can be checked against the oracle. */
+int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev_obs, double *dev_reward,
+                     uint8_t *dev_done, uint8_t *dev_flags /* nullable */, int64_t step_stride_envs, void *stream);
 
 /* Random-action rollout driver (train/random.py:14-27 batched): fills i32[K][n_envs] with a counter-based
  * Philox4x32-10 stream keyed by (seed, step0+k, env_id_base+e), uniform on Discrete(3) (ship_env.py:19). */

@@ -104,6 +104,7 @@ def lib():
         L.ora_world_at.argtypes = [C.c_void_p, C.c_int]
         L.ora_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.ora_batch_reset.argtypes = [C.c_void_p, C.c_int, C.POINTER(Config), C.POINTER(Bank), C.POINTER(C.c_int32), dp]
+        L.ora_batch_auto_reset.argtypes = [C.c_void_p, C.c_int, C.POINTER(Bank), C.POINTER(C.c_uint8), dp]
         L.ora_batch_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(Bank), C.POINTER(C.c_int32), dp, dp,
                                      C.POINTER(C.c_uint8), C.c_int, C.c_int]
         L.ora_action.restype = C.c_int32
@@ -260,6 +261,12 @@ class Batch:
                              _dp(self.obs), _dp(self.reward), self.done.ctypes.data_as(C.POINTER(C.c_uint8)),
                              int(auto_reset), int(n_threads))
         return self.obs.copy(), self.reward.copy(), self.done.copy()
+
+    def auto_reset_done(self):
+        """After step(auto_reset=False): move the done envs to their next bank record as the fused call would have; returns
+        the observation rows (reset observations for the done envs)."""
+        lib().ora_batch_auto_reset(self._p, self.n, C.byref(self.bank), self.done.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(self.obs))
+        return self.obs.copy()
 
     def rollout(self, seed, env_base, K, n_threads=1):
         return lib().ora_rollout(self._p, self.n, C.byref(self.bank), int(seed), int(env_base), int(K), int(n_threads),

@@ -617,6 +617,20 @@ void ora_batch_step(ora_world *ws, int n, const ora_bank *bank, const int32_t *a
     }
 }
 
+/* The auto-reset half of ora_batch_step on its own: after a step taken with auto_reset = 0 (so that the step's
+ * colliding / goal_reached attributes can still be read), move every done env to its next bank record exactly as the
+ * fused call does; the reset observation overwrites the env's row. */
+void ora_batch_auto_reset(ora_world *ws, int n, const ora_bank *bank, const uint8_t *done, double *obs)
+{
+    for (int e = 0; e < n; e++) {
+        ora_world *w = &ws[e];
+        int D = w->n_states * w->cfg.history;
+        if (!done[e]) continue;
+        w->episodes++;
+        reset_from_bank(w, bank, next_map(bank, w->map_id), obs + (size_t)e * D);
+    }
+}
+
 /* Philox4x32-10 (Salmon et al. 2011), counter = (env_lo, env_hi, step_lo, step_hi), key = seed. */
 static inline void philox_round(uint32_t c[4], const uint32_t k[2])
 {

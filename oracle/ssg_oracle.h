@@ -204,6 +204,7 @@ void ora_batch_reset(ora_world *ws, int n, const ora_config *cfg, const ora_bank
                      double *obs /* [n][H*F] */);
 void ora_batch_step(ora_world *ws, int n, const ora_bank *bank, const int32_t *actions, double *obs, double *reward,
                     uint8_t *done, int auto_reset, int n_threads);
+void ora_batch_auto_reset(ora_world *ws, int n, const ora_bank *bank, const uint8_t *done, double *obs);
 /* counter-based action stream shared with the HIP side (Philox4x32-10) */
 int32_t ora_action(uint64_t seed, uint64_t step, uint64_t env_id);
 void ora_fill_actions(uint64_t seed, uint64_t step0, int K, int64_t env_base, int n, int32_t *out /* [K][n] */);

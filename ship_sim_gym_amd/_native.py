@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSG_LIB_PATH: development override (tools/build_variant.sh builds diagnostic variants next to the product library)
 LIB_PATH = os.environ.get("SSG_LIB_PATH") or os.path.join(_HERE, "libshipsim.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3
 MAP_STRIDE = 145
 MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 5
@@ -25,7 +25,7 @@ EXPORTS = (
     "ssg_config_set_ship", "ssg_state_nbytes", "ssg_state_field", "ssg_bind_state", "ssg_set_map_bank", "ssg_reset",
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
-    "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry",
+    "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_rollout_traj",
 )
 
 
@@ -88,6 +88,7 @@ def lib():
     L.ssg_reset.argtypes = [vp, vp, vp, vp, vp]
     L.ssg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.ssg_rollout.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.ssg_rollout_traj.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp]
     L.ssg_fill_actions.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp]
     L.ssg_generate_bank.argtypes = [vp, C.c_uint64, C.c_double, vp, C.c_int, vp, vp]
     L.ssg_debug_copy8.argtypes = [vp, vp, C.c_size_t, vp]

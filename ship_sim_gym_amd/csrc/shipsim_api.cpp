@@ -17,7 +17,7 @@ struct ssg_handle {
     ssg_config cfg;
     ssg::DevCfg dev{};
     int n_pad = 0;
-    size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, nbytes = 0;
+    size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
     size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0;
     ssg::DynCfg dyn{};
@@ -336,6 +336,7 @@ void refresh_dev(ssg_handle *h)
     d.i32cols = base ? reinterpret_cast<int32_t *>(base + h->off_i32) : nullptr;
     d.mask = base ? reinterpret_cast<uint8_t *>(base + h->off_mask) : nullptr;
     d.obs2 = (base && c.history > 2) ? reinterpret_cast<double *>(base + h->off_obs2) : nullptr;
+    d.obsH = (base && c.history > 2) ? reinterpret_cast<double *>(base + h->off_obsH) : nullptr;
     d.bank = h->bank;
     d.n_ships = c.n_ships;
     const bool dyn = base && c.n_ships > 1;
@@ -471,7 +472,9 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     h->off_i32 = h->off_f64 + (size_t)(ssg::COL_LIDAR + cfg->n_beams) * np * sizeof(double);
     h->off_mask = h->off_i32 + (size_t)ssg::ICOL_COUNT * np * sizeof(int32_t);
     h->off_obs2 = (h->off_mask + np + 255) & ~(size_t)255;
-    h->nbytes = (cfg->history > 2) ? h->off_obs2 + np * (size_t)(2 * (6 + cfg->n_beams)) * sizeof(double) : h->off_mask + np;
+    // history > 2: the step kernel's two-frame staging rows, then the handle's own [n][H*F] observation rows
+    h->off_obsH = h->off_obs2 + np * (size_t)(2 * (6 + cfg->n_beams)) * sizeof(double);
+    h->nbytes = (cfg->history > 2) ? h->off_obsH + np * (size_t)(cfg->history * (6 + cfg->n_beams)) * sizeof(double) : h->off_mask + np;
     if (cfg->map_ring > 0) { // work queue of the ring refill: (env, episode) pairs + its length
         h->off_ring_queue = (h->nbytes + 255) & ~(size_t)255;
         h->off_ring_count = h->off_ring_queue + np * (size_t)cfg->map_ring * sizeof(unsigned long long);
@@ -559,6 +562,8 @@ int ssg_bind_state(ssg_handle *h, void *dev_state)
     return SSG_OK;
 }
 
+static int ring_refill(ssg_handle *h, double *dev_raw, void *stream);
+
 int ssg_init_state(ssg_handle *h, void *stream)
 {
     int rc = check_ready(h, false);
@@ -566,6 +571,9 @@ int ssg_init_state(ssg_handle *h, void *stream)
     hipError_t e = hipMemsetAsync(h->state, 0, h->nbytes, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_init_state: ") + hipGetErrorString(e));
     h->zeroed = true;
+    // map_ring mode: the episode counters and the rings' "worlds drawn" counters were just zeroed together, so the rings
+    // must hold episodes 0 .. R-1 again: redraw them (the bookkeeping and the bank never disagree)
+    if (h->cfg.map_ring > 0 && h->ring_ready) return ring_refill(h, nullptr, stream);
     return SSG_OK;
 }
 
@@ -660,16 +668,24 @@ static int prepare(ssg_handle *h)
 int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
              uint8_t *dev_flags, void *stream)
 {
-    return ssg_rollout(h, dev_actions, 1, dev_obs, dev_reward, dev_done, dev_flags, stream);
+    return ssg_rollout_traj(h, dev_actions, 1, dev_obs, dev_reward, dev_done, dev_flags, 0, stream);
 }
 
 int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_obs, double *dev_reward,
                 uint8_t *dev_done, uint8_t *dev_flags, void *stream)
 {
+    return ssg_rollout_traj(h, dev_actions, K, dev_obs, dev_reward, dev_done, dev_flags, 0, stream);
+}
+
+int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_obs, double *dev_reward,
+                     uint8_t *dev_done, uint8_t *dev_flags, int64_t step_stride_envs, void *stream)
+{
     int rc = check_ready(h, true);
     if (rc != SSG_OK) return rc;
     if (!dev_actions || !dev_obs || !dev_reward || !dev_done || K < 1)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_step/ssg_rollout: NULL buffer or K < 1");
+    if (step_stride_envs != 0 && step_stride_envs < (int64_t)h->cfg.n_envs)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_rollout_traj: step_stride_envs must be 0 or >= n_envs (steps would overlap)");
     rc = prepare(h);
     if (rc != SSG_OK) return rc;
     rc = flush_remap(h, stream);
@@ -682,6 +698,13 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
         const int v = s ? std::atoi(s) : SSG_ROLLOUT_STEPS_PER_LAUNCH;
         return v < 1 ? 1 : v;
     }();
+    const long long traj = (long long)step_stride_envs;
+    const size_t D = (size_t)h->cfg.history * (size_t)(6 + h->cfg.n_beams);
+    // output slots of step k (the same rows for every step when traj == 0)
+    auto obs_at = [&](int k) { return dev_obs + (size_t)k * (size_t)traj * D; };
+    auto rew_at = [&](int k) { return dev_reward + (size_t)k * (size_t)traj; };
+    auto done_at = [&](int k) { return dev_done + (size_t)k * (size_t)traj; };
+    auto flags_at = [&](int k) { return dev_flags ? dev_flags + (size_t)k * (size_t)traj : nullptr; };
     const bool dyn = h->cfg.n_ships > 1;
     if (h->cfg.history > 2 || dyn) {
         // non-default history: one launch per step into the staging rows, then the frame shift (see the kernel).
@@ -702,9 +725,9 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
                 if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
             }
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
-                                            shift ? h->dev.obs2 : dev_obs, dev_reward, dev_done, dev_flags,
+                                            shift ? h->dev.obs2 : obs_at(k), rew_at(k), done_at(k), flags_at(k), 0,
                                             static_cast<hipStream_t>(stream));
-            if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, dev_done, dev_obs, static_cast<hipStream_t>(stream));
+            if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
             if (e != hipSuccess) {
                 // the step kernel is what empties the dyn queue counter: do not leave it set for the next call
                 if (dyn) (void)hipMemsetAsync(h->dev.dyn_count, 0, sizeof(unsigned), static_cast<hipStream_t>(stream));
@@ -725,7 +748,7 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
             int kk = (K - k < kFuse) ? (K - k) : kFuse;
             kk = kk < h->ring_credit ? kk : h->ring_credit;
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,
-                                            dev_obs, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
+                                            obs_at(k), rew_at(k), done_at(k), flags_at(k), traj, static_cast<hipStream_t>(stream));
             if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
             h->ring_credit -= kk;
             k += kk;
@@ -735,7 +758,7 @@ int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_ob
     for (int k = 0; k < K; k += kFuse) {
         const int kk = (K - k < kFuse) ? (K - k) : kFuse;
         hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,
-                                        dev_obs, dev_reward, dev_done, dev_flags, static_cast<hipStream_t>(stream));
+                                        obs_at(k), rew_at(k), done_at(k), flags_at(k), traj, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
     }
     return SSG_OK;
@@ -780,6 +803,11 @@ int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *d
     if (!(width_frac > 0.0) || !(width_frac <= 1.0)) return fail(h, SSG_ERR_BAD_ARG, "ssg_refill_worlds: bad width_frac");
     h->ring_seed = seed;
     h->ring_width_frac = width_frac;
+    if (!h->zeroed) { // zero a freshly bound blob HERE, before the rings' counters are written (a later full ssg_reset must not wipe them)
+        hipError_t e = hipMemsetAsync(h->state, 0, h->nbytes, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_refill_worlds: ") + hipGetErrorString(e));
+        h->zeroed = true;
+    }
     rc = ring_refill(h, dev_raw, stream);
     if (rc == SSG_OK) h->ring_ready = true;
     return rc;

@@ -43,6 +43,7 @@ struct DevCfg {
     int n_beams, history /* frames the step kernel writes: min(full_history, 2) */, max_steps, n_goals;
     int full_history;     // EnvConfig.HISTORY_SIZE
     double *obs2;         // [n_envs][2F] staging rows of the step kernel when full_history > 2 (inside the state blob)
+    double *obsH;         // [n_envs][H*F] the handle's own observation rows when full_history > 2 (frame-shift source)
     unsigned flags;
     int n_maps;
     int map_ring;         // 0, or R: env e owns bank records [e*R, e*R + R) as a ring of worlds (one per episode)
@@ -82,8 +83,9 @@ struct DynCfg {
     int stop_after;         // development aid (SSG_DYN_STOP): leave the dyn kernel after phase n; 0 = run it all
 };
 
+// traj: env rows between the output slots of consecutive steps of the launch (0 = every step rewrites the same rows)
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions_kn, int K, double *obs,
-                       double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream);
+                       double *reward, uint8_t *done, uint8_t *flags, long long traj, hipStream_t stream);
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);

@@ -719,10 +719,12 @@ template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
                                                        uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out,
-                                                       const int K)
+                                                       const int K, const long long traj)
 {
     // K consecutive steps in one launch (K = 1 for ssg_step): the bank is staged once and role 3 keeps the body state in
-    // registers.  Step k reads actions_kn + k*n_envs; obs / reward / done / flags are rewritten by every step.
+    // registers.  Step k reads actions_kn + k*n_envs and writes its obs / reward / done / flags `k * traj` env rows past the
+    // buffers' starts: traj = 0 rewrites the same [n_envs] rows every step (ssg_rollout), traj >= n_envs lays the steps of
+    // the launch out as a trajectory [K][traj] (ssg_rollout_traj: what train/random.py:14-27 consumes, every step).
     constexpr int NB0 = nb_lo(NB);
     const int role = threadIdx.x / EPW;                        // wave-uniform (EPW is a multiple of 64)
     const int tl = threadIdx.x - role * EPW;                   // env slot inside the workgroup
@@ -953,8 +955,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 const bool goal_reached = (gd & 4u) != 0u;
                 double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
                 if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;
-                st_out(&reward_out[el_], rew);
-                st_out(&done_out[el_], (uint8_t)((colliding | ((gd & 1u) != 0u)) ? 1 : 0));
+                const size_t eo = (size_t)el_ + (size_t)k * (size_t)traj; // this step's slot of the trajectory (uniform offset)
+                st_out(&reward_out[eo], rew);
+                st_out(&done_out[eo], (uint8_t)((colliding | ((gd & 1u) != 0u)) ? 1 : 0));
                 if (flags_out) {
                     unsigned ev = 0;
                     if (colliding) ev |= SSG_EV_COLLIDING;
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                     if (gd & 8u) ev |= SSG_EV_OUT_OF_BOUNDS;
                     if (gd & 16u) ev |= SSG_EV_MAX_STEPS;
                     if (gd & 32u) ev |= SSG_EV_NO_GOALS_LEFT;
-                    st_out(&flags_out[el_], (uint8_t)ev);
+                    st_out(&flags_out[eo], (uint8_t)ev);
                 }
             }
             SSG_STAMP_K(4);
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             }
             SSG_STAMP_K(6);
             {
-                double *__restrict__ obase = obs + (size_t)tile_e0 * (size_t)(F * c.history); // tile start in HBM
+                double *__restrict__ obase = obs + ((size_t)tile_e0 + (size_t)k * (size_t)traj) * (size_t)(F * c.history); // tile start in HBM, this step's slot
                 const int rows_live = min(64, c.n_envs - tile_e0);                             // rows of this tile in range
                 if (!SSG_ABL(7)) {
                     // (the result keys are in registers by now; in a single-step launch the lidar waves still read them for
@@ -1269,7 +1272,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     if (live) {
         // The last step's outputs (the observer wrote those of the steps before), from the same LDS words the observer
         // reads: determine_reward (ship_env.py:62-77) and is_done (ship_env.py:115-134).
-        const int el = el_, par = (K - 1) & 1;
+        const int par = (K - 1) & 1;
+        const size_t el = (size_t)el_ + (size_t)(K - 1) * (size_t)traj;
         const unsigned gd = gdone[par * EPW + tl];
         const bool colliding = (gres[par * EPW + tl] != 0u) | ((gd & 2u) != 0u);
         const bool goal_reached = (gd & 4u) != 0u;
@@ -1321,10 +1325,15 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
     c.i32cols[ICOL_STEP * np + e] = 0;
     c.i32cols[ICOL_MAP * np + e] = m;
     c.mask[e] = (uint8_t)((1u << c.n_goals) - 1u);
-    if (obs) {
-        const int F = 6 + c.n_beams;
-        double *orow = obs + (size_t)e * (size_t)(F * c.full_history);
-        for (int i = 0; i < F * (c.full_history - 1); ++i) orow[i] = -1.0; // deque([-1]*n), ship_env.py:180-181
+    // deque([-1]*n), ship_env.py:180-181, then the spawn frame — into the caller's rows and, with HISTORY_SIZE > 2, into the
+    // handle's own copy of the rows (the frame-shift kernel's source: the caller's buffer is output only)
+    const int F = 6 + c.n_beams;
+    double *dst[2] = {obs ? obs + (size_t)e * (size_t)(F * c.full_history) : nullptr,
+                      c.obsH ? c.obsH + (size_t)e * (size_t)(F * c.full_history) : nullptr};
+    for (int t = 0; t < 2; ++t) {
+        double *orow = dst[t];
+        if (!orow) continue;
+        for (int i = 0; i < F * (c.full_history - 1); ++i) orow[i] = -1.0;
         orow += F * (c.full_history - 1);
         orow[0] = c.spawn_x; orow[1] = c.spawn_y; orow[2] = 0.0; orow[3] = 0.0;
         orow[4] = rec[SSG_MAP_OFF_SPAWN_GOAL]; orow[5] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
@@ -1344,20 +1353,23 @@ __global__ void remap_map_ids_kernel(const DevCfg c)
 
 // ---------------------------------------------------------------------------------------------------------
 // HISTORY_SIZE > 2 (non-default; every reference script uses 2): the step kernel writes its two frames into the
-// staging rows obs2 and this kernel maintains the caller's [n_envs][H*F] rows like the reference's deque
-// (ship_env.py:113,180-181): drop the oldest frame, append the new one; an auto-reset env gets (H-1) frames of -1
-// and the spawn frame.  One lane per env, sequential over the row (a lane only reads ahead of what it writes).
+// staging rows obs2 and this kernel maintains the handle's own [n_envs][H*F] rows (obsH, inside the state blob) like the
+// reference's deque (ship_env.py:113,180-181): drop the oldest frame, append the new one; an auto-reset env gets (H-1)
+// frames of -1 and the spawn frame.  The updated row is then copied to the caller's output row (which is never read: a
+// masked ssg_reset into any buffer, or a trajectory slot per step, leave the history intact).  One lane per env,
+// sequential over the row (a lane only reads ahead of what it writes).
 // ---------------------------------------------------------------------------------------------------------
 __global__ void history_shift_kernel(const DevCfg c, const uint8_t *__restrict__ done, double *__restrict__ obs)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs) return;
     const int F = 6 + c.n_beams, H = c.full_history;
-    double *row = obs + (size_t)e * (size_t)(F * H);
+    double *row = c.obsH + (size_t)e * (size_t)(F * H);
+    double *out = obs + (size_t)e * (size_t)(F * H);
     const double *nf = c.obs2 + (size_t)e * (size_t)(2 * F) + F; // newest frame (or the spawn frame after a reset)
     const bool was_reset = done[e] && (c.flags & SSG_FLAG_AUTO_RESET);
-    for (int j = 0; j < F * (H - 1); ++j) row[j] = was_reset ? -1.0 : row[j + F];
-    for (int j = 0; j < F; ++j) row[F * (H - 1) + j] = nf[j];
+    for (int j = 0; j < F * (H - 1); ++j) { const double v = was_reset ? -1.0 : row[j + F]; row[j] = v; out[j] = v; }
+    for (int j = 0; j < F; ++j) { const double v = nf[j]; row[F * (H - 1) + j] = v; out[F * (H - 1) + j] = v; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1409,7 +1421,7 @@ __global__ void fill_actions_kernel(uint64_t seed, uint64_t step0, int K, long l
 // The step kernel is instantiated per beam count; the instantiations are spread over four translation units
 // (this file compiled with -DSSG_NB_GROUP=0..3, four beam counts each) so the library builds in parallel.
 // ---------------------------------------------------------------------------------------------------------
-using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *, int);
+using step_fn_t = void (*)(const DevCfg, const int32_t *, double *, double *, uint8_t *, uint8_t *, int, long long);
 // variant: 0 = default, 1 = SSG_FLAG_EXACT_LIDAR (beam counts 8 and 10), 2 = config 4 / DYN (64 or 256 envs per workgroup)
 
 #ifdef SSG_NB_GROUP
@@ -1502,12 +1514,12 @@ hipError_t prepare_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes)
 }
 
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions, int K, double *obs,
-                       double *reward, uint8_t *done, uint8_t *flags, hipStream_t stream)
+                       double *reward, uint8_t *done, uint8_t *flags, long long traj, hipStream_t stream)
 {
     step_fn_t k = step_fn(c.n_beams, epw, lds, variant_of(c));
     if (!k) return hipErrorInvalidValue;
     const int grid = (c.n_envs + epw - 1) / epw;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K, traj);
     return hipGetLastError();
 }
 

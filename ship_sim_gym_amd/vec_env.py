@@ -28,6 +28,7 @@ Two map modes:
   Mersenne-Twister draws (use ``"fresh"`` for that); same geometry code as the host path, bit for bit.
 """
 import ctypes as C
+import inspect
 import math
 
 import numpy as np
@@ -209,16 +210,23 @@ class ShipVecEnv(*_BASES):
         self._handles = {}
         self._await_reset = np.zeros(self.num_envs, dtype=bool)  # rllib flow: done envs already re-initialised
         self._reset_obs_h = None
-        for base in _BASES:  # the trainers' base-class constructors (SB: VecEnv.__init__(num_envs, obs_space, act_space))
-            if base is object:
+        self._call_base_ctors()
+
+    def _call_base_ctors(self):
+        """The trainers' base-class constructors.  stable-baselines declares VecEnv.__init__(num_envs, observation_space,
+        action_space), ray >= 1.x VectorEnv.__init__(observation_space, action_space, num_envs), ray 0.6 (the reference's
+        pin) none: each is called with the KEYWORDS its signature names, never positionally, and our own attributes are
+        re-asserted afterwards so that no base can have swapped them."""
+        mine = {"num_envs": self.num_envs, "observation_space": self.observation_space, "action_space": self.action_space}
+        for base in type(self).__mro__[1:]:
+            if base is object or "__init__" not in vars(base):
                 continue
             try:
-                base.__init__(self, self.num_envs, self.observation_space, self.action_space)
-            except TypeError:
-                try:
-                    base.__init__(self)
-                except Exception:
-                    pass
+                params = inspect.signature(base.__init__).parameters
+                base.__init__(self, **{k: v for k, v in mine.items() if k in params})
+            except Exception:
+                pass
+        self.num_envs, self.observation_space, self.action_space = mine["num_envs"], mine["observation_space"], mine["action_space"]
 
     @classmethod
     def from_env_fns(cls, env_fns, **kw):
@@ -375,19 +383,43 @@ class ShipVecEnv(*_BASES):
             N.check(rc, self._h, "ssg_step")
         return self.obs, self.reward, self.done, self.flags
 
-    def rollout_tensor(self, actions_kn):
-        """K back-to-back steps from a pre-generated int32 [K, N] action tensor (random-action throughput run)."""
+    def rollout_tensor(self, actions_kn, trajectory=False, out=None):
+        """K back-to-back steps from a pre-generated int32 [K, N] action tensor (random-action throughput run).
+
+        trajectory=False: every step rewrites the env's reused [N, ...] buffers; returns the LAST step's
+        (obs, reward, done, flags).  trajectory=True (ssg_rollout_traj): every step's outputs are kept, as the reference's
+        rollout loop sees them (train/random.py:14-27) — returns (obs [K, N, D], reward [K, N], done [K, N], flags [K, N])
+        device tensors; `out` = a tuple of four such preallocated tensors (first dimension >= K, contiguous) to write
+        into instead of allocating.  self.obs / reward / done / flags are left untouched in trajectory mode."""
         torch = _torch()
         K = int(actions_kn.shape[0])
-        o, r, d, f = self._out_ptrs()
-        if torch.cuda.current_device() == self._dev_index:
-            rc = N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, o, r, d, f, self._stream())
-        else:
-            with torch.cuda.device(self.device):
+        if not trajectory:
+            o, r, d, f = self._out_ptrs()
+            if torch.cuda.current_device() == self._dev_index:
                 rc = N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, o, r, d, f, self._stream())
+            else:
+                with torch.cuda.device(self.device):
+                    rc = N.lib().ssg_rollout(self._h, C.c_void_p(actions_kn.data_ptr()), K, o, r, d, f, self._stream())
+            if rc:
+                N.check(rc, self._h, "ssg_rollout")
+            return self.obs, self.reward, self.done, self.flags
+        n, D = self.num_envs, self.states_history
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = (torch.empty((K, n, D), dtype=torch.float64, device=self.device),
+                       torch.empty((K, n), dtype=torch.float64, device=self.device),
+                       torch.empty((K, n), dtype=torch.uint8, device=self.device),
+                       torch.empty((K, n), dtype=torch.uint8, device=self.device))
+            to, tr, td, tf = out
+            assert to.dtype == torch.float64 and tr.dtype == torch.float64 and td.dtype == torch.uint8 and tf.dtype == torch.uint8
+            assert tuple(to.shape[1:]) == (n, D) and all(tuple(t.shape[1:]) == (n,) for t in (tr, td, tf))
+            assert all(t.is_contiguous() and t.shape[0] >= K and t.device == self.device for t in out)
+            rc = N.lib().ssg_rollout_traj(self._h, C.c_void_p(actions_kn.data_ptr()), K, C.c_void_p(to.data_ptr()),
+                                          C.c_void_p(tr.data_ptr()), C.c_void_p(td.data_ptr()), C.c_void_p(tf.data_ptr()),
+                                          n, self._stream())
         if rc:
-            N.check(rc, self._h, "ssg_rollout")
-        return self.obs, self.reward, self.done, self.flags
+            N.check(rc, self._h, "ssg_rollout_traj")
+        return to[:K], tr[:K], td[:K], tf[:K]
 
     def random_actions(self, seed, step0, K):
         """int32 [K, N] Philox action stream keyed by (seed, step, global env id), generated on the device."""

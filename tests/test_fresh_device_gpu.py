@@ -136,3 +136,50 @@ def test_fresh_device_fused_rollout_equals_single_steps_and_vecenv_api(native):
     o, r, d, info = a.step(np.zeros(n, dtype=np.int64))
     assert o.shape == (n, 28) and r.shape == (n,)
     a.close(); b.close()
+
+
+def test_ring_bookkeeping_with_one_step_episodes_and_reinit(native):
+    """MAX_STEPS = 1: every step ends the episode, so an env consumes one world per step and the automatic refills run with
+    the current episode > 0 from the first one on.  Whatever the refill cadence, the record an env sits on must be the world
+    of its CURRENT episode (compared with a ring-64 generator of the same keys); zeroing the state mid-run
+    (ssg_init_state) restarts the episode counters AND the rings together."""
+    import ctypes as C
+    import torch
+    from ship_sim_gym_amd.config import EnvConfig
+
+    class E(EnvConfig):
+        MAX_STEPS = 1
+
+    n, R = 192, 4
+    v = _vec(n, ring=R, map_seed=5, n_beams=8, env_config=E)
+    gen = _vec(n, ring=64, map_seed=5, n_beams=8, env_config=E)
+    g = gen.bank.view(n, 64, -1)
+
+    def check_current_records(tag):
+        started = v.field(native.F_EPISODES).long()
+        cur = started - 1
+        assert int(cur.max()) < 64
+        idx = torch.arange(n, device=v.device)
+        mine = v.bank.view(n, R, -1)[idx, cur % R]
+        assert torch.equal(mine, g[idx, cur]), tag
+        assert torch.equal(v.field(native.F_MAP_ID).long(), idx * R + cur % R), tag
+
+    v.reset_tensor()
+    check_current_records("after the first reset")
+    acts = v.random_actions(3, 0, 40)
+    for k in range(25):
+        _, _, done, _ = v.step_tensor(acts[k])
+        assert bool(done.all())
+        check_current_records("step %d" % k)
+    v.rollout_tensor(acts[25:])  # fused path: launches of at most R-1 steps
+    check_current_records("after the fused rollout")
+    assert int(v.field(native.F_EPISODES).min()) == 41
+    # mid-run re-initialisation: counters and rings restart together
+    native.check(native.lib().ssg_init_state(v._h, v._stream()), v._h, "ssg_init_state")
+    v.reset_tensor()
+    assert int(v.field(native.F_EPISODES).max()) == 1
+    check_current_records("after ssg_init_state + reset")
+    for k in range(10):
+        v.step_tensor(acts[k])
+        check_current_records("re-init step %d" % k)
+    v.close(); gen.close()

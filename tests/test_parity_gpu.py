@@ -163,6 +163,93 @@ def test_fused_rollout_equals_single_steps(torch_cuda, native):
         assert a.stats() == b.stats()
 
 
+def test_fused_trajectory_every_step_matches_oracle(torch_cuda, oracle, native):
+    """The kernel the headline times, checked step by step: ssg_rollout_traj keeps the (obs, reward, done, flags) of EVERY
+    step of its fused launches (what train/random.py:14-27 consumes); each of the 2 x 100 fused steps + a ragged third
+    launch of 37 is compared with the oracle stepping the same envs on the same Philox actions."""
+    torch = torch_cuda
+    vec = _vec(2048, n_maps=64, n_beams=8)
+    n, K = vec.num_envs, 237
+    ob = oracle.Batch(n, oracle_cfg(oracle, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    acts = vec.random_actions(4242, 0, K)
+    acts_h = acts.cpu().numpy()
+    to, tr, td, tf = vec.rollout_tensor(acts, trajectory=True)
+    assert tuple(to.shape) == (K, n, vec.states_history) and tuple(tr.shape) == tuple(td.shape) == tuple(tf.shape) == (K, n)
+    g_obs, g_rew, g_done, g_flags = to.cpu().numpy(), tr.cpu().numpy(), td.cpu().numpy(), tf.cpu().numpy()
+    worst, n_done = 0.0, 0
+    for k in range(K):
+        ob.step(acts_h[k], auto_reset=False)
+        pk = ob.peek_all()  # the oracle's colliding / goal_reached attributes of this step
+        np.testing.assert_array_equal((g_flags[k] & native.EV_COLLIDING) != 0, pk[:, 9] != 0, err_msg="colliding, fused step %d" % k)
+        np.testing.assert_array_equal((g_flags[k] & native.EV_GOAL_REACHED) != 0, pk[:, 10] != 0, err_msg="goal, fused step %d" % k)
+        np.testing.assert_array_equal(g_done[k], ob.done, err_msg="done flags differ at fused step %d" % k)
+        np.testing.assert_array_equal(g_rew[k], ob.reward, err_msg="rewards differ at fused step %d" % k)
+        r_obs = ob.auto_reset_done()  # VecEnv semantics: the done envs move to the next bank record; rows = reset obs
+        err = float(np.max(np.abs(g_obs[k] - r_obs)))
+        assert err <= ATOL, "obs differ by %g at fused step %d" % (err, k)
+        worst = max(worst, err)
+        n_done += int(ob.done.sum())
+    assert n_done > 300
+    print("fused trajectory: max |obs - oracle| = %.3e over %d steps, %d episode ends" % (worst, K, n_done))
+    # the trajectory's last step is what the overwrite mode leaves, and the state columns agree bitwise
+    b = _vec(2048, n_maps=64, n_beams=8)
+    b.reset_tensor()
+    b.rollout_tensor(acts)
+    torch.cuda.synchronize()
+    assert torch.equal(b.obs, to[K - 1]) and torch.equal(b.reward, tr[K - 1]) and torch.equal(b.done, td[K - 1])
+    assert torch.equal(b.flags, tf[K - 1]) and torch.equal(b.state, vec.state)
+
+
+def test_trajectory_mode_other_paths_and_strides(torch_cuda, native):
+    """ssg_rollout_traj on the paths that launch once per step (history 3, config 4), with a caller-provided buffer that
+    is longer than K, and through the raw ABI with a stride wider than n_envs: every slot equals the single-step outputs."""
+    torch = torch_cuda
+    import ctypes as C
+    from ship_sim_gym_amd.config import EnvConfig
+
+    class E3(EnvConfig):
+        HISTORY_SIZE = 3
+
+    for kw in (dict(n_beams=8), dict(env_config=E3), dict(n_ships=4)):
+        a, b = _vec(700, n_maps=16, **kw), _vec(700, n_maps=16, **kw)
+        a.reset_tensor(); b.reset_tensor()
+        K = 130
+        acts = a.random_actions(31, 0, K)
+        n, D = a.num_envs, a.states_history
+        out = (torch.full((K + 3, n, D), 7.0, dtype=torch.float64, device=a.device), torch.full((K + 3, n), 7.0, dtype=torch.float64, device=a.device),
+               torch.full((K + 3, n), 7, dtype=torch.uint8, device=a.device), torch.full((K + 3, n), 7, dtype=torch.uint8, device=a.device))
+        to, tr, td, tf = b.rollout_tensor(acts, trajectory=True, out=out)
+        for k in range(K):
+            o, r, d, f = a.step_tensor(acts[k])
+            assert torch.equal(o, to[k]) and torch.equal(r, tr[k]) and torch.equal(d, td[k]) and torch.equal(f, tf[k]), (kw, k)
+        if "n_ships" in kw:  # (config 4's work queue is filled in scheduling order: compare the fields, not the raw blob)
+            for fid in (native.F_X, native.F_W, native.F_LIDAR, native.F_RUDDER, native.F_STEP_COUNT, native.F_MAP_ID, native.F_GOAL_MASK,
+                        native.F_STATS, native.F_TRAFFIC, native.F_GOAL_BODIES, native.F_DYN_FLAGS, native.F_EPISODES):
+                assert torch.equal(a.field(fid), b.field(fid)), fid
+        else:
+            assert torch.equal(a.state, b.state)
+        assert all(bool((t[K:] == 7).all()) for t in out)  # nothing written past step K-1
+    # raw ABI, stride 1000 > n_envs 700: this handle's shard of a wider [K][1000] layout; the gap columns stay untouched
+    a, b = _vec(700, n_maps=16, n_beams=8), _vec(700, n_maps=16, n_beams=8)
+    a.reset_tensor(); b.reset_tensor()
+    K, S, D = 120, 1000, a.states_history
+    acts = a.random_actions(32, 0, K)
+    to = torch.full((K, S, D), 9.0, dtype=torch.float64, device=a.device)
+    tr = torch.full((K, S), 9.0, dtype=torch.float64, device=a.device)
+    td = torch.full((K, S), 9, dtype=torch.uint8, device=a.device)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    L = native.lib()
+    native.check(L.ssg_rollout_traj(b._h, vp(acts), K, vp(to), vp(tr), vp(td), None, S, b._stream()), b._h, "traj")
+    for k in range(K):
+        o, r, d, _ = a.step_tensor(acts[k])
+        assert torch.equal(o, to[k, :700]) and torch.equal(r, tr[k, :700]) and torch.equal(d, td[k, :700])
+    assert bool((to[:, 700:] == 9).all()) and bool((tr[:, 700:] == 9).all()) and bool((td[:, 700:] == 9).all())
+    # overlapping slots are refused
+    rc = L.ssg_rollout_traj(b._h, vp(acts), K, vp(to), vp(tr), vp(td), None, 699, b._stream())
+    assert rc == -1 and b"step_stride_envs" in L.ssg_last_error(b._h)
+
+
 def test_shard_equivalence(torch_cuda, native):
     """N envs on one handle == the same envs split over two handles (env_id_base keyed), bitwise."""
     n = 1024
@@ -290,13 +377,20 @@ def test_vec_env_protocols(torch_cuda, native):
         _vec(4, env_config=E)
 
 
-def test_rllib_flow_terminal_obs_and_single_reset(torch_cuda, native):
+@pytest.mark.parametrize("hist", [2, 3])
+def test_rllib_flow_terminal_obs_and_single_reset(torch_cuda, native, hist):
     """RLlib VectorEnv flow (train/rllib/ppo.py:21-24,43): vector_step returns the TERMINAL observation of a done env,
     reset_at(i) is the single reset.  The trajectory must equal the SB-protocol env's (in-kernel auto-reset) step for
     step: same rewards / dones, same observations except on done rows, where SB reports the reset observation that
-    RLlib gets from reset_at."""
-    sb = _vec(64, n_maps=8)
-    rl = _vec(64, n_maps=8, rllib=True)
+    RLlib gets from reset_at.  HISTORY_SIZE 3 takes the frame-shift route: the steps after a reset must show the
+    reference's [-1]*(H-1) frames + spawn frame history, not the finished episode's frames."""
+    from ship_sim_gym_amd.config import EnvConfig
+
+    class E(EnvConfig):
+        HISTORY_SIZE = hist
+
+    sb = _vec(64, n_maps=8, env_config=E)
+    rl = _vec(64, n_maps=8, rllib=True, env_config=E)
     assert rl.rllib and not rl.auto_reset
     o_sb, o_rl = sb.reset(), np.stack(rl.vector_reset())
     np.testing.assert_array_equal(o_sb, o_rl)
@@ -311,7 +405,7 @@ def test_rllib_flow_terminal_obs_and_single_reset(torch_cuda, native):
         np.testing.assert_array_equal(o_rl[~d_sb], o_sb[~d_sb])
         for i in np.nonzero(d_sb)[0]:
             n_done += 1
-            assert not np.all(o_rl[i][:16] == -1)                 # terminal observation: a real previous frame
+            assert not np.all(o_rl[i][16 * (hist - 2):16 * (hist - 1)] == -1)  # terminal observation: a real previous frame
             np.testing.assert_array_equal(rl.reset_at(int(i)), o_sb[i])   # the one reset == SB's auto-reset observation
     assert n_done > 30
     np.testing.assert_array_equal(sb.field(native.F_MAP_ID).cpu().numpy(), rl.field(native.F_MAP_ID).cpu().numpy())

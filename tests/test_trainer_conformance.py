@@ -163,3 +163,25 @@ def test_rllib_flow_returns_terminal_obs_and_resets_once():
     done[:] = False
     v.vector_step([0] * 6)
     assert len(resets) == 1
+
+
+def test_base_constructors_get_keywords_not_positions(vec_env_with_fake_trainers):
+    """ray >= 1.x declares VectorEnv.__init__(observation_space, action_space, num_envs) — the reverse of stable-baselines'
+    (num_envs, observation_space, action_space).  Each base must receive the right object under the right name, and the
+    env's own attributes must survive the base constructors."""
+    ve, VecEnv, VectorEnv = vec_env_with_fake_trainers
+    seen = {}
+
+    def ray1_init(self, observation_space, action_space, num_envs):
+        seen["ray"] = (observation_space, action_space, num_envs)
+        self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
+    VectorEnv.__init__ = ray1_init
+    try:
+        v = _Stub.make(ve)
+        v.observation_space = "OBS"
+        v._call_base_ctors()
+        assert seen["ray"] == ("OBS", v.action_space, 6)
+        assert getattr(v, "sb_init_called", False)                 # the SB-shaped base ran too, with its own order
+        assert (v.num_envs, v.observation_space) == (6, "OBS") and v.action_space.n == 3
+    finally:
+        del VectorEnv.__init__

@@ -18,6 +18,11 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         v2 = sorted(v)
         print("trace:", n[:60], "calls", len(v), "avg_us %.3f med_us %.3f min_us %.3f" % (sum(v) / len(v) / 1e3, v2[len(v2) // 2] / 1e3, v2[0] / 1e3), meta[n])
 big = {}
+step_avg_ns = None
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    v = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"]]
+    if v:
+        step_avg_ns = sum(v) / len(v)
 print("== PMC (mean per dispatch of the step kernel) ==")
 for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
@@ -27,7 +32,8 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         print("%-28s mean %.6g  (n=%d)   largest dispatch %.6g" % (k, sum(v) / len(v), len(v), max(v)))
-        if k in ("FETCH_SIZE", "WRITE_SIZE"):
+        if k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+                 "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD"):
             big[k] = sum(v) / len(v)  # every rollout launch runs the same 100 steps
 
 print("== FETCH_SIZE / WRITE_SIZE calibration (tools/calib_pmc.py: 1 GiB read + 1 GiB written per dispatch, 8 B per lane) ==")
@@ -52,3 +58,26 @@ if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
                "fetch_calibration": fcal, "write_calibration": wcal,
                "source": os.environ.get("SSG_PROF_SOURCE", os.path.basename(out))},
               open(os.path.join(out, "traffic.json"), "w"))
+    # what bench.py derives roofline.hbm_measured / valu_issue_frac / bound from (only when source_sha matches the tree's)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    per = float(envs * spl)
+    cj = {"source_sha": bench.source_sha(), "mode": os.environ.get("SSG_PROF_MODE", "trajectory"),
+          "source": os.environ.get("SSG_PROF_SOURCE", os.path.basename(out)), "envs": envs, "steps_per_launch": spl,
+          "hbm_bytes_per_env_step": hbm / per, "fetch_bytes_per_env_step": big["FETCH_SIZE"] / fcal * 1024 / per,
+          "write_bytes_per_env_step": big["WRITE_SIZE"] / wcal * 1024 / per,
+          "avg_launch_us_profiled": (step_avg_ns or 0) / 1e3}
+    if "SQ_INSTS_VALU" in big:
+        cj["valu_wave_insts_per_env_step"] = big["SQ_INSTS_VALU"] / per
+        cj["salu_wave_insts_per_env_step"] = big.get("SQ_INSTS_SALU", 0) / per
+        cj["lds_wave_insts_per_env_step"] = big.get("SQ_INSTS_LDS", 0) / per
+    if "SQ_LDS_IDX_ACTIVE" in big and step_avg_ns:
+        # cycles the LDS pipe of a CU is busy / cycles of the launch (256 CUs, 2.4 GHz nominal)
+        cj["lds_pipe_busy_frac"] = big["SQ_LDS_IDX_ACTIVE"] / 256.0 / (step_avg_ns * 2.4)
+        cj["lds_bank_conflict_frac_of_busy"] = big.get("SQ_LDS_BANK_CONFLICT", 0) / big["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_ACTIVE_INST_VALU" in big and "SQ_WAVE_CYCLES" in big:
+        cj["valu_busy_frac_of_simd_cycles"] = big["SQ_ACTIVE_INST_VALU"] / (big["SQ_WAVE_CYCLES"] / 4.0)
+        cj["wait_any_frac_of_wave_cycles"] = big.get("SQ_WAIT_ANY", 0) / big["SQ_WAVE_CYCLES"]
+    json.dump(cj, open(os.path.join(out, "counters.json"), "w"), indent=1)
+    print("== counters.json ==")
+    print(json.dumps(cj, indent=1))
