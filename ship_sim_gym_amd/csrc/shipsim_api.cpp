@@ -19,7 +19,7 @@ struct ssg_handle {
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
-    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0;
+    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0;
     ssg::DynCfg dyn{};
     void *state = nullptr;
     const double *bank = nullptr;
@@ -347,6 +347,8 @@ void refresh_dev(ssg_handle *h)
     d.dyn_hash = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_hash) : nullptr;
     d.dyn_queue = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_queue) : nullptr;
     d.dyn_count = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_count) : nullptr;
+    d.dyn_qkey = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_qkey) : nullptr;
+    d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
 }
 
 
@@ -490,7 +492,9 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_hash = h->off_dyn_flag + np;
         h->off_dyn_queue = h->off_dyn_hash + np * sizeof(unsigned long long);
         h->off_dyn_count = h->off_dyn_queue + np * sizeof(int32_t);
-        h->nbytes = h->off_dyn_count + 256;
+        h->off_dyn_qkey = h->off_dyn_count + (((size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
+        h->off_dyn_sorted = h->off_dyn_qkey + np * sizeof(unsigned long long);
+        h->nbytes = h->off_dyn_sorted + np * sizeof(int32_t);
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -730,7 +734,7 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
             if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
             if (e != hipSuccess) {
                 // the step kernel is what empties the dyn queue counter: do not leave it set for the next call
-                if (dyn) (void)hipMemsetAsync(h->dev.dyn_count, 0, sizeof(unsigned), static_cast<hipStream_t>(stream));
+                if (dyn) (void)hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
                 return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
             }
         }

@@ -588,6 +588,7 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
     __syncthreads();
     const bool valid = e < c.n_envs;
     bool need_full = false;
+    unsigned bucket = 0;
     if (valid) {
         DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
         const size_t np = col.np;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         // Everything this pass can need is requested at once (one memory round trip instead of five dependent ones:
         // flag -> masks -> hash -> positions -> angles; the pass was latency-bound at 12.8 us for 65 536 envs).
         int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
+        const int age = c.i32cols[(size_t)ICOL_STEP * np + e]; // steps since the reset: where the env is in its post-reset transient
         unsigned flag = col.flag[e];
         unsigned gm_raw = c.mask[e];
         unsigned long long live0 = col.live[e];
@@ -663,6 +665,13 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         }
         if (rest) col.flag[e] = (uint8_t)(4u | (hit ? 1u : 0u));
         need_full = !rest;
+#ifndef SSG_DYN_KEY
+#define SSG_DYN_KEY 0
+#endif
+        const unsigned agek = (unsigned)(age < kDynAgeBuckets - 1 ? (age < 0 ? 0 : age) : kDynAgeBuckets - 1);
+        const unsigned mapk = (unsigned)map_id & (unsigned)(kDynMapBuckets - 1);
+        bucket = SSG_DYN_KEY == 0 ? agek * (unsigned)kDynMapBuckets + mapk   // (development knob: 1 = by map, 2 = by age, 3 = map-major)
+               : SSG_DYN_KEY == 1 ? mapk : SSG_DYN_KEY == 2 ? agek : mapk * (unsigned)kDynAgeBuckets + agek;
     }
     // Compact the envs that need the full step.  One global atomic per WORKGROUP: with one per wave, the 1024
     // same-address atomics of a step were serialised in the L2 and cost the kernel ~15 of its 20 us.
@@ -676,7 +685,47 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
     __syncthreads();
     if (need_full) {
         const unsigned slot = wg_base + wave_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        if (slot < (unsigned)c.n_pad) c.dyn_queue[slot] = e; // (only an uninitialised counter could point past the queue)
+        // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
+        const unsigned pos = atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+        if (slot < (unsigned)c.n_pad) { // (only an uninitialised counter could point past the queue)
+            c.dyn_queue[slot] = e;
+            c.dyn_qkey[slot] = ((unsigned long long)bucket << 32) | (unsigned long long)pos;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pass 1b: counting sort of the queue by bucket.  Every workgroup scans the 512 bucket counters itself (2 KB from L2) and
+// scatters its 256 queue entries to base[bucket] + arrival number.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c)
+{
+    __shared__ unsigned base[kDynBuckets];
+    __shared__ unsigned wave_tot[4];
+    static_assert(kDynBuckets == 512, "two buckets per thread of a 256-thread workgroup");
+    const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_envs);
+    if ((unsigned)blockIdx.x * 256u >= n_queued) return; // workgroup-uniform
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
+    unsigned incl = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        incl += (lane >= o) ? v : 0u;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned off = 0;
+    for (int w = 0; w < wv; ++w) off += wave_tot[w];
+    const unsigned excl = off + incl - (c0 + c1);
+    base[2 * t] = excl;
+    base[2 * t + 1] = excl + c0;
+    __syncthreads();
+    const unsigned i = blockIdx.x * 256u + (unsigned)t;
+    if (i < n_queued) {
+        const unsigned long long k = c.dyn_qkey[i];
+        const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
+        if (dst < (unsigned)c.n_pad) c.dyn_sorted[dst] = c.dyn_queue[i];
     }
 }
 
@@ -690,7 +739,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_envs);
     if ((unsigned)blockIdx.x * (unsigned)kGrp >= n_queued) return; // wave-uniform: nothing queued for this workgroup
     const bool queued = (lane < kGrp) & ((unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane < n_queued);
-    const int e = queued ? c.dyn_queue[blockIdx.x * kGrp + lane] : 0;
+    const int e = queued ? c.dyn_sorted[blockIdx.x * kGrp + lane] : 0;
+    if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
+        for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
     const int lane_doubles = B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
                              kBankDoubles + kEpaDoubles;
     const int cbase = kGrp * lane_doubles;
@@ -1238,6 +1289,7 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
     dd.stop_after = stop_after;
     hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + kClassifyThreads - 1) / kClassifyThreads)),
                        dim3(kClassifyThreads), (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, dd);
+    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256), 0, stream, c);
     hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + kGrp - 1) / kGrp)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
     return hipGetLastError();
 }

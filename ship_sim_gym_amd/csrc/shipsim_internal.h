@@ -32,6 +32,13 @@ enum {
 enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* contact hashes, polygon pairs */,
        DU_COUNT = kDynPairs + kPolyPairs };
 
+// The queue of the full dyn step is sorted by (steps since the reset, bank record): after a reset the traffic ships and goal
+// bodies of an env replay a transient that depends on its world and age only (the player pushes nothing), so envs of one
+// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.
+constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuckets * kDynMapBuckets;
+constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
+constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
+constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
 constexpr int kStatsDoubles = 4 * kStatsSlots;
@@ -68,7 +75,9 @@ struct DevCfg {
                                   // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
     unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
     int32_t *dyn_queue;           // envs that need the full dyn step this step (compacted by dyn_classify_kernel)
-    unsigned *dyn_count;          // length of dyn_queue; zeroed by the step kernel
+    unsigned *dyn_count;          // [0] length of dyn_queue (zeroed by the step kernel); [kDynBucket0 ..) bucket counts of the sort
+    unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
+    int32_t *dyn_sorted;          // the queue ordered by bucket (dyn_sort_kernel): what the full dyn step walks
 };
 
 // Constants of the traffic ships and of Chipmunk's solver, by value to the dyn kernels only.

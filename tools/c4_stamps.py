@@ -50,3 +50,18 @@ for lo, hi in ((0, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 2000)):
             np.percentile(st[8][m], 90), st[8][m].max(), st[9][m].mean()))
 q = fl & 4
 print("resting %.3f of envs; resting by age:" % (q != 0).mean(), [round(float(((q != 0) & (age >= lo) & (age < hi)).sum() / max(1, ((age >= lo) & (age < hi)).sum())), 2) for lo, hi in ((0, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 2000))])
+
+# per wave (envs that share the same final stamp were lanes of one wave): what makes the slow waves slow?
+tot = st[5]
+keys, inv = np.unique(tot[sel], return_inverse=True)
+rows = []
+for w in range(len(keys)):
+    m = inv == w
+    rows.append((keys[w], m.sum(), st[6][sel][m].max(), st[9][sel][m].max(), st[7][sel][m].max(), st[8][sel][m].max(),
+                 len(np.unique(st[7][sel][m] * 100 + st[8][sel][m] * 10 + st[9][sel][m])),
+                 st[0][sel][m][0], (st[2] - st[1])[sel][m][0], (st[4] - st[3])[sel][m][0]))
+rows.sort()
+print("waves: %d; total cycles p10 %.0f median %.0f p90 %.0f max %.0f" % (len(rows), rows[len(rows) // 10][0], rows[len(rows) // 2][0], rows[len(rows) * 9 // 10][0], rows[-1][0]))
+print("slowest / fastest waves: total, lanes, max n_act, max queries, max gjk it, max epa it, distinct (gjk,epa,q) signatures, load, collide, solver")
+for r in rows[-8:] + rows[:4]:
+    print("   ", " ".join("%7.0f" % v for v in r))
