@@ -30,6 +30,12 @@ class Poly(C.Structure):
                 ("bb_l", C.c_double), ("bb_b", C.c_double), ("bb_r", C.c_double), ("bb_t", C.c_double)]
 
 
+class Body(C.Structure):
+    """ora_body: the cpBody fields the path reads"""
+    _fields_ = [("p", V2), ("v", V2), ("f", V2), ("rot", V2), ("a", C.c_double), ("w", C.c_double), ("t", C.c_double),
+                ("m_inv", C.c_double), ("i_inv", C.c_double), ("v_bias", V2), ("w_bias", C.c_double)]
+
+
 class SegInfo(C.Structure):
     _fields_ = [("shape_hit", C.c_int), ("point", V2), ("normal", V2), ("alpha", C.c_double)]
 
@@ -80,6 +86,11 @@ def lib():
         L.ora_poly_point_query.argtypes = [C.POINTER(Poly), V2, C.POINTER(V2)]
         L.ora_poly_segment_query.restype = C.c_int
         L.ora_poly_segment_query.argtypes = [C.POINTER(Poly), V2, V2, C.c_double, C.POINTER(SegInfo)]
+        L.ora_body_update_position.argtypes = [C.POINTER(Body), C.c_double]
+        L.ora_body_update_velocity.argtypes = [C.POINTER(Body), C.c_double, C.c_double]
+        L.ora_body_apply_force_at_local_point.argtypes = [C.POINTER(Body), V2, V2]
+        L.ora_circle_segment_query.restype = C.c_int
+        L.ora_circle_segment_query.argtypes = [V2, C.c_double, V2, V2, C.c_double, C.POINTER(SegInfo)]
         L.ora_polys_collide.restype = C.c_int
         L.ora_polys_collide.argtypes = [C.POINTER(Poly), C.POINTER(Poly)]
         L.ora_circle_poly_collide.restype = C.c_int

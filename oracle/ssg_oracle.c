@@ -462,15 +462,48 @@ static void lidar_query(ora_world *w)
     }
 }
 
+/* ---- cpBody primitives, exported so that tests/golden/shims/pymunk (the stand-in the reference's own Python is executed
+ * against when the control-flow goldens are made) runs on exactly the arithmetic the oracle world runs on ---- */
+/* cpBodyUpdatePosition (v_bias / w_bias are zero for the player: no solver) */
+void ora_body_update_position(ora_body *b, double dt)
+{
+    b->p = vadd(b->p, vmult(vadd(b->v, V(0, 0)), dt));
+    b->a = b->a + (b->w + 0.0) * dt;
+    b->rot = V(cos(b->a), sin(b->a));
+}
+/* cpBodyUpdateVelocity with gravity 0; `damping` = pow(space.damping, dt); forces are cleared afterwards (cpSpaceStep) */
+void ora_body_update_velocity(ora_body *b, double damping, double dt)
+{
+    b->v = vadd(vmult(b->v, damping), vmult(vadd(V(0, 0), vmult(b->f, b->m_inv)), dt));
+    b->w = b->w * damping + b->t * b->i_inv * dt;
+    b->f = V(0, 0);
+    b->t = 0.0;
+}
+/* cpBodyApplyForceAtLocalPoint: force and point in body coordinates, centre of gravity (0,0) */
+void ora_body_apply_force_at_local_point(ora_body *b, ora_v2 force, ora_v2 point)
+{
+    ora_v2 fw = xf_vect(b->rot, force);
+    ora_v2 pw = xf_point(b->p, b->rot, point);
+    b->f = vadd(b->f, fw);
+    ora_v2 r = vsub(pw, xf_point(b->p, b->rot, V(0, 0)));
+    b->t += vcross(r, fw);
+}
+/* cpCircleShapeSegmentQuery (Space.segment_query also visits the goal circles already in the space) */
+int ora_circle_segment_query(ora_v2 center, double r1, ora_v2 a, ora_v2 b, double r2, ora_seg_info *info)
+{
+    ora_seg_info blank = {0, b, {0, 0}, 1.0};
+    *info = blank;
+    circle_segment_query(center, r1, a, b, r2, info);
+    return info->shape_hit;
+}
+
 static void space_step(ora_world *w)
 {
     const ora_config *c = &w->cfg;
     double dt = c->dt;
     ora_body *b = &w->ship;
     /* (1) cpBodyUpdatePosition for every dynamic body.  Goal bodies have v = w = 0 and never move. */
-    b->p = vadd(b->p, vmult(vadd(b->v, V(0, 0)), dt));
-    b->a = b->a + (b->w + 0.0) * dt;
-    b->rot = V(cos(b->a), sin(b->a));
+    ora_body_update_position(b, dt);
     const int dyn = c->n_traffic > 0;
     int reached_mask = 0;
     if (dyn) ora_dyn_integrate(w); /* config 4: traffic + goal bodies move in the same pass (ssg_dynamics.c) */
@@ -493,10 +526,7 @@ static void space_step(ora_world *w)
     }
     /* (3) cpBodyUpdateVelocity, damping = pow(space.damping, dt), gravity = 0 */
     double damping = pow(c->space_damping, dt);
-    b->v = vadd(vmult(b->v, damping), vmult(vadd(V(0, 0), vmult(b->f, b->m_inv)), dt));
-    b->w = b->w * damping + b->t * b->i_inv * dt;
-    b->f = V(0, 0);
-    b->t = 0.0;
+    ora_body_update_velocity(b, damping, dt);
     /* (4) impulse solver: not restated for the player (see file header); config 4 solves the other bodies */
     if (dyn) ora_dyn_collide_solve(w, reached_mask);
 }
@@ -509,11 +539,7 @@ static void apply_action(ora_world *w, int action)
     if (action == 0) {
         /* Ship.move_forward -> cpBodyApplyForceAtLocalPoint(force_vector*1, point_of_thrust) */
         ora_v2 force = V(0.0 * 1, c->force_y * 1);
-        ora_v2 fw = xf_vect(b->rot, force);
-        ora_v2 pw = xf_point(b->p, b->rot, w->thrust_pt);
-        b->f = vadd(b->f, fw);
-        ora_v2 r = vsub(pw, xf_point(b->p, b->rot, V(0, 0)));
-        b->t += vcross(r, fw);
+        ora_body_apply_force_at_local_point(b, force, w->thrust_pt);
     } else if (action == 1 || action == 2) {
         /* Ship.rotate models.py:142-146 */
         w->rudder += (action == 1) ? -c->rudder_step : c->rudder_step;

@@ -160,6 +160,12 @@ int ora_polys_collide_v(const ora_poly *a, const ora_poly *b, int strict);      
 int ora_circle_poly_collide_v(ora_v2 c, double r, const ora_poly *poly, int strict);
 void ora_batch_counters(const ora_world *ws, int n, int64_t *out4); /* sums of the four sat_* counters */
 
+/* cpBody primitives (the same functions the oracle world steps with; also what tests/golden/shims/pymunk calls) */
+void ora_body_update_position(ora_body *b, double dt);
+void ora_body_update_velocity(ora_body *b, double damping, double dt);
+void ora_body_apply_force_at_local_point(ora_body *b, ora_v2 force, ora_v2 point);
+int ora_circle_segment_query(ora_v2 center, double r1, ora_v2 a, ora_v2 b, double r2, ora_seg_info *info);
+
 /* ---- world ---- */
 void ora_default_config(ora_config *cfg);
 void ora_world_init(ora_world *w, const ora_config *cfg);
