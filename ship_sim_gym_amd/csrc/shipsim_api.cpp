@@ -19,7 +19,7 @@ struct ssg_handle {
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
-    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0;
+    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0, off_dyn_row = 0;
     ssg::DynCfg dyn{};
     void *state = nullptr;
     const double *bank = nullptr;
@@ -349,6 +349,7 @@ void refresh_dev(ssg_handle *h)
     d.dyn_count = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_count) : nullptr;
     d.dyn_qkey = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_qkey) : nullptr;
     d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
+    d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
 }
 
 
@@ -494,7 +495,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_count = h->off_dyn_queue + np * sizeof(int32_t);
         h->off_dyn_qkey = h->off_dyn_count + (((size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
         h->off_dyn_sorted = h->off_dyn_qkey + np * sizeof(unsigned long long);
-        h->nbytes = h->off_dyn_sorted + np * sizeof(int32_t);
+        h->off_dyn_row = (h->off_dyn_sorted + np * sizeof(int32_t) + 255) & ~(size_t)255;
+        h->nbytes = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }

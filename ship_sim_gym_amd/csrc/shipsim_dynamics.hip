@@ -481,10 +481,13 @@ struct DynCols {
 // (re)create the non-player bodies of one env: a fresh pm.Space() after ShipGame.reset + add_default_traffic
 __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, int e, const double *rec)
 {
+    double *row = c.dyn_row + (size_t)e * kDynRow; // the row-major shadow the full step loads from
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * col.np + e;
         t[0 * col.np] = d.tx[k]; t[1 * col.np] = d.ty[k];
         for (int f = 2; f < 9; ++f) t[(size_t)f * col.np] = 0.0;
+        row[kDynRowTraffic + 9 * k] = d.tx[k]; row[kDynRowTraffic + 9 * k + 1] = d.ty[k];
+        for (int f = 2; f < 9; ++f) row[kDynRowTraffic + 9 * k + f] = 0.0;
     }
     // all goal centres first, then the stores: a load issued after a store it might alias waits for nothing, but the
     // compiler keeps program order, and one L2 round trip per goal coordinate made this the slowest part of pass 1
@@ -498,6 +501,8 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
         q[0 * col.np] = gxy[2 * g];
         q[1 * col.np] = gxy[2 * g + 1];
         for (int f = 2; f < DC_GOAL_COLS; ++f) q[(size_t)f * col.np] = 0.0;
+        row[DC_GOAL_COLS * g] = gxy[2 * g]; row[DC_GOAL_COLS * g + 1] = gxy[2 * g + 1];
+        for (int f = 2; f < DC_GOAL_COLS; ++f) row[DC_GOAL_COLS * g + f] = 0.0;
     }
     col.live[e] = 0ull;
 }
@@ -790,17 +795,22 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
     // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
     double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
+    {
+        // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
+        // gathers over 75 x 64 lines per wave (the sorted queue scatters a wave's envs over the whole batch)
+        static_assert(DC_GOAL_COLS * SSG_MAX_GOALS == kDynRowTraffic && kDynRowTraffic + 9 * SSG_N_TRAFFIC <= kDynRow && kDynRow % 2 == 0, "row layout");
+        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)e * kDynRow);
+        double rw[kDynRow];
 #pragma unroll
-    for (int g = 0; g < SSG_MAX_GOALS; ++g) {
-        const double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * (g < ng ? g : 0)) * np + e; // (a goal past n_goals: goal 0 again, unused)
+        for (int i = 0; i < kDynRow / 2; ++i) { const double2 v = row2[i]; rw[2 * i] = v.x; rw[2 * i + 1] = v.y; }
 #pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS; ++f) gin[g][f] = q[(size_t)f * np];
-    }
+        for (int g = 0; g < SSG_MAX_GOALS; ++g)
 #pragma unroll
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+            for (int f = 0; f < DC_GOAL_COLS; ++f) gin[g][f] = rw[DC_GOAL_COLS * g + f];
 #pragma unroll
-        for (int f = 0; f < 9; ++f) tin[k][f] = t[(size_t)f * np];
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k)
+#pragma unroll
+            for (int f = 0; f < 9; ++f) tin[k][f] = rw[kDynRowTraffic + 9 * k + f];
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -1242,6 +1252,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                              BF(s, B_VBX), BF(s, B_VBY), BF(s, B_WB)};
 #pragma unroll
         for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; changed |= differs(v[f], tin[k][f]); }
+        double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) row[f] = v[f];
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -1251,6 +1264,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                                         BF(g, B_W), BF(g, B_WB)};
 #pragma unroll
         for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; changed |= differs(v[f], gin[g][f]); }
+        double2 *row2 = reinterpret_cast<double2 *>(c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g);
+#pragma unroll
+        for (int f = 0; f < DC_GOAL_COLS / 2; ++f) row2[f] = make_double2(v[2 * f], v[2 * f + 1]);
     }
     changed |= (live != live0) | (ain != aout);
     stamp(5);
@@ -1299,6 +1315,11 @@ __global__ void dyn_invalidate_kernel(const DevCfg c, const uint8_t *__restrict_
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs || (mask && !mask[e])) return;
     c.dyn_flag[e] &= (uint8_t)~4u;
+    // the caller wrote the body columns: bring the row-major shadow the full step loads from up to date
+    const size_t np = (size_t)c.n_pad;
+    double *row = c.dyn_row + (size_t)e * kDynRow;
+    for (int i = 0; i < DC_GOAL_COLS * SSG_MAX_GOALS; ++i) row[i] = c.dyn_f64[(size_t)(DC_GOALS + i) * np + e];
+    for (int i = 0; i < 9 * SSG_N_TRAFFIC; ++i) row[kDynRowTraffic + i] = c.dyn_f64[(size_t)(DC_TRAFFIC + i) * np + e];
 }
 
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream)

@@ -39,6 +39,12 @@ constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuck
 constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
+// The sorted queue scatters the envs of a wave over the whole batch: gathered from the struct-of-arrays columns, an env's 75
+// body fields cost the wave 75 x 64 cache lines.  The full dyn step therefore keeps a ROW-MAJOR shadow of them, five 128-byte
+// lines per env: [0, 48) goal g field f at 8g + f, [48, 75) traffic ship k field f at 48 + 9k + f.  Written by everything that
+// writes the columns (dyn_init, the full step's write-back, ssg_dyn_invalidate after a caller's own writes); read by the full
+// step only.  The columns stay the interface of everything else (classify pass, step kernel, ssg_state_field).
+constexpr int kDynRow = 80, kDynRowTraffic = 48;
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
 constexpr int kStatsDoubles = 4 * kStatsSlots;
@@ -78,6 +84,7 @@ struct DevCfg {
     unsigned *dyn_count;          // [0] length of dyn_queue (zeroed by the step kernel); [kDynBucket0 ..) bucket counts of the sort
     unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
     int32_t *dyn_sorted;          // the queue ordered by bucket (dyn_sort_kernel): what the full dyn step walks
+    double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
 };
 
 // Constants of the traffic ships and of Chipmunk's solver, by value to the dyn kernels only.
