@@ -19,7 +19,8 @@ struct ssg_handle {
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
-    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0, off_dyn_row = 0;
+    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0, off_dyn_row = 0, off_dyn_segcnt = 0;
+    bool dyn_queue_valid = false; // the step kernel's last launch left the next step's dyn queue (nothing host-side touched the envs since)
     ssg::DynCfg dyn{};
     void *state = nullptr;
     const double *bank = nullptr;
@@ -350,6 +351,9 @@ void refresh_dev(ssg_handle *h)
     d.dyn_qkey = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_qkey) : nullptr;
     d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
+    d.dyn_segcnt = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_segcnt) : nullptr;
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) d.dyn_reach2[k] = h->dyn.reach2[k];
+    h->dyn_queue_valid = false; // (anything that refreshes the kernel arguments may have changed what the queue was built from)
 }
 
 
@@ -496,7 +500,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_qkey = h->off_dyn_count + (((size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
         h->off_dyn_sorted = h->off_dyn_qkey + np * sizeof(unsigned long long);
         h->off_dyn_row = (h->off_dyn_sorted + np * sizeof(int32_t) + 255) & ~(size_t)255;
-        h->nbytes = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
+        h->off_dyn_segcnt = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
+        h->nbytes = h->off_dyn_segcnt + ((np / 64 * sizeof(unsigned) + 255) & ~(size_t)255);
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -577,6 +582,7 @@ int ssg_init_state(ssg_handle *h, void *stream)
     hipError_t e = hipMemsetAsync(h->state, 0, h->nbytes, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_init_state: ") + hipGetErrorString(e));
     h->zeroed = true;
+    h->dyn_queue_valid = false;
     // map_ring mode: the episode counters and the rings' "worlds drawn" counters were just zeroed together, so the rings
     // must hold episodes 0 .. R-1 again: redraw them (the bookkeeping and the bank never disagree)
     if (h->cfg.map_ring > 0 && h->ring_ready) return ring_refill(h, nullptr, stream);
@@ -621,6 +627,7 @@ static int ring_refill(ssg_handle *h, double *dev_raw, void *stream)
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ring refill launch: ") + hipGetErrorString(e));
     h->ring_credit = h->cfg.map_ring - 1;
     h->dyn.bank_epoch++;
+    h->dyn_queue_valid = false;
     return SSG_OK;
 }
 
@@ -651,6 +658,7 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
         }
         h->ring_credit -= 1;
     }
+    h->dyn_queue_valid = false;
     hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
     if (e == hipSuccess && h->cfg.n_ships > 1) // add_default_traffic + fresh goal bodies for the reset envs
         e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, static_cast<hipStream_t>(stream));
@@ -727,7 +735,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 h->ring_credit -= 1;
             }
             if (dyn) {
-                hipError_t e = ssg::launch_dyn_step(h->dev, h->dyn, static_cast<hipStream_t>(stream));
+                hipError_t e = hipSuccess;
+                if (!h->dyn_queue_valid) // the classify pass rebuilds the queue: its bucket counters and length start from zero
+                    e = hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
+                if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
                 if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
             }
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
@@ -735,10 +746,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                                             static_cast<hipStream_t>(stream));
             if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
             if (e != hipSuccess) {
-                // the step kernel is what empties the dyn queue counter: do not leave it set for the next call
-                if (dyn) (void)hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
+                h->dyn_queue_valid = false; // (the next call rebuilds the dyn queue from the flags, counters zeroed)
                 return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
             }
+            if (dyn) h->dyn_queue_valid = true; // the step kernel's body role has queued the envs whose bodies must be stepped next
         }
         return SSG_OK;
     }
@@ -797,7 +808,7 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
     hipError_t e = ssg::launch_generate_bank(seed, n_maps, h->cfg.n_goals, h->cfg.width, h->cfg.height, width_frac,
                                              h->cfg.spawn_x, h->cfg.spawn_y, dev_bank, dev_raw, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("generate_bank launch: ") + hipGetErrorString(e));
-    if (dev_bank == h->bank) h->dyn.bank_epoch++; // regenerated in place
+    if (dev_bank == h->bank) { h->dyn.bank_epoch++; h->dyn_queue_valid = false; } // regenerated in place
     return SSG_OK;
 }
 
@@ -824,6 +835,7 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream)
     int rc = check_ready(h, false);
     if (rc != SSG_OK) return rc;
     if (h->cfg.n_ships <= 1) return SSG_OK; // nothing to wake
+    h->dyn_queue_valid = false;
     hipError_t e = ssg::launch_dyn_invalidate(h->dev, dev_mask, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn_invalidate launch: ") + hipGetErrorString(e));
     return SSG_OK;

@@ -49,7 +49,7 @@ constexpr int kGrp = SSG_DYN_GRP;
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
 constexpr int kMaxGjk = 30, kMaxEpa = 30;
-constexpr int kLdsArb = 5;         // arbiter records per env held in LDS; further ones (rare) go to scratch
+constexpr int kLdsArb = 3;         // arbiter records per env held in LDS; further ones (rare: 98.8 % of the queued envs have <= 2) go to scratch
 constexpr int kMaxActive = 8;      // arbiters on one env's solver list
 enum { ST_NONE = 0, ST_FIRST = 1, ST_NORMAL = 2, ST_IGNORE = 3, ST_CACHED = 4 };
 
@@ -584,15 +584,52 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kClassifyThreads = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
+
+// collide_ship for a RESTING env: the player after its own cpBodyUpdatePosition against the three parked traffic ships
+// (hull constants at lds[0 ..]; same expressions as player_shape() / the full step).
+__device__ __forceinline__ bool resting_player_hit(const DevCfg &c, int e)
+{
+    const size_t np = (size_t)c.n_pad;
+    double tp[SSG_N_TRAFFIC][3];
+#pragma unroll
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        const double *t = c.dyn_f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+        tp[k][0] = t[0]; tp[k][1] = t[np]; tp[k][2] = t[2 * np];
+    }
+    const ShipShape pl = player_shape(c, e, 0);
+    bool hit = false;
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        ShipShape sk;
+        sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
+        sk.p = mk(tp[k][0], tp[k][1]);
+        sincos_body(tp[k][2], &sk.sa, &sk.ca);
+        sk.cache();
+        hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
+    }
+    return hit;
+}
+
+// Which goals' cached arbiters leave with the goals the player has reached (deferred space.remove, game.py:252).
+__device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigned long long live, unsigned gmask, int ng)
+{
+    for (int g = 0; g < ng; ++g) {
+        if ((gmask >> g) & 1u) continue;
+        for (int s = 0; s < 2; ++s) live &= ~(1ull << pid_gb(g, s));
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) live &= ~(1ull << pid_gt(g, k));
+        for (int h = 0; h < ng; ++h)
+            if (h != g) live &= ~(1ull << (h < g ? pid_gg(h, g) : pid_gg(g, h)));
+    }
+    return live;
+}
+
+// In steady state the step kernel's body role classifies every env for the NEXT step at the end of each step (it holds the
+// player's state in registers: shipsim_kernels.hip, role 3) and this kernel does not run.  It runs when the host touched the
+// envs in between — ssg_reset, a new bank, ssg_dyn_invalidate, a fresh handle — and rebuilds the queue from the per-env flags.
 __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const DevCfg c, const DynCfg d)
 {
-    __shared__ unsigned wg_cnt, wg_base;
     const int e = blockIdx.x * kClassifyThreads + threadIdx.x;
-    stage_hulls(c, d, 0, threadIdx.x);
-    if (threadIdx.x == 0) wg_cnt = 0u;
-    __syncthreads();
     const bool valid = e < c.n_envs;
-    bool need_full = false;
+    bool need_full = false, sat_only = false;
     unsigned bucket = 0;
     if (valid) {
         DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
@@ -619,29 +656,15 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         asm volatile("" : "+v"(px), "+v"(py), "+v"(pvx), "+v"(pvy), "+v"(pang), "+v"(pw));
 #pragma unroll
         for (int k = 0; k < SSG_N_TRAFFIC; ++k) asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]));
-        const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
-        if (flag & 2u) { // the step kernel auto-reset this env at the end of the last step
-            dyn_init(c, d, col, e, rec);
-            live0 = 0ull; // (what dyn_init has just written)
-        }
         const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
-        // deferred space.remove of goals the player reached last step (game.py:252): their cached arbiters go too
-        unsigned long long live = live0;
-        for (int g = 0; g < ng; ++g) {
-            if ((gmask >> g) & 1u) continue;
-            for (int s = 0; s < 2; ++s) live &= ~(1ull << pid_gb(g, s));
-            for (int k = 0; k < SSG_N_TRAFFIC; ++k) live &= ~(1ull << pid_gt(g, k));
-            for (int h = 0; h < ng; ++h)
-                if (h != g) live &= ~(1ull << (h < g ? pid_gg(h, g) : pid_gg(g, h)));
-        }
-        if (live != live0) col.live[e] = live;
         // rest bit still valid?  It was established for this bank generation; callers that write the body columns
         // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).  A cached arbiter that left with its goal
-        // was part of the fixed point: the bodies it touched are stepped again.
-        bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) && (live == live0);
-        bool hit = false;
+        // was part of the fixed point: the bodies it touched are stepped again.  (An env the step kernel auto-reset — bit 1 —
+        // gets its bodies rebuilt by the full step.)
+        bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) &&
+                    (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
         if (rest) {
-            // the player's position after its own cpBodyUpdatePosition; its rotation only if some ship is in reach
+            // the player's position after its own cpBodyUpdatePosition; the exact test only if some ship is in reach
             const double ppx = px + pvx * c.dt;
             const double ppy = py + pvy * c.dt;
             bool reach = false;
@@ -652,50 +675,25 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
                 const double dx = tp[k][0] - ppx, dy = tp[k][1] - ppy;
                 reach |= (dx * dx + dy * dy) <= d.reach2[k];
             }
-            if (reach) {
-                ShipShape pl; // (same expressions as player_shape())
-                pl.hoff = 0; pl.hashid = 0;
-                pl.p = mk(ppx, ppy);
-                sincos_body(pang + pw * c.dt, &pl.sa, &pl.ca);
-                pl.cache();
-                for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-                    ShipShape sk;
-                    sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
-                    sk.p = mk(tp[k][0], tp[k][1]);
-                    sincos_body(tp[k][2], &sk.sa, &sk.ca);
-                    sk.cache();
-                    hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
-                }
-            }
+            col.flag[e] = 4u;     // at rest, traffic bit clear; dyn_sort_kernel sets it for the envs in reach that do touch
+            sat_only = reach;
         }
-        if (rest) col.flag[e] = (uint8_t)(4u | (hit ? 1u : 0u));
         need_full = !rest;
-#ifndef SSG_DYN_KEY
-#define SSG_DYN_KEY 0
-#endif
-        const unsigned agek = (unsigned)(age < kDynAgeBuckets - 1 ? (age < 0 ? 0 : age) : kDynAgeBuckets - 1);
-        const unsigned mapk = (unsigned)map_id & (unsigned)(kDynMapBuckets - 1);
-        bucket = SSG_DYN_KEY == 0 ? agek * (unsigned)kDynMapBuckets + mapk   // (development knob: 1 = by map, 2 = by age, 3 = map-major)
-               : SSG_DYN_KEY == 1 ? mapk : SSG_DYN_KEY == 2 ? agek : mapk * (unsigned)kDynAgeBuckets + agek;
+        bucket = dyn_bucket_of(age, map_id);
+        (void)pang; (void)pw;
     }
-    // Compact the envs that need the full step.  One global atomic per WORKGROUP: with one per wave, the 1024
-    // same-address atomics of a step were serialised in the L2 and cost the kernel ~15 of its 20 us.
-    const unsigned long long m = __ballot(need_full);
+    // The queue is segmented by tiles of 64 envs (a wave of this kernel = one tile): no atomics to append.
+    const unsigned long long m = __ballot(need_full | sat_only);
     const int lane = threadIdx.x & 63;
-    unsigned wave_base = 0;
-    if (m && lane == 0) wave_base = atomicAdd(&wg_cnt, (unsigned)__popcll(m)); // LDS
-    wave_base = __shfl(wave_base, 0);
-    __syncthreads();
-    if (threadIdx.x == 0) wg_base = wg_cnt ? atomicAdd(c.dyn_count, wg_cnt) : 0u;
-    __syncthreads();
-    if (need_full) {
-        const unsigned slot = wg_base + wave_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
-        const unsigned pos = atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
-        if (slot < (unsigned)c.n_pad) { // (only an uninitialised counter could point past the queue)
-            c.dyn_queue[slot] = e;
-            c.dyn_qkey[slot] = ((unsigned long long)bucket << 32) | (unsigned long long)pos;
-        }
+    const int seg = e >> 6; // (n_pad is a multiple of 256: every wave of the grid owns a whole segment)
+    if (lane == 0 && (size_t)seg < (size_t)c.n_pad / 64) c.dyn_segcnt[seg] = (unsigned)__popcll(m);
+    if (need_full | sat_only) {
+        const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        unsigned long long key = kDynSatOnly;
+        if (need_full) // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
+            key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+        c.dyn_queue[slot] = e;
+        c.dyn_qkey[slot] = key;
     }
 }
 
@@ -703,14 +701,31 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
 // Pass 1b: counting sort of the queue by bucket.  Every workgroup scans the 512 bucket counters itself (2 KB from L2) and
 // scatters its 256 queue entries to base[bucket] + arrival number.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c)
+__global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const DynCfg d)
 {
     __shared__ unsigned base[kDynBuckets];
     __shared__ unsigned wave_tot[4];
     static_assert(kDynBuckets == 512, "two buckets per thread of a 256-thread workgroup");
-    const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_envs);
-    if ((unsigned)blockIdx.x * 256u >= n_queued) return; // workgroup-uniform
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // this workgroup's four segments of the queue (segment = tile of 64 envs, entries [64*seg, 64*seg + count))
+    const unsigned i = blockIdx.x * 256u + (unsigned)t;
+    const unsigned seg = i >> 6;
+    const unsigned cnt = ((size_t)seg < (size_t)c.n_pad / 64) ? min(c.dyn_segcnt[seg], 64u) : 0u; // (clamped: garbage counters must not index past a segment)
+    const bool valid = (unsigned)lane < cnt;
+    const unsigned long long k = valid ? c.dyn_qkey[i] : 0ull;
+    const bool sat_only = valid & (k == kDynSatOnly);
+    const unsigned n_full = (unsigned)__popcll(__ballot(valid & !sat_only));
+    stage_hulls(c, d, 0, t);
+    if (lane == 0) wave_tot[wv] = (cnt ? 0x10000u : 0u) | n_full;
+    __syncthreads();
+    const unsigned wsum = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (wsum == 0u) return; // nothing queued among this workgroup's 256 envs (workgroup-uniform)
+    const unsigned wg_total = wsum & 0xFFFFu;
+    __syncthreads();
+    if (sat_only) { // a resting env whose player comes within reach of a parked ship: collide_ship's exact test, traffic bit of the flag
+        const int e = c.dyn_queue[i];
+        if (resting_player_hit(c, e)) c.dyn_flag[e] = (uint8_t)(4u | 1u);
+    }
     const unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
     unsigned incl = c0 + c1;
 #pragma unroll
@@ -726,9 +741,8 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c)
     base[2 * t] = excl;
     base[2 * t + 1] = excl + c0;
     __syncthreads();
-    const unsigned i = blockIdx.x * 256u + (unsigned)t;
-    if (i < n_queued) {
-        const unsigned long long k = c.dyn_qkey[i];
+    if (t == 0 && wg_total) atomicAdd(c.dyn_count, wg_total); // the queue's length (zeroed by the step kernel)
+    if (valid & !sat_only) {
         const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
         if (dst < (unsigned)c.n_pad) c.dyn_sorted[dst] = c.dyn_queue[i];
     }
@@ -748,7 +762,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
         for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
     const int lane_doubles = B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
-                             kBankDoubles + kEpaDoubles;
+                             2 * kBankDoubles + kEpaDoubles;
     const int cbase = kGrp * lane_doubles;
     stage_hulls(c, d, cbase, lane);
     __builtin_amdgcn_s_waitcnt(0xC07F); // one wave per workgroup: the LDS writes above are visible to its lanes
@@ -767,7 +781,11 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             col.f64[(size_t)(DC_ARB + 4 * 50 + i) * np + e] = (double)(__builtin_amdgcn_s_memtime() - t_start);
     };
     const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
-    unsigned long long live = col.live[e]; // (pass 1 rebuilt the bodies after a reset and dropped removed goals' arbiters)
+    // bit 1 of the flag: the step kernel auto-reset this env at the end of the last step — a fresh pm.Space(): its bodies are
+    // rebuilt here (ShipGame.reset + add_default_traffic), nothing of the old episode is read
+    const bool fresh = (col.flag[e] & 2u) != 0u;
+    // deferred space.remove of the goals the player reached last step (game.py:252): their cached arbiters go with them
+    unsigned long long live = fresh ? 0ull : drop_removed_goal_arbiters(col.live[e], gmask, ng);
     const unsigned long long live0 = live;
     // Did this step write back anything but the bits it read?  The body columns are compared directly: what was read stays
     // in registers until the write-back (this kernel runs one wave per SIMD, 512 VGPRs to spare; hashing both sides cost
@@ -794,6 +812,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
     // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
+    // (the player's six columns are requested with everything else: its pose after its own cpBodyUpdatePosition)
+    const ShipShape pl = player_shape(c, e, cbase);
     double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
     {
         // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
@@ -811,6 +831,23 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         for (int k = 0; k < SSG_N_TRAFFIC; ++k)
 #pragma unroll
             for (int f = 0; f < 9; ++f) tin[k][f] = rw[kDynRowTraffic + 9 * k + f];
+        if (fresh) { // dyn_init's values, in registers; the write-back below stores every field of such an env
+            double gxy[2 * SSG_MAX_GOALS];
+#pragma unroll
+            for (int i = 0; i < 2 * SSG_MAX_GOALS; ++i) gxy[i] = rec[SSG_MAP_OFF_GOALS + i];
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+                gin[g][0] = gxy[2 * g]; gin[g][1] = gxy[2 * g + 1];
+#pragma unroll
+                for (int f = 2; f < DC_GOAL_COLS; ++f) gin[g][f] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                tin[k][0] = d.tx[k]; tin[k][1] = d.ty[k];
+#pragma unroll
+                for (int f = 2; f < 9; ++f) tin[k][f] = 0.0;
+            }
+        }
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -857,28 +894,30 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     EpaMem emem;
     int dbg_cnt[3] = {0, 0, 0};
     unsigned long long prof_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, prof_last = 0ull;
-    emem.base = (abase + A_STRIDE * kLdsArb) * kGrp + lane + kBankDoubles * kGrp; emem.ov = epa_ov; emem.cnt = dbg_cnt; emem.prof = prof_acc; emem.last = &prof_last;
-    int staged = -1;
+    emem.base = (abase + A_STRIDE * kLdsArb) * kGrp + lane + 2 * kBankDoubles * kGrp; emem.ov = epa_ov; emem.cnt = dbg_cnt; emem.prof = prof_acc; emem.last = &prof_last;
     auto bank_box = [&](int s) -> BB {
         BB o;
         o.l = s ? bk[1][1] : bk[0][1]; o.b = s ? bk[1][2] : bk[0][2]; o.r = s ? bk[1][3] : bk[0][3]; o.t = s ? bk[1][4] : bk[0][4];
         return o;
     };
-    auto bank_shape = [&](int s) -> BankShape { // stages bank s's planes if they are not the ones in LDS
-        if (staged != s) {
-            const double *pl = rec + SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES;
-            double tmp[kBankDoubles];
+    {
+        // Both banks' planes go to this lane's LDS columns up front, requested together with the body row: staged on demand
+        // (one bank at a time, again whenever the pair loops switched side) the 48 gathers from the map record were an exposed
+        // L2 round trip in front of every narrowphase query.
+        double tmp[2 * kBankDoubles];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < SSG_MAX_HULL; ++j)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) tmp[4 * j + f] = pl[SSG_PLANE_DOUBLES * j + f]; // all 12 slots exist in the record
+                for (int f = 0; f < 4; ++f) // all 12 slots exist in the record
+                    tmp[s * kBankDoubles + 4 * j + f] = rec[SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
 #pragma unroll
-            for (int q = 0; q < kBankDoubles; ++q) lds[bbase + q * kGrp] = tmp[q];
-            staged = s;
-            SSG_TICK(emem, 5);
-        }
+        for (int q = 0; q < 2 * kBankDoubles; ++q) lds[bbase + q * kGrp] = tmp[q];
+    }
+    auto bank_shape = [&](int s) -> BankShape {
         BankShape b;
-        b.base = bbase;
+        b.base = bbase + s * kBankDoubles * kGrp;
         b.n = (int)(s ? bk[1][0] : bk[0][0]);
         b.box = bank_box(s);
         b.hashid = (unsigned)s;
@@ -890,10 +929,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     if (d.stop_after == 1) return;
     // the player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel) against traffic
     bool hit = false;
-    {
-        const ShipShape pl = player_shape(c, e, cbase);
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) hit |= ships_touch(pl, ship_shape(k)); // collide_ship: type 0 x type 1
-    }
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) hit |= ships_touch(pl, ship_shape(k)); // collide_ship: type 0 x type 1
 
     stamp(1);
     if (d.stop_after == 2) return;
@@ -1250,11 +1286,15 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const int s = slot_ship0 + k;
         const double v[9] = {BF(s, B_PX), BF(s, B_PY), L(xbase + X_STRIDE * k + X_A), BF(s, B_VX), BF(s, B_VY), BF(s, B_W),
                              BF(s, B_VBX), BF(s, B_VBY), BF(s, B_WB)};
-#pragma unroll
-        for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; changed |= differs(v[f], tin[k][f]); }
+        // (columns and row hold what was loaded: only the fields this step changed are stored — in the post-reset transient
+        // that is ship 1 and whatever it shoves, not the 75 fields of the env)
         double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
 #pragma unroll
-        for (int f = 0; f < 9; ++f) row[f] = v[f];
+        for (int f = 0; f < 9; ++f) {
+            const bool df = differs(v[f], tin[k][f]);
+            if (df | fresh) { t[(size_t)f * np] = v[f]; row[f] = v[f]; }
+            changed |= df;
+        }
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -1262,11 +1302,13 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
         const double v[DC_GOAL_COLS] = {BF(g, B_PX), BF(g, B_PY), BF(g, B_VX), BF(g, B_VY), BF(g, B_VBX), BF(g, B_VBY),
                                         BF(g, B_W), BF(g, B_WB)};
+        double *row = c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g;
 #pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; changed |= differs(v[f], gin[g][f]); }
-        double2 *row2 = reinterpret_cast<double2 *>(c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g);
-#pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS / 2; ++f) row2[f] = make_double2(v[2 * f], v[2 * f + 1]);
+        for (int f = 0; f < DC_GOAL_COLS; ++f) {
+            const bool df = differs(v[f], gin[g][f]);
+            if (df | fresh) { q[(size_t)f * np] = v[f]; row[f] = v[f]; }
+            changed |= df;
+        }
     }
     changed |= (live != live0) | (ain != aout);
     stamp(5);
@@ -1284,7 +1326,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 size_t dyn_lds_bytes(int n_goals)
 {
     const int doubles = B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
-                        kBankDoubles + kEpaDoubles;
+                        2 * kBankDoubles + kEpaDoubles;
     return ((size_t)doubles * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
 }
 
@@ -1296,16 +1338,17 @@ hipError_t prepare_dyn(const DevCfg &c)
                                160 * 1024);
 }
 
-hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
+hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream)
 {
     // pass 1 over every env, then pass 2 over the queue it built (grid sized for the worst case; workgroups past the
     // queue's end leave at once).  The step kernel that follows empties the queue counter.
     static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
     dd.stop_after = stop_after;
-    hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + kClassifyThreads - 1) / kClassifyThreads)),
-                       dim3(kClassifyThreads), (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, dd);
-    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256), 0, stream, c);
+    if (classify)
+        hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_pad + kClassifyThreads - 1) / kClassifyThreads)),
+                           dim3(kClassifyThreads), 0, stream, c, dd);
+    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)(c.n_pad / 256)), dim3(256), (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, dd);
     hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + kGrp - 1) / kGrp)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
     return hipGetLastError();
 }

@@ -39,6 +39,13 @@ constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuck
 constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
+constexpr unsigned long long kDynSatOnly = ~0ull; // queue entry key of a resting env that only needs the player x traffic test
+// sort bucket of an env that is `age` steps into its episode on bank record `map_id`
+__host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
+{
+    const unsigned agek = (unsigned)(age < kDynAgeBuckets - 1 ? (age < 0 ? 0 : age) : kDynAgeBuckets - 1);
+    return agek * (unsigned)kDynMapBuckets + ((unsigned)map_id & (unsigned)(kDynMapBuckets - 1));
+}
 // The sorted queue scatters the envs of a wave over the whole batch: gathered from the struct-of-arrays columns, an env's 75
 // body fields cost the wave 75 x 64 cache lines.  The full dyn step therefore keeps a ROW-MAJOR shadow of them, five 128-byte
 // lines per env: [0, 48) goal g field f at 8g + f, [48, 75) traffic ship k field f at 48 + 9k + f.  Written by everything that
@@ -80,9 +87,15 @@ struct DevCfg {
                                   // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
                                   // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
     unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
-    int32_t *dyn_queue;           // envs that need the full dyn step this step (compacted by dyn_classify_kernel)
-    unsigned *dyn_count;          // [0] length of dyn_queue (zeroed by the step kernel); [kDynBucket0 ..) bucket counts of the sort
+    // The queue of the full dyn step.  Produced for step t+1 by the step kernel's body role at the end of step t (or, after a
+    // host-side reset / bank change / ssg_dyn_invalidate, by dyn_classify_kernel): SEGMENTED, one segment of 64 slots per tile
+    // of 64 envs (entries dyn_queue[64*s + i], i < dyn_segcnt[s]: no atomics to append), each entry with its sort bucket and
+    // arrival number; dyn_sort_kernel turns it into dyn_sorted and counts it.
+    int32_t *dyn_queue;
+    unsigned *dyn_segcnt;         // [n_pad / 64] entries per segment; every producer writes every segment's count
+    unsigned *dyn_count;          // [0] length of dyn_sorted (dyn_sort_kernel adds, the step kernel zeroes); [kDynBucket0 ..) bucket counts
     unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
+    double dyn_reach2[SSG_N_TRAFFIC]; // = DynCfg::reach2, for the step kernel's classification of resting envs
     int32_t *dyn_sorted;          // the queue ordered by bucket (dyn_sort_kernel): what the full dyn step walks
     double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
 };
@@ -105,7 +118,9 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
-hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream); // classify + full step of the queue
+// sort + full step of the queue; classify = true: rebuild the queue first from the per-env flags (the step kernel did not
+// produce it: first step after a host-side reset, bank change or ssg_dyn_invalidate)
+hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream);
 hipError_t prepare_dyn(const DevCfg &c);
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);

@@ -1252,6 +1252,56 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
             c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
         }
+        // Which envs need the full cpSpaceStep of their other bodies NEXT step (shipsim_dynamics.hip)?  Everything that decides
+        // it is in this role's registers now: a reset env (fresh bodies), an env whose bodies are not at rest, one that lost a
+        // goal holding a cached arbiter this step.  A resting env whose player will be within reach of a parked
+        // traffic ship after its next cpBodyUpdatePosition is queued for collide_ship's exact test only (dyn_sort_kernel runs it).
+        // The others keep their rest bit, traffic bit clear.  Queue = one segment per tile:
+        // no atomics to append; the entry carries its sort bucket (steps since the reset, bank record).
+        bool need_full = false, sat_only = false;
+        if (live) {
+            bool resting = !do_reset & ((dflag & 4u) != 0u);
+            if (resting & goal_reached) {
+                // the goal(s) reached this step leave the space: the rest state survives unless one of them had a cached arbiter
+                // (pair ids of shipsim_dynamics.hip: goal g x bank s = 9 + 2g + s, goal g x ship k = 21 + 3g + k, goals h < g = 39 + g(g-1)/2 + h)
+                const unsigned long long lv = c.dyn_live[el_];
+                unsigned long long gone = 0ull;
+                const unsigned removed = ~gm & ((1u << c.n_goals) - 1u);
+                for (int g = 0; g < c.n_goals; ++g) {
+                    if (!((removed >> g) & 1u)) continue;
+                    gone |= 3ull << (9 + 2 * g);
+                    gone |= 7ull << (21 + 3 * g);
+                    for (int h = 0; h < c.n_goals; ++h)
+                        if (h != g) gone |= 1ull << (h < g ? 39 + g * (g - 1) / 2 + h : 39 + h * (h - 1) / 2 + g);
+                }
+                resting = (lv & gone) == 0ull;
+            }
+            bool reach = false;
+            if (resting) {
+                const double ppx = x + vx * c.dt, ppy = y + vy * c.dt;
+#pragma unroll
+                for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
+                    const double tx = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk) * np + el_], ty = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk + 1) * np + el_];
+                    const double dx = tx - ppx, dy = ty - ppy;
+                    reach |= (dx * dx + dy * dy) <= c.dyn_reach2[kk];
+                }
+            }
+            need_full = !resting;
+            sat_only = resting & reach;
+        }
+        const unsigned long long qm = __ballot(need_full | sat_only);
+        const int seg = (blockIdx.x * EPW + tl) >> 6; // this tile's segment (wave-uniform)
+        if (lane == 0) c.dyn_segcnt[seg] = (unsigned)__popcll(qm);
+        if (need_full | sat_only) {
+            const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(qm & ((1ull << lane) - 1ull));
+            unsigned long long key = kDynSatOnly; // a resting env within reach of a parked ship: collide_ship's exact test only
+            if (need_full) {
+                const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
+                key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+            }
+            c.dyn_queue[slot] = el_;
+            c.dyn_qkey[slot] = key;
+        }
     }
     if (do_reset) {
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
