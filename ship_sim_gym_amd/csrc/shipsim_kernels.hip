@@ -1,14 +1,19 @@
 // shipsim_kernels.hip — hand-written gfx950 (CDNA4 / MI355X) kernels for the batched ShipEnv hot path.
 //
-// Design (DESIGN.md §4):
+// Design (DESIGN.md §4-5):
 //  * One wavefront lane per env, body state as FP64 struct-of-arrays columns in HBM (coalesced 8-byte accesses).
 //  * The map bank (river-bank hull planes + goal centres) is staged in LDS once per workgroup with LDS-DMA.
-//  * ROLE-SPLIT workgroups: a workgroup of 2*EPW threads serves EPW envs.  Its first EPW/64 waves ("A") do the
-//    pre-step half of ShipEnv.step for those envs (body rotation, thrust/rudder, the whole LiDAR query), its last
-//    EPW/64 waves ("B") the post-step half (integrator, ship transform, narrowphase against banks and goals,
-//    reward/done, observation and state write-back).  A lone wave on a SIMD issues FP64 at half rate, and
-//    65 536 envs are only one wave per SIMD; splitting each env's work over two wave roles puts two waves on every
-//    SIMD and halves each wave's instruction stream.  A hands B five doubles per env + the lidar results via LDS.
+//  * ROLE-SPLIT, PIPELINED workgroups: a workgroup of 4*EPW threads serves EPW envs = EPW/64 tiles of 64 envs, each tile by
+//    four waves with one role each — LIDAR-lo and LIDAR-hi (half the beams of LiDAR.query each, and the bank narrowphase
+//    against one bank hull each), OBSERVER (sticky-lidar merge, nearest goal, reward / done / flags, the observation rows)
+//    and BODY (action, integrator, ship transform, goal narrowphase, statistics, reset; its registers carry the state from
+//    step to step).  A lone wave on a SIMD issues FP64 at a quarter of the pipe's rate and runs latency-bound; four co-resident
+//    roles keep the SIMD's VALU and the CU's LDS pipe busy.  The roles of a tile exchange the pose, the collision bits and the
+//    lidar results through LDS under two per-tile rendezvous words (no workgroup barrier after the one that publishes the
+//    staged bank), and run one step apart: while BODY integrates step k+1, OBSERVER writes step k's rows and the LIDAR
+//    roles query for step k+1 (see the step kernel's header comment for the timeline).
+//  * K steps per launch (ssg_rollout / ssg_rollout_traj): the bank stays in LDS and the state in registers; step k's outputs
+//    go to the same rows every step, or to their own slot of a [K][N] trajectory.
 //  * Divergent work is made dense: the few lanes whose ship is near a bank / goal, and the (beam, hull) pairs
 //    that survive bounding-box culling, are served by whole waves (ballot/readlane broadcast, LDS work queues).
 //  * No dense contraction anywhere, so no MFMA.  Arithmetic that advances or judges the state (integrator, forces,

@@ -97,6 +97,7 @@ __device__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
 struct Hull {
     int n;
     const double *pl; // n planes of SSG_PLANE_DOUBLES doubles inside the record being built
+    double l, b, r, t; // the hull's AABB
 };
 
 __device__ double point_query(const Hull &h, double px, double py)
@@ -125,7 +126,10 @@ __device__ bool segment_query_x(const Hull &h, double ax, double ay, double bx, 
     double alpha = 1.0;
     bool hit = false;
     outx = bx;
-    if (point_query(h, ax, ay) <= r2) return true; // reported point stays the far end
+    // (the start point's distance to the hull is at least its distance to the hull's box: beyond r2 of the box the point
+    // query — a division and a square root per edge — cannot report a hit at alpha 0)
+    const double bx_ = fmax(fmax(h.l - ax, ax - h.r), 0.0), by_ = fmax(fmax(h.b - ay, ay - h.t), 0.0);
+    if (bx_ * bx_ + by_ * by_ <= r2 * r2 * 1.0000001 && point_query(h, ax, ay) <= r2) return true; // reported point stays the far end
     for (int i = 0; i < h.n; ++i) {
         const double *p = h.pl + SSG_PLANE_DOUBLES * i;
         const double nx = p[2], ny = p[3];
@@ -189,13 +193,20 @@ __device__ void generate_world(Rng &rng, int n_goals, double width, double heigh
         const double x_min = s ? width - bank_width : 0.0, x_max = s ? width : bank_width;
         const double centre = x_min + (x_max - x_min); // the reference's x_middle is x_max (game_map.py:48)
         P2 pts[SSG_MAX_HULL], hull[2 * SSG_MAX_HULL];
-        // for each vertex: draw (x, y) until x falls inside the bank's strip (at most 1000 tries), game_map.py:52-60.  Half the
-        // candidates are rejected; written as ONE loop over candidates in which every lane advances its own vertex index, a
-        // wave runs max-over-lanes of the TOTAL tries (~60) instead of the sum over vertices of the per-vertex maxima (~140).
-        // Each lane still consumes its stream in exactly the per-vertex order.
+        // gen_river_poly draws, per vertex, x ~ gauss(centre, 50) until it falls inside the bank's strip [x_min, x_max] (at most
+        // 1000 tries, game_map.py:52-60) and y ~ y_start + gauss(y_delta * i, 20).  The reference's centre IS x_max
+        // (game_map.py:48), so the accepted x is a normal truncated to [centre - strip, centre]: drawn here as the REFLECTED
+        // half-normal centre - |50 z| (same conditional law; rejected only beyond the strip's 3 sigma: 0.27 % instead of the
+        // 50.1 % of the two-sided draw), and one Box-Muller transform yields both z (its cosine branch) and the y deviate (its
+        // sine branch) — independent standard normals.  ~1 transform per vertex instead of ~4 transcendental gauss() calls;
+        // same distribution, a different (Philox, not Mersenne-Twister anyway) stream.
         for (int i = 1, tries = 0; i <= N;) {
-            const double x = rng.gauss(centre, 50.0);
-            const double y = y_start + rng.gauss(y_delta * i, 20.0);
+            const double u1 = 1.0 - rng.uniform(), u2 = rng.uniform();
+            const double rad = sqrt(-2.0 * log(u1));
+            double sn, cs;
+            sincos(6.283185307179586 * u2, &sn, &cs);
+            const double x = centre - fabs(50.0 * (rad * cs));
+            const double y = y_start + (y_delta * i + 20.0 * (rad * sn));
             ++tries;
             if (!((x < x_min || x > x_max) && tries < 1000)) {
                 pts[i - 1] = P2{x, y};
@@ -226,8 +237,10 @@ __device__ void generate_world(Rng &rng, int n_goals, double width, double heigh
         bbp[0] = l; bbp[1] = b; bbp[2] = r; bbp[3] = t;
     }
     // ---- gen_goal_path (game.py:300-330) ----
-    const Hull hl{(int)rec[SSG_MAP_OFF_COUNTS + 0], rec + SSG_MAP_OFF_PLANES};
-    const Hull hr{(int)rec[SSG_MAP_OFF_COUNTS + 1], rec + SSG_MAP_OFF_PLANES + SSG_MAX_HULL * SSG_PLANE_DOUBLES};
+    const Hull hl{(int)rec[SSG_MAP_OFF_COUNTS + 0], rec + SSG_MAP_OFF_PLANES, rec[SSG_MAP_OFF_AABB + 0], rec[SSG_MAP_OFF_AABB + 1],
+                  rec[SSG_MAP_OFF_AABB + 2], rec[SSG_MAP_OFF_AABB + 3]};
+    const Hull hr{(int)rec[SSG_MAP_OFF_COUNTS + 1], rec + SSG_MAP_OFF_PLANES + SSG_MAX_HULL * SSG_PLANE_DOUBLES, rec[SSG_MAP_OFF_AABB + 4],
+                  rec[SSG_MAP_OFF_AABB + 5], rec[SSG_MAP_OFF_AABB + 6], rec[SSG_MAP_OFF_AABB + 7]};
     const double gy_delta = height / (n_goals + 1), x_middle = width / 2;
     double best = 0.0, sgx = -1.0, sgy = -1.0;
     for (int i = 1; i <= n_goals; ++i) {
