@@ -44,7 +44,8 @@ struct Rng {
     __device__ uint32_t u32()
     {
         if (!have) refill();
-        return out[--have];
+        --have; // (selected, not indexed: a dynamically indexed private array lives in scratch memory)
+        return have == 3 ? out[3] : (have == 2 ? out[2] : (have == 1 ? out[1] : out[0]));
     }
     __device__ double uniform() // [0, 1) with 53 random bits
     {
@@ -61,67 +62,103 @@ struct Rng {
 
 struct P2 { double x, y; };
 
-__device__ double cross3(P2 o, P2 a, P2 b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); }
+__device__ __forceinline__ double cross3(P2 o, P2 a, P2 b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); }
+__device__ __forceinline__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
 
-// strict convex hull, CCW, first vertex = lexicographic minimum (same as the host's monotone chain)
-__device__ int convex_hull(P2 *pts, int n, P2 *hull)
+// A world is built by ONE lane, and its chain is what the refill kernel's time is made of (a few hundred waves, each
+// alone on its SIMD).  Nothing on that chain may go to memory: the twelve polygon points and the hull's planes live in
+// REGISTERS (every loop over them is unrolled to the fixed bound SSG_MAX_HULL and predicated on the count, so every index is
+// static), and only the monotone chain's stack, whose depth is data-dependent, sits in per-lane LDS columns.  (A first
+// version kept points / hull in private arrays = scratch memory and read the planes back from the record in global memory:
+// 130 us of its 277 us per refill went into hulling, 116 us into the goal path's twenty segment queries.)
+constexpr int kHullStack = SSG_MAX_HULL + 2;
+
+struct HullR { // cpPolyShape planes of one bank hull: v0, n, v0.n per plane, and the cached AABB
+    int n;
+    double vx[SSG_MAX_HULL], vy[SSG_MAX_HULL], nx[SSG_MAX_HULL], ny[SSG_MAX_HULL], d[SSG_MAX_HULL];
+    double l, b, r, t;
+};
+
+// strict convex hull, CCW, first vertex = lexicographic (x, then y) minimum (same as the host's monotone chain), of the
+// SSG_MAX_HULL points p[]; the hull's vertices end up in stk[(2*k + comp) * 64 + lane], k < returned count
+__device__ __forceinline__ int convex_hull(P2 (&p)[SSG_MAX_HULL], double *stk, int lane)
 {
-    for (int i = 1; i < n; ++i) { // insertion sort by (x, y)
-        P2 v = pts[i];
-        int j = i - 1;
-        while (j >= 0 && (pts[j].x > v.x || (pts[j].x == v.x && pts[j].y > v.y))) { pts[j + 1] = pts[j]; --j; }
-        pts[j + 1] = v;
+    // sort by (x, y): odd-even transposition network (static indices; any correct sort gives the host's order)
+#pragma unroll
+    for (int pass = 0; pass < SSG_MAX_HULL; ++pass) {
+#pragma unroll
+        for (int i = pass & 1; i + 1 < SSG_MAX_HULL; i += 2) {
+            const bool sw = (p[i].x > p[i + 1].x) | ((p[i].x == p[i + 1].x) & (p[i].y > p[i + 1].y));
+            const P2 a = p[i], b = p[i + 1];
+            p[i].x = sw ? b.x : a.x; p[i].y = sw ? b.y : a.y;
+            p[i + 1].x = sw ? a.x : b.x; p[i + 1].y = sw ? a.y : b.y;
+        }
     }
-    int m = 0; // drop exact duplicates
-    for (int i = 0; i < n; ++i)
-        if (i == 0 || pts[i].x != pts[m - 1].x || pts[i].y != pts[m - 1].y) pts[m++] = pts[i];
-    n = m;
+    bool keep[SSG_MAX_HULL]; // exact duplicates are dropped (the host does; practically never with random vertices)
+    int n = 0, last = 0;     // number of distinct points, index of the last one
+#pragma unroll
+    for (int i = 0; i < SSG_MAX_HULL; ++i) {
+        keep[i] = (i == 0) || (p[i].x != p[i - 1].x) || (p[i].y != p[i - 1].y);
+        n += keep[i] ? 1 : 0;
+        last = keep[i] ? i : last;
+    }
+    auto put = [&](int k, P2 v) { stk[(2 * k) * 64 + lane] = v.x; stk[(2 * k + 1) * 64 + lane] = v.y; };
+    auto get = [&](int k) -> P2 { return P2{stk[(2 * k) * 64 + lane], stk[(2 * k + 1) * 64 + lane]}; };
     if (n <= 2) {
-        for (int i = 0; i < n; ++i) hull[i] = pts[i];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < SSG_MAX_HULL; ++i)
+            if (keep[i]) put(k++, p[i]);
         return n;
     }
+    // monotone chain; the two topmost entries are mirrored in registers (h1 = stack[k-1], h2 = stack[k-2])
     int k = 0;
-    for (int i = 0; i < n; ++i) {
-        while (k >= 2 && cross3(hull[k - 2], hull[k - 1], pts[i]) <= 0.0) --k;
-        hull[k++] = pts[i];
-    }
-    for (int i = n - 2, t = k + 1; i >= 0; --i) {
-        while (k >= t && cross3(hull[k - 2], hull[k - 1], pts[i]) <= 0.0) --k;
-        hull[k++] = pts[i];
-    }
+    P2 h1 = P2{0, 0}, h2 = P2{0, 0};
+    auto push = [&](P2 v, int floor_) {
+        while (k >= floor_ && cross3(h2, h1, v) <= 0.0) { // pop
+            --k;
+            h1 = h2;
+            if (k >= 2) h2 = get(k - 2);
+        }
+        put(k++, v);
+        h2 = h1; h1 = v;
+    };
+#pragma unroll
+    for (int i = 0; i < SSG_MAX_HULL; ++i) // lower chain
+        if (keep[i]) push(p[i], 2);
+    const int t = k + 1;
+#pragma unroll
+    for (int i = SSG_MAX_HULL - 1; i >= 0; --i) // upper chain: from the second-to-last distinct point down to the first
+        if (keep[i] && i != last) push(p[i], t);
     return k - 1;
 }
 
-__device__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
-
-struct Hull {
-    int n;
-    const double *pl; // n planes of SSG_PLANE_DOUBLES doubles inside the record being built
-    double l, b, r, t; // the hull's AABB
-};
-
-__device__ double point_query(const Hull &h, double px, double py)
+__device__ __forceinline__ double point_query(const HullR &h, double px, double py)
 {
-    double v0x = h.pl[SSG_PLANE_DOUBLES * (h.n - 1) + 0], v0y = h.pl[SSG_PLANE_DOUBLES * (h.n - 1) + 1];
+    double v0x = 0.0, v0y = 0.0; // the last vertex
+#pragma unroll
+    for (int i = 0; i < SSG_MAX_HULL; ++i) { v0x = (i == h.n - 1) ? h.vx[i] : v0x; v0y = (i == h.n - 1) ? h.vy[i] : v0y; }
     double best = INFINITY;
     bool outside = false;
-    for (int i = 0; i < h.n; ++i) {
-        const double *p = h.pl + SSG_PLANE_DOUBLES * i;
-        const double v1x = p[0], v1y = p[1];
-        outside = outside || ((p[2] * (px - v1x) + p[3] * (py - v1y)) > 0.0);
-        const double dx = v0x - v1x, dy = v0y - v1y;
-        const double t = clamp01((dx * (px - v1x) + dy * (py - v1y)) / (dx * dx + dy * dy));
-        const double qx = v1x + dx * t, qy = v1y + dy * t;
-        const double ex = px - qx, ey = py - qy;
-        const double d = sqrt(ex * ex + ey * ey);
-        if (d < best) best = d;
-        v0x = v1x; v0y = v1y;
+#pragma unroll
+    for (int i = 0; i < SSG_MAX_HULL; ++i) {
+        if (i < h.n) {
+            const double v1x = h.vx[i], v1y = h.vy[i];
+            outside = outside || ((h.nx[i] * (px - v1x) + h.ny[i] * (py - v1y)) > 0.0);
+            const double dx = v0x - v1x, dy = v0y - v1y;
+            const double t = clamp01((dx * (px - v1x) + dy * (py - v1y)) / (dx * dx + dy * dy));
+            const double qx = v1x + dx * t, qy = v1y + dy * t;
+            const double ex = px - qx, ey = py - qy;
+            const double d = sqrt(ex * ex + ey * ey);
+            if (d < best) best = d;
+            v0x = v1x; v0y = v1y;
+        }
     }
     return outside ? best : -best;
 }
 
 // cpShapeSegmentQuery with query radius r2 against one hull: returns hit, reported point x (all gen_goal_path uses)
-__device__ bool segment_query_x(const Hull &h, double ax, double ay, double bx, double by, double r2, double &outx)
+__device__ __forceinline__ bool segment_query_x(const HullR &h, double ax, double ay, double bx, double by, double r2, double &outx)
 {
     double alpha = 1.0;
     bool hit = false;
@@ -130,45 +167,50 @@ __device__ bool segment_query_x(const Hull &h, double ax, double ay, double bx, 
     // query — a division and a square root per edge — cannot report a hit at alpha 0)
     const double bx_ = fmax(fmax(h.l - ax, ax - h.r), 0.0), by_ = fmax(fmax(h.b - ay, ay - h.t), 0.0);
     if (bx_ * bx_ + by_ * by_ <= r2 * r2 * 1.0000001 && point_query(h, ax, ay) <= r2) return true; // reported point stays the far end
-    for (int i = 0; i < h.n; ++i) {
-        const double *p = h.pl + SSG_PLANE_DOUBLES * i;
-        const double nx = p[2], ny = p[3];
-        const double an = ax * nx + ay * ny;
-        const double d = an - p[4] - r2;
-        if (d < 0.0) continue;
-        const double bn = bx * nx + by * ny;
-        const double t = d / fmax(an - bn, DBL_MIN);
-        if (t < 0.0 || 1.0 < t) continue;
-        const double omt = 1.0 - t;
-        const double ptx = ax * omt + bx * t, pty = ay * omt + by * t;
-        const double dtv = nx * pty - ny * ptx;
-        const double *pp = h.pl + SSG_PLANE_DOUBLES * ((i - 1 + h.n) % h.n);       // the edge's start vertex v[i-1]
-        const double dtmin = nx * pp[1] - ny * pp[0], dtmax = nx * p[1] - ny * p[0]; // cpvcross(n, v[i-1]), cpvcross(n, v[i])
-        if (dtmin <= dtv && dtv <= dtmax) {
-            hit = true;
-            outx = ptx - nx * r2;
-            alpha = t;
+    double pvx = 0.0, pvy = 0.0; // v[i-1], starting from the last vertex
+#pragma unroll
+    for (int i = 0; i < SSG_MAX_HULL; ++i) { pvx = (i == h.n - 1) ? h.vx[i] : pvx; pvy = (i == h.n - 1) ? h.vy[i] : pvy; }
+#pragma unroll
+    for (int i = 0; i < SSG_MAX_HULL; ++i) {
+        if (i < h.n) {
+            const double nx = h.nx[i], ny = h.ny[i];
+            const double an = ax * nx + ay * ny;
+            const double d = an - h.d[i] - r2;
+            const double bn = bx * nx + by * ny;
+            const double t = d / fmax(an - bn, DBL_MIN);
+            const double omt = 1.0 - t;
+            const double ptx = ax * omt + bx * t, pty = ay * omt + by * t;
+            const double dtv = nx * pty - ny * ptx;
+            const double dtmin = nx * pvy - ny * pvx, dtmax = nx * h.vy[i] - ny * h.vx[i]; // cpvcross(n, v[i-1]), cpvcross(n, v[i])
+            if (!(d < 0.0) && !(t < 0.0 || 1.0 < t) && dtmin <= dtv && dtv <= dtmax) {
+                hit = true;
+                outx = ptx - nx * r2;
+                alpha = t;
+            }
+            pvx = h.vx[i]; pvy = h.vy[i];
         }
     }
     if (r2 > 0.0) {
-        for (int i = 0; i < h.n; ++i) {
-            const double *p = h.pl + SSG_PLANE_DOUBLES * i;
-            const double cx = p[0], cy = p[1];
-            const double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
-            const double daa = dax * dax + day * day, dab = dax * dbx + day * dby, dbb = dbx * dbx + dby * dby;
-            const double qa = daa - 2.0 * dab + dbb;
-            const double qb = dab - daa;
-            const double det = qb * qb - qa * (daa - r2 * r2);
-            if (det >= 0.0) {
-                const double t = (-qb - sqrt(det)) / qa;
-                if (0.0 <= t && t <= 1.0 && t < alpha) {
-                    const double omt = 1.0 - t;
-                    double nx = dax * omt + dbx * t, ny = day * omt + dby * t;
-                    const double inv = 1.0 / (sqrt(nx * nx + ny * ny) + DBL_MIN);
-                    nx *= inv;
-                    hit = true;
-                    outx = (ax * omt + bx * t) - nx * r2;
-                    alpha = t;
+#pragma unroll
+        for (int i = 0; i < SSG_MAX_HULL; ++i) {
+            if (i < h.n) {
+                const double cx = h.vx[i], cy = h.vy[i];
+                const double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
+                const double daa = dax * dax + day * day, dab = dax * dbx + day * dby, dbb = dbx * dbx + dby * dby;
+                const double qa = daa - 2.0 * dab + dbb;
+                const double qb = dab - daa;
+                const double det = qb * qb - qa * (daa - r2 * r2);
+                if (det >= 0.0) {
+                    const double t = (-qb - sqrt(det)) / qa;
+                    if (0.0 <= t && t <= 1.0 && t < alpha) {
+                        const double omt = 1.0 - t;
+                        double nx = dax * omt + dbx * t, ny = day * omt + dby * t;
+                        const double inv = 1.0 / (sqrt(nx * nx + ny * ny) + DBL_MIN);
+                        nx *= inv;
+                        hit = true;
+                        outx = (ax * omt + bx * t) - nx * r2;
+                        alpha = t;
+                    }
                 }
             }
         }
@@ -176,23 +218,27 @@ __device__ bool segment_query_x(const Hull &h, double ax, double ay, double bx, 
     return hit;
 }
 
-
 // One world: ShipGame.reset's gen_level + gen_goal_path (game.py:60-71,300-330) into the record `rec`, from the stream
 // `rng`.  rw (nullable): [2][12][2] polygon vertices, then per goal (y, u, fallback_x) = 3 doubles -> 48 + 3*n_goals.
-__device__ void generate_world(Rng &rng, int n_goals, double width, double height, double width_frac, double spawn_x,
-                               double spawn_y, double *__restrict__ rec, double *__restrict__ rw)
+// stk: kHullStack * 2 * 64 doubles of LDS (per-lane columns); lane = this thread's lane (one wave per workgroup).
+__device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double width, double height, double width_frac, double spawn_x,
+                                               double spawn_y, double *__restrict__ rec, double *__restrict__ rw, double *stk, int lane)
 {
     for (int i = 0; i < SSG_MAP_STRIDE; ++i) rec[i] = 0.0;
 
     // ---- gen_river_poly (game_map.py:22-73) ----
-    const int N = 10;
+    constexpr int N = 10;
+    static_assert(N + 2 == SSG_MAX_HULL, "ten jittered points + two corners");
     const double y_start = -100.0;
     const double y_delta = (height * 1.2 - y_start) / N;
     const double bank_width = width_frac * width / 2;
-    for (int s = 0; s < 2; ++s) {
+    HullR hl, hr;
+    auto build_side = [&](const int s, HullR &h) {
         const double x_min = s ? width - bank_width : 0.0, x_max = s ? width : bank_width;
         const double centre = x_min + (x_max - x_min); // the reference's x_middle is x_max (game_map.py:48)
-        P2 pts[SSG_MAX_HULL], hull[2 * SSG_MAX_HULL];
+        P2 pts[SSG_MAX_HULL];
+#pragma unroll
+        for (int k = 0; k < SSG_MAX_HULL; ++k) pts[k] = P2{0.0, 0.0};
         // gen_river_poly draws, per vertex, x ~ gauss(centre, 50) until it falls inside the bank's strip [x_min, x_max] (at most
         // 1000 tries, game_map.py:52-60) and y ~ y_start + gauss(y_delta * i, 20).  The reference's centre IS x_max
         // (game_map.py:48), so the accepted x is a normal truncated to [centre - strip, centre]: drawn here as the REFLECTED
@@ -200,47 +246,66 @@ __device__ void generate_world(Rng &rng, int n_goals, double width, double heigh
         // 50.1 % of the two-sided draw), and one Box-Muller transform yields both z (its cosine branch) and the y deviate (its
         // sine branch) — independent standard normals.  ~1 transform per vertex instead of ~4 transcendental gauss() calls;
         // same distribution, a different (Philox, not Mersenne-Twister anyway) stream.
+        // (ONE rolled loop over candidates in which every lane advances its own vertex index; the accepted vertex goes to
+        // its register by a static select sweep, so that pts[] is never indexed dynamically.)
         for (int i = 1, tries = 0; i <= N;) {
             const double u1 = 1.0 - rng.uniform(), u2 = rng.uniform();
             const double rad = sqrt(-2.0 * log(u1));
             double sn, cs;
-            sincos(6.283185307179586 * u2, &sn, &cs);
+            sincospi(2.0 * u2, &sn, &cs); // (exact argument reduction: no Payne-Hanek machinery on the chain)
             const double x = centre - fabs(50.0 * (rad * cs));
             const double y = y_start + (y_delta * i + 20.0 * (rad * sn));
             ++tries;
             if (!((x < x_min || x > x_max) && tries < 1000)) {
-                pts[i - 1] = P2{x, y};
+#pragma unroll
+                for (int k = 0; k < N; ++k) { pts[k].x = (k == i - 1) ? x : pts[k].x; pts[k].y = (k == i - 1) ? y : pts[k].y; }
                 ++i;
                 tries = 0;
             }
         }
         pts[N] = P2{s ? width : 0.0, height};
         pts[N + 1] = P2{s ? width : 0.0, 0.0};
-        if (rw)
+        if (rw) {
+#pragma unroll
             for (int i = 0; i < SSG_MAX_HULL; ++i) { rw[s * 24 + 2 * i] = pts[i].x; rw[s * 24 + 2 * i + 1] = pts[i].y; }
+        }
+#if defined(SSG_GEN_STOP) && SSG_GEN_STOP == 1 /* timing-only development builds */
+        rec[SSG_MAP_OFF_PLANES + s] = pts[3].x + pts[7].y;
+        return;
+#endif
         // ---- pm.Poly: hull + splitting planes + cached AABB (models.py:180) ----
-        const int n = convex_hull(pts, N + 2, hull);
+        const int n = convex_hull(pts, stk, lane);
+        h.n = n;
         rec[SSG_MAP_OFF_COUNTS + s] = (double)n;
         double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
         double *pp = rec + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
-        for (int i = 0; i < n; ++i) {
-            const P2 a = hull[(i - 1 + n) % n], bb = hull[i];
-            const double ex = bb.x - a.x, ey = bb.y - a.y;
-            const double rx = ey, ry = -ex;
-            const double inv = 1.0 / (sqrt(rx * rx + ry * ry) + DBL_MIN);
-            double *q = pp + SSG_PLANE_DOUBLES * i;
-            q[0] = bb.x; q[1] = bb.y; q[2] = rx * inv; q[3] = ry * inv;
-            q[4] = q[0] * q[2] + q[1] * q[3];
-            l = fmin(l, bb.x); r = fmax(r, bb.x); b = fmin(b, bb.y); t = fmax(t, bb.y);
+        P2 a = P2{stk[(2 * (n - 1)) * 64 + lane], stk[(2 * (n - 1) + 1) * 64 + lane]}; // hull[n-1]
+#pragma unroll
+        for (int i = 0; i < SSG_MAX_HULL; ++i) {
+            h.vx[i] = h.vy[i] = h.nx[i] = h.ny[i] = h.d[i] = 0.0;
+            if (i < n) {
+                const P2 bb = P2{stk[(2 * i) * 64 + lane], stk[(2 * i + 1) * 64 + lane]};
+                const double ex = bb.x - a.x, ey = bb.y - a.y;
+                const double rx = ey, ry = -ex;
+                const double inv = 1.0 / (sqrt(rx * rx + ry * ry) + DBL_MIN);
+                h.vx[i] = bb.x; h.vy[i] = bb.y; h.nx[i] = rx * inv; h.ny[i] = ry * inv;
+                h.d[i] = h.vx[i] * h.nx[i] + h.vy[i] * h.ny[i];
+                double *q = pp + SSG_PLANE_DOUBLES * i;
+                q[0] = h.vx[i]; q[1] = h.vy[i]; q[2] = h.nx[i]; q[3] = h.ny[i]; q[4] = h.d[i];
+                l = fmin(l, bb.x); r = fmax(r, bb.x); b = fmin(b, bb.y); t = fmax(t, bb.y);
+                a = bb;
+            }
         }
+        h.l = l; h.b = b; h.r = r; h.t = t;
         double *bbp = rec + SSG_MAP_OFF_AABB + 4 * s;
         bbp[0] = l; bbp[1] = b; bbp[2] = r; bbp[3] = t;
-    }
+    };
+    build_side(0, hl);
+    build_side(1, hr);
+#if defined(SSG_GEN_STOP) && SSG_GEN_STOP <= 2
+    return;
+#endif
     // ---- gen_goal_path (game.py:300-330) ----
-    const Hull hl{(int)rec[SSG_MAP_OFF_COUNTS + 0], rec + SSG_MAP_OFF_PLANES, rec[SSG_MAP_OFF_AABB + 0], rec[SSG_MAP_OFF_AABB + 1],
-                  rec[SSG_MAP_OFF_AABB + 2], rec[SSG_MAP_OFF_AABB + 3]};
-    const Hull hr{(int)rec[SSG_MAP_OFF_COUNTS + 1], rec + SSG_MAP_OFF_PLANES + SSG_MAX_HULL * SSG_PLANE_DOUBLES, rec[SSG_MAP_OFF_AABB + 4],
-                  rec[SSG_MAP_OFF_AABB + 5], rec[SSG_MAP_OFF_AABB + 6], rec[SSG_MAP_OFF_AABB + 7]};
     const double gy_delta = height / (n_goals + 1), x_middle = width / 2;
     double best = 0.0, sgx = -1.0, sgy = -1.0;
     for (int i = 1; i <= n_goals; ++i) {
@@ -273,10 +338,11 @@ __device__ void generate_world(Rng &rng, int n_goals, double width, double heigh
 } // namespace
 
 // raw: per map 48 + 3*n_goals doubles (generate_world)
-__global__ void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, double width, double height,
+__global__ __launch_bounds__(64) void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, double width, double height,
                                      double width_frac, double spawn_x, double spawn_y, double *__restrict__ bank,
                                      double *__restrict__ raw)
 {
+    __shared__ double stk[kHullStack * 2 * 64];
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_maps) return;
     Rng rng;
@@ -284,7 +350,7 @@ __global__ void generate_bank_kernel(uint64_t seed, int n_maps, int n_goals, dou
     rng.ctr[0] = (uint32_t)m; rng.ctr[1] = 0x57474e00u /* "WGN" domain tag */; rng.ctr[2] = 0; rng.ctr[3] = 0;
     rng.have = 0;
     generate_world(rng, n_goals, width, height, width_frac, spawn_x, spawn_y, bank + (size_t)m * SSG_MAP_STRIDE,
-                   raw ? raw + (size_t)m * (48 + 3 * n_goals) : nullptr);
+                   raw ? raw + (size_t)m * (48 + 3 * n_goals) : nullptr, stk, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -322,9 +388,10 @@ __global__ void refill_scan_kernel(const DevCfg c, unsigned long long *__restric
     for (int i = 0; i < need; ++i) queue[base + i] = ((unsigned long long)(unsigned)e << 32) | (unsigned)(gen + i);
 }
 
-__global__ void refill_gen_kernel(const DevCfg c, uint64_t seed, double width_frac, const unsigned long long *__restrict__ queue,
+__global__ __launch_bounds__(64) void refill_gen_kernel(const DevCfg c, uint64_t seed, double width_frac, const unsigned long long *__restrict__ queue,
                                   const unsigned *__restrict__ count, double *__restrict__ bank, double *__restrict__ raw)
 {
+    __shared__ double stk[kHullStack * 2 * 64];
     const unsigned n = min(*count, (unsigned)c.n_envs * (unsigned)c.map_ring);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long it = queue[i];
@@ -338,7 +405,7 @@ __global__ void refill_gen_kernel(const DevCfg c, uint64_t seed, double width_fr
         rng.have = 0;
         const size_t slot = (size_t)e * (size_t)c.map_ring + (size_t)(episode % (unsigned)c.map_ring);
         generate_world(rng, c.n_goals, c.width, c.height, width_frac, c.spawn_x, c.spawn_y, bank + slot * SSG_MAP_STRIDE,
-                       raw ? raw + slot * (size_t)(48 + 3 * c.n_goals) : nullptr);
+                       raw ? raw + slot * (size_t)(48 + 3 * c.n_goals) : nullptr, stk, (int)threadIdx.x);
     }
 }
 
