@@ -990,46 +990,101 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         SSG_TICK(emem, 4);
     };
 
-    Info info;
-    for (int g = 0; g < ng; ++g) {
-        if (!((gmask >> g) & 1u)) continue;
-        const CircleShape cg = goal_shape(g);
-        const BB gb = cg.bb();
-        for (int s = 0; s < 2; ++s) {
-            if (!bb_hit(gb, bank_box(s))) continue; // queryReject
-            const BankShape bs = bank_shape(s);
-            collide(cg, bs, info, emem);
-            push(info, g, slot_static, pid_gb(g, s), 0.0);
+    // ---- broadphase: every candidate pair's cpBBIntersects (queryReject) at once, in registers --------------------------
+    // cpSpaceStep visits the pairs in the canonical order of the named ORDER assumption: per goal g its two bank pairs, then
+    // the goals h < g; then per ship k its two bank pairs, the goals, the ships j < k.  Bit o of `cand` = the o-th pair of that
+    // order passed the box test; the narrowphase below takes the set bits in ascending order, so arbiters reach the solver's
+    // list in the same order as the rolled pair loops produced them — which paid ~44 dependent LDS round trips and branches
+    // per env for the one or two pairs that survive.
+    constexpr int kGoalBlock = 2 * SSG_MAX_GOALS + SSG_MAX_GOALS * (SSG_MAX_GOALS - 1) / 2; // 27 bits: goal g starts at 2g + g(g-1)/2
+    auto o_goal = [](int g) { return 2 * g + g * (g - 1) / 2; };
+    auto o_ship = [=](int k) { return kGoalBlock + (2 + SSG_MAX_GOALS) * k + k * (k - 1) / 2; };
+    static_assert(kGoalBlock + 3 * (2 + SSG_MAX_GOALS) + 3 <= 64 && SSG_N_TRAFFIC == 3, "candidate mask layout");
+    unsigned long long cand = 0ull;
+    {
+        BB gbx[SSG_MAX_GOALS], kbx[SSG_N_TRAFFIC];
+        const BB bank0 = bank_box(0), bank1 = bank_box(1);
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+            CircleShape cg;
+            cg.c = (g < ng) ? mk(BF(g < ng ? g : 0, B_PX), BF(g < ng ? g : 0, B_PY)) : mk(0, 0);
+            cg.rad = c.goal_r;
+            gbx[g] = cg.bb();
         }
-        for (int h = 0; h < g; ++h) {
-            if (!((gmask >> h) & 1u)) continue;
-            const CircleShape ch = goal_shape(h);
-            if (!bb_hit(ch.bb(), gb)) continue;
-            collide(ch, cg, info, emem);
-            push(info, h, g, pid_gg(h, g), 0.0);
+#pragma unroll
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) kbx[k] = ship_shape(k).bb();
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+            const bool pg = (g < ng) & (bool)((gmask >> g) & 1u);
+            cand |= (unsigned long long)(pg & bb_hit(gbx[g], bank0)) << (o_goal(g) + 0);
+            cand |= (unsigned long long)(pg & bb_hit(gbx[g], bank1)) << (o_goal(g) + 1);
+#pragma unroll
+            for (int h = 0; h < g; ++h)
+                cand |= (unsigned long long)(pg & (bool)((gmask >> h) & 1u) & bb_hit(gbx[h], gbx[g])) << (o_goal(g) + 2 + h);
+        }
+#pragma unroll
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+            cand |= (unsigned long long)bb_hit(kbx[k], bank0) << (o_ship(k) + 0);
+            cand |= (unsigned long long)bb_hit(kbx[k], bank1) << (o_ship(k) + 1);
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS; ++g)
+                cand |= (unsigned long long)((g < ng) & (bool)((gmask >> g) & 1u) & bb_hit(gbx[g], kbx[k])) << (o_ship(k) + 2 + g);
+#pragma unroll
+            for (int j = 0; j < k; ++j) cand |= (unsigned long long)bb_hit(kbx[j], kbx[k]) << (o_ship(k) + 2 + SSG_MAX_GOALS + j);
         }
     }
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        const ShipShape sk = ship_shape(k);
-        const BB kb = sk.bb();
-        for (int s = 0; s < 2; ++s) {
-            if (!bb_hit(kb, bank_box(s))) continue;
-            const BankShape bs = bank_shape(s);
-            collide(sk, bs, info, emem);
-            push(info, slot_ship0 + k, slot_static, pid_tb(k, s), d.ship_friction * 0.0);
+    // ---- narrowphase (cpCollide) of the surviving pairs, canonical order per env; one code site per pair type -------------
+    Info info;
+    for (;;) {
+        // the wave's next pair = the lowest candidate of any lane (wave-uniform: one code site per trip; every lane still
+        // meets its own pairs in ascending, i.e. canonical, order)
+        // (minimum over the ACTIVE lanes by ballots, most significant bit first: lanes of a partly filled wave have left the
+        // kernel, and a shuffle would read whatever their registers hold)
+        const int ol = cand ? __ffsll((long long)cand) - 1 : 63;
+        unsigned long long sel = __ballot(cand != 0ull);
+        if (sel == 0ull) break;
+#pragma unroll
+        for (int b = 5; b >= 0; --b) {
+            const unsigned long long zeros = __ballot((bool)((sel >> lane) & 1ull) & !((ol >> b) & 1));
+            sel = zeros ? zeros : sel;
         }
-        for (int g = 0; g < ng; ++g) {
-            if (!((gmask >> g) & 1u)) continue;
-            const CircleShape cg = goal_shape(g);
-            if (!bb_hit(cg.bb(), kb)) continue;
-            collide(cg, sk, info, emem);
-            push(info, g, slot_ship0 + k, pid_gt(g, k), 0.0 * d.ship_friction);
-        }
-        for (int j = 0; j < k; ++j) {
-            const ShipShape sj = ship_shape(j);
-            if (!bb_hit(sj.bb(), kb)) continue;
-            collide(sj, sk, info, emem);
-            push(info, slot_ship0 + j, slot_ship0 + k, pid_tt(j, k), d.ship_friction * d.ship_friction);
+        const int o = __builtin_amdgcn_readlane(ol, __ffsll((long long)sel) - 1);
+        if ((cand >> o) & 1ull) {
+            cand &= ~(1ull << o);
+            if (o < kGoalBlock) {
+                const int g = (o >= o_goal(5)) ? 5 : (o >= o_goal(4)) ? 4 : (o >= o_goal(3)) ? 3 : (o >= o_goal(2)) ? 2 : (o >= o_goal(1)) ? 1 : 0;
+                const int r = o - (2 * g + g * (g - 1) / 2);
+                const CircleShape cg = goal_shape(g);
+                if (r < 2) {
+                    const BankShape bs = bank_shape(r);
+                    collide(cg, bs, info, emem);
+                    push(info, g, slot_static, pid_gb(g, r), 0.0);
+                } else {
+                    const int h = r - 2;
+                    const CircleShape ch = goal_shape(h);
+                    collide(ch, cg, info, emem);
+                    push(info, h, g, pid_gg(h, g), 0.0);
+                }
+            } else {
+                const int k = (o >= o_ship(2)) ? 2 : (o >= o_ship(1)) ? 1 : 0;
+                const int r = o - (kGoalBlock + (2 + SSG_MAX_GOALS) * k + k * (k - 1) / 2);
+                const ShipShape sk = ship_shape(k);
+                if (r < 2) {
+                    const BankShape bs = bank_shape(r);
+                    collide(sk, bs, info, emem);
+                    push(info, slot_ship0 + k, slot_static, pid_tb(k, r), d.ship_friction * 0.0);
+                } else if (r < 2 + SSG_MAX_GOALS) {
+                    const int g = r - 2;
+                    const CircleShape cg = goal_shape(g);
+                    collide(cg, sk, info, emem);
+                    push(info, g, slot_ship0 + k, pid_gt(g, k), 0.0 * d.ship_friction);
+                } else {
+                    const int j = r - 2 - SSG_MAX_GOALS;
+                    const ShipShape sj = ship_shape(j);
+                    collide(sj, sk, info, emem);
+                    push(info, slot_ship0 + j, slot_ship0 + k, pid_tt(j, k), d.ship_friction * d.ship_friction);
+                }
+            }
         }
     }
 
