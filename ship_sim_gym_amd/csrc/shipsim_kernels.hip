@@ -155,6 +155,23 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
     gx = -1.0;
     gy = -1.0;
     double best = INFINITY;
+    if constexpr (!LDS_BANK && !DYN) { // gathered record: all goal centres in one round trip, not one per goal
+        double gxy[2 * SSG_MAX_GOALS];
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) { const double2 v = bank_at2<LDS_BANK>(c, goff + 2 * g); gxy[2 * g] = v.x; gxy[2 * g + 1] = v.y; }
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+            if (g >= c.n_goals) break;
+            const double px = gxy[2 * g], py = gxy[2 * g + 1];
+            const double dx = px - x, dy = py - y;
+            const double d = dx * dx + dy * dy;
+            const bool take = ((gm >> g) & 1u) & (d < best);
+            best = take ? d : best;
+            gx = take ? px : gx;
+            gy = take ? py : gy;
+        }
+        return;
+    }
     for (int g = 0; g < c.n_goals; ++g) {
         const double px = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
         const double py = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
@@ -250,7 +267,9 @@ constexpr unsigned long long kLidarMiss = ~0ull; // result key of a beam no hull
 // res[beam][lane]: the smallest key is the hit of the FIRST shape in list order that reports one (models.py:61-72:
 // the left bank before the right), whatever order the pairs were processed in; kLidarMiss = no hit.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kPlaneChunk = 4; // hull planes fetched from LDS ahead of their arithmetic, per loop trip
+// hull planes fetched ahead of their arithmetic, per loop trip: 4 from LDS; 8 when the record is gathered from L2 / HBM (every
+// trip is then a dependent ~1 k-cycle round trip on the lidar role's chain, and 99.4 % of the bank hulls have <= 8 planes)
+template <bool LDS_BANK> struct PlaneChunk { static constexpr int n = LDS_BANK ? 4 : 8; };
 
 template <bool LDS_BANK, bool EXACT>
 __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue,
@@ -276,7 +295,10 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         double ptx = ex, pty = ey;
         double bd = -1.0, bden = 1.0;
         int bj = 0;
-        for (int j0 = 0; __any(act & (j0 < cnt)); j0 += kPlaneChunk) {
+        constexpr int kPlaneChunk = PlaneChunk<LDS_BANK>::n;
+        // (the record is gathered: the plane count is requested WITH the first chunk — the chunk's addresses do not depend on it —
+        // and the loop condition below is evaluated after both are in flight)
+        for (int j0 = 0; (j0 == 0 && !LDS_BANK) || __any(act & (j0 < cnt)); j0 += kPlaneChunk) {
             double pv0x[kPlaneChunk], pv0y[kPlaneChunk], pnx[kPlaneChunk], pny[kPlaneChunk], pv0n[kPlaneChunk];
             double pdtmin[kPlaneChunk], pdtmax[kPlaneChunk];
 #pragma unroll
@@ -633,16 +655,41 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
         if (!__any(near_s)) continue;
         const int cnt = (cnts >> (8 * s)) & 0xFF;
         bool sep = false;
-        for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
-            if (near_s & !sep & (j < cnt)) { // (only the lanes still looking gather a plane: the LDS pipe is the busiest unit)
-                const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
-                const double2 nn = bank_at2<LDS_BANK>(c, q + 2);
-                const double nx = nn.x, ny = nn.y;
-                const double v0n = bank_at<LDS_BANK>(c, q + 4);
-                bool allfront = true;
+        if constexpr (LDS_BANK) {
+            for (int j = 0; __any(near_s & !sep & (j < cnt)); ++j) {
+                if (near_s & !sep & (j < cnt)) { // (only the lanes still looking gather a plane: the LDS pipe is the busiest unit)
+                    const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
+                    const double2 nn = bank_at2<LDS_BANK>(c, q + 2);
+                    const double nx = nn.x, ny = nn.y;
+                    const double v0n = bank_at<LDS_BANK>(c, q + 4);
+                    bool allfront = true;
 #pragma unroll
-                for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
-                sep = allfront;
+                    for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx * swx[i] + ny * swy[i]) > v0n);
+                    sep = allfront;
+                }
+            }
+        } else {
+            // the record is gathered from L2 / HBM: four planes per trip (one dependent round trip instead of four); which plane
+            // separates does not matter, only whether one does
+            for (int j0 = 0; __any(near_s & !sep & (j0 < cnt)); j0 += 4) {
+                if (near_s & !sep & (j0 < cnt)) {
+                    double nx[4], ny[4], v0n[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = (j0 + u < SSG_MAX_HULL) ? j0 + u : 0;
+                        const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
+                        const double2 nn = bank_at2<LDS_BANK>(c, q + 2);
+                        nx[u] = nn.x; ny[u] = nn.y;
+                        v0n[u] = bank_at<LDS_BANK>(c, q + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bool allfront = j0 + u < cnt;
+#pragma unroll
+                        for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx[u] * swx[i] + ny[u] * swy[i]) > v0n[u]);
+                        sep = sep | allfront;
+                    }
+                }
             }
         }
         nearbits = sep ? (nearbits & ~(1u << s)) : nearbits;
@@ -1159,9 +1206,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         unsigned *gw = reinterpret_cast<unsigned *>(gq + 64 * SSG_MAX_GOALS);
         gw[lane] = 0u;
         int n_pairs = 0;
-        for (int g = 0; g < c.n_goals; ++g) {
-            const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
-            const double gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
+        auto near_test = [&](int g, double gx, double gy) {
             const double r = c.goal_r;
             const bool near = live & !SSG_ABL(5) & (bool)((gm >> g) & 1u) & ((gx - r) <= sbr) & (sbl <= (gx + r)) &
                               ((gy - r) <= sbt) & (sbb <= (gy + r));
@@ -1169,6 +1214,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const int pos = n_pairs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             if (near) gq[pos] = (unsigned short)(lane | (g << 6));
             n_pairs += __popcll(m);
+        };
+        if constexpr (!LDS_BANK && !DYN) { // gathered record: all goal centres in one round trip, not one per goal
+            double gxy[2 * SSG_MAX_GOALS];
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS; ++g) { const double2 v = bank_at2<LDS_BANK>(c, goff + 2 * g); gxy[2 * g] = v.x; gxy[2 * g + 1] = v.y; }
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS; ++g)
+                if (g < c.n_goals) near_test(g, gxy[2 * g], gxy[2 * g + 1]);
+        } else {
+            for (int g = 0; g < c.n_goals; ++g) near_test(g, goal_at<LDS_BANK, DYN>(c, goff, g, 0), goal_at<LDS_BANK, DYN>(c, goff, g, 1));
         }
         for (int base = 0; base < n_pairs; base += 12) {
             const int p = base + wq;

@@ -9,7 +9,8 @@ from ship_sim_gym_amd import _native as N
 from ship_sim_gym_amd.vec_env import ShipVecEnv
 n = int(os.environ.get("SSG_N", "65536"))
 nb = int(os.environ.get("SSG_NB", "8"))
-vec = ShipVecEnv(n, n_maps=64, n_beams=nb)
+mode = os.environ.get("SSG_MODE", "bank")  # or fresh_device: per-env records gathered from L2
+vec = ShipVecEnv(n, n_maps=64, n_beams=nb, map_mode=mode, ring=64) if mode != "bank" else ShipVecEnv(n, n_maps=64, n_beams=nb)
 L = N.lib()
 epw = 64 if n <= 64 * 256 else (128 if n <= 128 * 256 else 256)
 nw = 4 * ((n + epw - 1) // epw) * epw // 64
