@@ -183,3 +183,20 @@ def test_ring_bookkeeping_with_one_step_episodes_and_reinit(native):
         v.step_tensor(acts[k])
         check_current_records("re-init step %d" % k)
     v.close(); gen.close()
+
+
+def test_fresh_device_trajectory_rollout_equals_single_steps(native):
+    """ssg_rollout_traj in map_ring mode (launches of at most R-1 fused steps with ring refills in between): every slot of the
+    trajectory equals the outputs of single steps."""
+    import torch
+    n, K = 1500, 40
+    a = _vec(n, ring=6, map_seed=21, n_beams=8)
+    b = _vec(n, ring=6, map_seed=21, n_beams=8)
+    a.reset_tensor(); b.reset_tensor()
+    acts = a.random_actions(13, 0, K)
+    to, tr, td, tf = b.rollout_tensor(acts, trajectory=True)
+    for k in range(K):
+        o, r, d, f = a.step_tensor(acts[k])
+        assert torch.equal(o, to[k]) and torch.equal(r, tr[k]) and torch.equal(d, td[k]) and torch.equal(f, tf[k]), k
+    assert torch.equal(a.field(native.F_EPISODES), b.field(native.F_EPISODES)) and torch.equal(a.bank, b.bank)
+    a.close(); b.close()
