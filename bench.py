@@ -159,10 +159,10 @@ def event_time_rollout(vec, acts, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank"):
+def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32):
     """Informational timing of another BASELINE config on this GPU (outside the headline's timed region)."""
     from ship_sim_gym_amd.vec_env import ShipVecEnv
-    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships)
+    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships, ring=ring)
     acts = vec.random_actions(12345, 0, K + W)
     vec.reset_tensor()
     vec.rollout_tensor(acts[:W])
@@ -429,8 +429,10 @@ def main():
                 other["c2_4096_envs_10_beams"] = side_config(dev, 4096, 10, 1, 1000, 200)
                 other["c4_65536_envs_x4_ships_10_beams"] = side_config(dev, 65536, 10, 4, 200, 200)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
-                # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 32 worlds per env)
-                other["c3_fresh_world_per_episode"] = side_config(dev, 65536, 8, 1, 310, 62, map_mode="fresh_device")
+                # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 48 worlds per env: launches
+                # of up to 47 fused steps between refills)
+                other["c3_fresh_world_per_episode"] = side_config(dev, 65536, 8, 1, 470, 94, map_mode="fresh_device", ring=48)
+                other["c3_fresh_world_per_episode"]["ring"] = 48
                 # the headline workload with every step overwriting the same [N, ...] rows (ssg_rollout): outputs stay in cache
                 vec.reset_tensor()
                 ao = vec.random_actions(999, 0, 600)

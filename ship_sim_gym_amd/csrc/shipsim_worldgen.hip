@@ -163,6 +163,10 @@ __device__ __forceinline__ bool segment_query_x(const HullR &h, double ax, doubl
     double alpha = 1.0;
     bool hit = false;
     outx = bx;
+    // The fat segment cannot touch a hull whose box it does not reach (every hit of cpShapeSegmentQuery is a real crossing of
+    // an edge offset by r2, or a pass within r2 of a vertex): the left-going ray against the right bank, the right-going one
+    // against the left bank — half of the goal path's queries — end here, with the same "no hit" the full query would report.
+    if (fmax(ax, bx) + r2 < h.l || fmin(ax, bx) - r2 > h.r || fmax(ay, by) + r2 < h.b || fmin(ay, by) - r2 > h.t) return false;
     // (the start point's distance to the hull is at least its distance to the hull's box: beyond r2 of the box the point
     // query — a division and a square root per edge — cannot report a hit at alpha 0)
     const double bx_ = fmax(fmax(h.l - ax, ax - h.r), 0.0), by_ = fmax(fmax(h.b - ay, ay - h.t), 0.0);
