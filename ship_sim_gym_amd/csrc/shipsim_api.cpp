@@ -610,6 +610,10 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch
     h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
              ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) <= 160u * 1024u;
+    if (!h->lds) { // gathered bank: the record heads live in LDS columns beside the lidar buffers — they must fit too
+        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, false, n_maps) > 160u * 1024u) h->block /= 2;
+        if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64;
+    }
     h->lds_bytes = ssg::step_lds_bytes(h->cfg.n_beams, h->block, h->lds, n_maps);
     h->prepared = false;
     refresh_dev(h);

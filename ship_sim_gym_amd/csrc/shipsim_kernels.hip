@@ -150,19 +150,16 @@ __device__ __forceinline__ double goal_at(const DevCfg &c, int goff, int g, int 
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
 template <bool LDS_BANK, bool DYN>
 __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned gm, double x, double y, double &gx,
-                                             double &gy)
+                                             double &gy, const double *hG = nullptr /* gathered bank: this env's goal columns in LDS */, int ld = 0)
 {
     gx = -1.0;
     gy = -1.0;
     double best = INFINITY;
-    if constexpr (!LDS_BANK && !DYN) { // gathered record: all goal centres in one round trip, not one per goal
-        double gxy[2 * SSG_MAX_GOALS];
-#pragma unroll
-        for (int g = 0; g < SSG_MAX_GOALS; ++g) { const double2 v = bank_at2<LDS_BANK>(c, goff + 2 * g); gxy[2 * g] = v.x; gxy[2 * g + 1] = v.y; }
+    if constexpr (!LDS_BANK && !DYN) { // gathered record: the goal centres are in this env's LDS columns
 #pragma unroll
         for (int g = 0; g < SSG_MAX_GOALS; ++g) {
             if (g >= c.n_goals) break;
-            const double px = gxy[2 * g], py = gxy[2 * g + 1];
+            const double px = hG[(2 * g) * ld], py = hG[(2 * g + 1) * ld];
             const double dx = px - x, dy = py - y;
             const double d = dx * dx + dy * dy;
             const bool take = ((gm >> g) & 1u) & (d < best);
@@ -246,6 +243,18 @@ __host__ __device__ __forceinline__ constexpr int lds_tile_bytes(int nb)
     return 2 * lds_res_bytes(nb) + 2 * lds_queue_bytes(nb_lo(nb));
 }
 
+// Gathered banks (LDS_BANK = false: per-env records of the `fresh` / `fresh_device` modes, banks too large for the LDS): a
+// divergent gather costs the CU's address path one request per LANE (~1 per cycle), and four roles re-gathering the head of
+// their env's record every step (hull counts + boxes, goal centres: 30 of a tile-step's ~80 gathers, all 64 lanes each) was
+// more than half of that.  The head of the record is therefore kept in per-lane LDS columns and re-fetched only by the lanes
+// whose env has just moved to its next record (a reset): [2 lidar roles][10][EPW] = record doubles 0..9 (counts, boxes), one
+// copy per lidar role because each follows its tile's resets on its own; [12][EPW] = doubles 10..21 (goal centres), written by
+// the body role, read by it and by the observer.
+constexpr int kHdrLidar = 10, kHdrGoals = 2 * SSG_MAX_GOALS;
+static_assert(SSG_MAP_OFF_COUNTS == 0 && SSG_MAP_OFF_AABB == 2 && SSG_MAP_OFF_GOALS == kHdrLidar && SSG_MAP_OFF_SPAWN_GOAL == kHdrLidar + kHdrGoals,
+              "the record's head: counts, boxes, goals, spawn goal");
+__host__ __device__ __forceinline__ constexpr int lds_hdr_bytes(int epw, bool lds_bank) { return lds_bank ? 0 : (2 * kHdrLidar + kHdrGoals) * epw * 8; }
+
 constexpr unsigned long long kLidarMiss = ~0ull; // result key of a beam no hull reported a hit for
 
 // ---------------------------------------------------------------------------------------------------------
@@ -275,7 +284,8 @@ template <bool LDS_BANK, bool EXACT>
 __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, const unsigned short *queue,
                                            unsigned long long *res /* [this role's first beam][64] */, const double *beamtab,
                                            const double cx, const double cy, const double ca, const double sa,
-                                           const int rec_off, const int lane)
+                                           const int rec_off, const int lane, const double *hLt = nullptr /* gathered bank: the
+                                           tile's count columns of this role's header copy: [s * ld + lane of the tile] */, const int ld = 0)
 {
     for (int base = 0; base < n_items; base += 64) {
         const int idx = base + lane;
@@ -286,7 +296,9 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         const int woff = __shfl(rec_off, src);
         double ex, ey;
         beam_end(wcx, wcy, wca, wsa, beamtab[bi], beamtab[SSG_MAX_BEAMS + bi], c.lidar_dist, ex, ey);
-        const int cnt = (int)bank_at<LDS_BANK>(c, woff + SSG_MAP_OFF_COUNTS + s);
+        int cnt;
+        if constexpr (LDS_BANK) cnt = (int)bank_at<LDS_BANK>(c, woff + SSG_MAP_OFF_COUNTS + s);
+        else cnt = (int)hLt[s * ld + src];
         const int pb = woff + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES);
         bool outside = false; // cpPolyShapePointQuery(a): some plane has a strictly in front
         bool out_sure = false, maybe = false;
@@ -474,7 +486,8 @@ template <int NB, bool LDS_BANK, bool EXACT>
 __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long *res, unsigned short *queue,
                                             const double *beamtab, const int b_first, const int b_count, const double cx,
                                             const double cy, const double ca, const double sa, const int rec_off,
-                                            const bool live, const int lane)
+                                            const bool live, const int lane, const double *hL = nullptr /* gathered bank: this env's
+                                            column of the role's header copy */, const int ld = 0)
 {
     constexpr int NB0 = nb_lo(NB);
     constexpr int kTrash = 2 * NB0 * 64; // 64 u16 past the queue swallow the writes of culled pairs
@@ -484,8 +497,14 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
     double al[2], ab[2], ar[2], at[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const double2 lb = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
-        const double2 rt = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+        double2 lb, rt;
+        if constexpr (LDS_BANK) {
+            lb = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+            rt = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+        } else {
+            lb.x = hL[(SSG_MAP_OFF_AABB + 4 * s + 0) * ld]; lb.y = hL[(SSG_MAP_OFF_AABB + 4 * s + 1) * ld];
+            rt.x = hL[(SSG_MAP_OFF_AABB + 4 * s + 2) * ld]; rt.y = hL[(SSG_MAP_OFF_AABB + 4 * s + 3) * ld];
+        }
         al[s] = lb.x - eps;
         ab[s] = lb.y - eps;
         ar[s] = rt.x + eps;
@@ -517,7 +536,8 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
         }
     }
     if (!SSG_ABL(3))
-        lidar_pass<LDS_BANK, EXACT>(c, n_items, queue, res + b_first * 64, beamtab + b_first, cx, cy, ca, sa, rec_off, lane);
+        lidar_pass<LDS_BANK, EXACT>(c, n_items, queue, res + b_first * 64, beamtab + b_first, cx, cy, ca, sa, rec_off, lane,
+                                    hL ? hL - lane : nullptr, ld);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -627,7 +647,9 @@ __device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *co
 template <bool LDS_BANK>
 __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *shiptab, const double x, const double y,
                                                  const double ca, const double sa, const int rec_off, const bool live,
-                                                 const int lane, const int only /* wave-uniform: hull 0 or 1, or -1 = both */)
+                                                 const int lane, const int only /* wave-uniform: hull 0 or 1, or -1 = both */,
+                                                 const double *hL = nullptr /* gathered bank: this env's column of the role's header copy */,
+                                                 const int ld = 0)
 {
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative stage: lane L = 5*q + i
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
@@ -639,12 +661,20 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
     int cnts = 0; // plane counts of both hulls, packed, so the served lane's counts travel by readlane
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const double2 lb = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
-        const double2 rt = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
-        const double al = lb.x, ab = lb.y, ar = rt.x, at = rt.y;
+        double al, ab, ar, at, cn;
+        if constexpr (LDS_BANK) {
+            const double2 lb = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 0);
+            const double2 rt = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_AABB + 4 * s + 2);
+            al = lb.x; ab = lb.y; ar = rt.x; at = rt.y;
+            cn = bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s);
+        } else {
+            al = hL[(SSG_MAP_OFF_AABB + 4 * s + 0) * ld]; ab = hL[(SSG_MAP_OFF_AABB + 4 * s + 1) * ld];
+            ar = hL[(SSG_MAP_OFF_AABB + 4 * s + 2) * ld]; at = hL[(SSG_MAP_OFF_AABB + 4 * s + 3) * ld];
+            cn = hL[(SSG_MAP_OFF_COUNTS + s) * ld];
+        }
         const bool near = live & !SSG_ABL(4) & ((only < 0) | (only == s)) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
         nearbits |= near ? (1u << s) : 0u;
-        cnts |= ((int)bank_at<LDS_BANK>(c, rec_off + SSG_MAP_OFF_COUNTS + s)) << (8 * s);
+        cnts |= ((int)cn) << (8 * s);
     }
     // Stage 1, per lane, all near lanes at once: is some BANK plane a separating axis (all five ship vertices
     // strictly in front)?  That settles almost every ship that is merely close to a bank; the loop ends as soon
@@ -813,6 +843,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *goal_scratch0 = reinterpret_cast<char *>(sync_bar + 2 * (EPW / 64));
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
     char *tile_base = scratch0 + (tl >> 6) * lds_tile_bytes(NB); // this env tile's lidar buffers
+    // gathered bank: the record heads in LDS (see lds_hdr_bytes); hL = this env's column of the lidar role's copy, hG = of the goals
+    double *hdr0 = reinterpret_cast<double *>(scratch0 + (EPW / 64) * lds_tile_bytes(NB));
+    double *hL = LDS_BANK ? nullptr : hdr0 + (role & 1) * (kHdrLidar * EPW) + tl;
+    double *hG = LDS_BANK ? nullptr : hdr0 + 2 * kHdrLidar * EPW + tl;
+    auto load_hdr_lidar = [&](int rec_off) { // record doubles 0..9 -> this role's copy (five 16-byte gathers)
+#pragma unroll
+        for (int f = 0; f < kHdrLidar / 2; ++f) { const double2 v = bank_at2<LDS_BANK>(c, rec_off + 2 * f); hL[(2 * f) * EPW] = v.x; hL[(2 * f + 1) * EPW] = v.y; }
+    };
+    auto load_hdr_goals = [&](int rec_off) { // record doubles 10..21 -> the goal columns (six 16-byte gathers)
+#pragma unroll
+        for (int f = 0; f < kHdrGoals / 2; ++f) { const double2 v = bank_at2<LDS_BANK>(c, rec_off + SSG_MAP_OFF_GOALS + 2 * f); hG[(2 * f) * EPW] = v.x; hG[(2 * f + 1) * EPW] = v.y; }
+    };
 
 #ifdef SSG_STAMPS
     unsigned long long stamp_[16] = {};
@@ -880,6 +922,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         {
             const double x = colX[el_], y = colY[el_], ang = colA[el_];
             map_id = colMap[el_];
+            if constexpr (!LDS_BANK) load_hdr_lidar(map_id * SSG_MAP_STRIDE);
             { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; } // body->transform rotation
             if (role == 0) { pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa; } // -> role 3: the first step's thrust direction
             if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
@@ -892,7 +935,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         }
         // the first step's query needs nothing from role 3: it runs while role 3 integrates
         lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first, b_count,
-                                         cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
+                                         cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
         for (int k = 0; k < K; ++k) {
             wait_pose(k); // role 3 has published this step's post-step pose
             SSG_STAMP_K(0);
@@ -904,7 +947,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // collide_ship of this step, one bank hull per lidar role (role 2 is writing the previous step's rows; in a launch's
             // first step the lidar waves have just finished the first query and would idle until B)
             reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
-                    bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role) ? 1 : 0;
+                    bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
             SSG_STAMP_K(3);
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
@@ -914,8 +957,11 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
                 map_id = rs ? next_map(c, nmap) : nmap;
+                if constexpr (!LDS_BANK) {
+                    if (rs) load_hdr_lidar(map_id * SSG_MAP_STRIDE); // only the lanes whose env moved to its next record gather
+                }
                 lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base + ((k + 1) & 1) * lds_res_bytes(NB)),
-                                                 queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane);
+                                                 queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
             }
             SSG_STAMP_K(2);
         }
@@ -971,7 +1017,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             __syncthreads(); // barrier 0
             SSG_STAMP(9);
             if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
-                nearest_goal<LDS_BANK, false>(c, map0_ * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0_, pv[0], pv[1], pv[4], pv[5]);
+                nearest_goal<LDS_BANK, false>(c, map0_ * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0_, pv[0], pv[1], pv[4], pv[5], hG, EPW);
         }
         const bool hist2 = c.history >= 2;
         ObsTile<NB> ot;
@@ -1023,15 +1069,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(4);
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
             double nf_gx = 0, nf_gy = 0;
-            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy);
+            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
             SSG_STAMP_K(5);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
             asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
             char *res_k = scratch0 + tile_w * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB);
             const int map_new = do_reset ? next_map(c, map_id) : map_id;
-            const double rs_gx = bank_at<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
-            const double rs_gy = bank_at<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL + 1);
+            double rs_gx = 0.0, rs_gy = 0.0; // the reset frame's goal: only a reset env's lanes fetch it when the bank is gathered
+            if (LDS_BANK || do_reset) {
+                const double2 sg = bank_at2<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
+                rs_gx = sg.x; rs_gy = sg.y;
+            }
             double nv[F];
             nv[0] = do_reset ? c.spawn_x : x;
             nv[1] = do_reset ? c.spawn_y : y;
@@ -1102,6 +1151,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         steps = colStep[el];
         episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
     }
+    if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // (gathered bank: this env's goal centres -> LDS, before barrier 0)
     int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
     // (the state is wanted in registers BEFORE barrier 0, under the bank's staging: left to itself the compiler sinks the
     // loads below the barrier and the first step starts a memory round trip late)
@@ -1215,13 +1265,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (near) gq[pos] = (unsigned short)(lane | (g << 6));
             n_pairs += __popcll(m);
         };
-        if constexpr (!LDS_BANK && !DYN) { // gathered record: all goal centres in one round trip, not one per goal
-            double gxy[2 * SSG_MAX_GOALS];
-#pragma unroll
-            for (int g = 0; g < SSG_MAX_GOALS; ++g) { const double2 v = bank_at2<LDS_BANK>(c, goff + 2 * g); gxy[2 * g] = v.x; gxy[2 * g + 1] = v.y; }
+        if constexpr (!LDS_BANK && !DYN) { // gathered record: the goal centres are in this env's LDS columns
 #pragma unroll
             for (int g = 0; g < SSG_MAX_GOALS; ++g)
-                if (g < c.n_goals) near_test(g, gxy[2 * g], gxy[2 * g + 1]);
+                if (g < c.n_goals) near_test(g, hG[(2 * g) * EPW], hG[(2 * g + 1) * EPW]);
         } else {
             for (int g = 0; g < c.n_goals; ++g) near_test(g, goal_at<LDS_BANK, DYN>(c, goff, g, 0), goal_at<LDS_BANK, DYN>(c, goff, g, 1));
         }
@@ -1232,8 +1279,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const int src = code & 63, g = code >> 6;
             const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
             const int boff = __shfl(goff, src);
-            const double gx = goal_at<LDS_BANK, DYN>(c, boff, g, 0);
-            const double gy = goal_at<LDS_BANK, DYN>(c, boff, g, 1);
+            double gx, gy;
+            if constexpr (!LDS_BANK && !DYN) { gx = hG[(2 * g) * EPW - lane + src]; gy = hG[(2 * g + 1) * EPW - lane + src]; } // env `src` of this tile
+            else { gx = goal_at<LDS_BANK, DYN>(c, boff, g, 0); gy = goal_at<LDS_BANK, DYN>(c, boff, g, 1); }
             // lane = (pair p, ship edge i from vertex i-1 to vertex i)
             const double v1x = bca * w_hx + (-bsa) * w_hy + bx, v1y = bsa * w_hx + bca * w_hy + by;
             const double v0x = bca * w_px + (-bsa) * w_py + bx, v0y = bsa * w_px + bca * w_py + by;
@@ -1306,6 +1354,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     if (do_reset) { // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
         map_id = next_map(c, map_id);
         episodes += 1;
+        if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // the new world's goal centres (only these lanes gather)
     }
     if constexpr (DYN) {
         if (live) {
@@ -1610,6 +1659,7 @@ size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
     b += (size_t)lds_fixed_bytes(epw);
     b += (size_t)(epw / 64) * (size_t)lds_tile_bytes(n_beams);
+    b += (size_t)lds_hdr_bytes(epw, lds_bank);
     return b;
 }
 
