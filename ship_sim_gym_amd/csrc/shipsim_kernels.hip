@@ -308,18 +308,20 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         double bd = -1.0, bden = 1.0;
         int bj = 0;
         constexpr int kPlaneChunk = PlaneChunk<LDS_BANK>::n;
-        // (the record is gathered: the plane count is requested WITH the first chunk — the chunk's addresses do not depend on it —
-        // and the loop condition below is evaluated after both are in flight)
-        for (int j0 = 0; (j0 == 0 && !LDS_BANK) || __any(act & (j0 < cnt)); j0 += kPlaneChunk) {
+        for (int j0 = 0; __any(act & (j0 < cnt)); j0 += kPlaneChunk) {
             double pv0x[kPlaneChunk], pv0y[kPlaneChunk], pnx[kPlaneChunk], pny[kPlaneChunk], pv0n[kPlaneChunk];
             double pdtmin[kPlaneChunk], pdtmax[kPlaneChunk];
 #pragma unroll
             for (int u = 0; u < kPlaneChunk; ++u) { // all LDS reads of the chunk first: one latency per chunk
                 const int j = j0 + u;
                 const int q = pb + SSG_PLANE_DOUBLES * ((j < SSG_MAX_HULL) ? j : 0); // independent of cnt: no LDS round trip in between
-                if (EXACT) { const double2 vv = bank_at2<LDS_BANK>(c, q + 0); pv0x[u] = vv.x; pv0y[u] = vv.y; }
-                { const double2 nn = bank_at2<LDS_BANK>(c, q + 2); pnx[u] = nn.x; pny[u] = nn.y; }
-                pv0n[u] = bank_at<LDS_BANK>(c, q + 4);
+                // (gathered record: only the lanes that have a plane j request it — a gather costs per active lane, and the count
+                // comes from LDS, so nothing is gained by fetching past the hull's last plane)
+                const bool want = LDS_BANK || (act & (j < cnt));
+                pv0x[u] = pv0y[u] = pnx[u] = pny[u] = pv0n[u] = 0.0;
+                if (EXACT && want) { const double2 vv = bank_at2<LDS_BANK>(c, q + 0); pv0x[u] = vv.x; pv0y[u] = vv.y; }
+                if (want) { const double2 nn = bank_at2<LDS_BANK>(c, q + 2); pnx[u] = nn.x; pny[u] = nn.y; }
+                if (want) pv0n[u] = bank_at<LDS_BANK>(c, q + 4);
                 if (EXACT) {
                     // the edge's extent along the plane: cpvcross(n, v[j-1]) .. cpvcross(n, v[j]); v[j-1] is the
                     // previous plane's v0 (the last plane's for j = 0)
