@@ -904,14 +904,19 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         // Both banks' planes go to this lane's LDS columns up front, requested together with the body row: staged on demand
         // (one bank at a time, again whenever the pair loops switched side) the 48 gathers from the map record were an exposed
         // L2 round trip in front of every narrowphase query.
+        // (16-byte loads: a divergent gather costs the address path one request per lane whatever its width; records are
+        // 8-byte aligned, gfx950 serves the unaligned dwordx4)
+        typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
         double tmp[2 * kBankDoubles];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < SSG_MAX_HULL; ++j)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) // all 12 slots exist in the record
-                    tmp[s * kBankDoubles + 4 * j + f] = rec[SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
+                for (int f = 0; f < 4; f += 2) { // all 12 slots exist in the record
+                    const double2_a8 v = *reinterpret_cast<const double2_a8 *>(rec + SSG_MAP_OFF_PLANES + s * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f);
+                    tmp[s * kBankDoubles + 4 * j + f] = v.x; tmp[s * kBankDoubles + 4 * j + f + 1] = v.y;
+                }
 #pragma unroll
         for (int q = 0; q < 2 * kBankDoubles; ++q) lds[bbase + q * kGrp] = tmp[q];
     }
