@@ -352,7 +352,18 @@ void refresh_dev(ssg_handle *h)
     d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
     d.dyn_segcnt = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_segcnt) : nullptr;
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) d.dyn_reach2[k] = h->dyn.reach2[k];
+    {   // the step kernel's reach test: (hull radius of traffic ship k, with a margin)^2 and the player's own hull radius
+        auto radius = [](const double *hull) {
+            double r2 = 0.0;
+            for (int i = 0; i < SSG_SHIP_VERTS; ++i) r2 = std::max(r2, hull[2 * i] * hull[2 * i] + hull[2 * i + 1] * hull[2 * i + 1]);
+            return std::sqrt(r2);
+        };
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+            const double r = radius(h->dyn.thull[k]) * 1.001 + 1.0;
+            d.dyn_reach2[k] = r * r;
+        }
+        d.dyn_hull_r = radius(c.ship_hull) * 1.001;
+    }
     h->dyn_queue_valid = false; // (anything that refreshes the kernel arguments may have changed what the queue was built from)
 }
 

@@ -17,12 +17,16 @@
 //    gathers of the solver are conflict-free.  (A first version kept them in per-lane arrays: 8.7 KB of scratch per
 //    lane, 1 GB of HBM traffic per step, 420 us.)
 //  * Shapes are never materialised: a ship's world vertices are its pose applied on the fly to the hull constants
-//    (staged once per workgroup in LDS, broadcast reads), a bank's planes are read from the map
-//    record in L2.  Only EPA's growing hull sits in scratch, and only the few entries it touches.
+//    (staged once per workgroup in LDS, broadcast reads); both banks' planes are staged into the lane's LDS columns with
+//    the body loads.  EPA's growing hull has seven LDS entries per lane, scratch beyond (practically never).
 //  * Arbiter records (accumulated impulses, contact hashes, state, age) persist in struct-of-arrays columns but are
 //    read or written only for pairs whose bit is set in the env's 64-bit live mask.
-// Per step this kernel runs BEFORE the step kernel, which then reads this step's goal positions and the
-// traffic-contact bit from the dyn columns (DevCfg::dyn_*).
+//  * Which envs are stepped: the ones the step kernel's body role queued at the end of the previous step (segmented queue,
+//    DevCfg::dyn_queue), sorted by (steps since the reset, bank record) so that the lanes of a wave walk the same path
+//    (dyn_sort_kernel), read through a row-major shadow of the body columns (DevCfg::dyn_row).  Envs whose space is at a
+//    fixed point of cpSpaceStep (the rest bit) are not stepped at all.
+// Per step: dyn_sort_kernel, dyn_step_kernel, then the step kernel, which reads this step's goal positions and the
+// traffic-contact bit from the dyn columns (DevCfg::dyn_*) and queues the envs for the next step.
 //
 // The canonical pair order, the cold GJK start and the unsolved player arbiters are the named assumptions of the
 // oracle (oracle/ssg_dynamics.c header); this file follows the same ones.
@@ -572,7 +576,7 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Pass 1, every env.  cpSpaceStep is a deterministic function of the bodies' cpBody fields, the cached arbiters and
+// The rest bit.  cpSpaceStep is a deterministic function of the bodies' cpBody fields, the cached arbiters and
 // the static banks (the player never pushes anything: PLAYER assumption).  When a full step wrote back exactly the
 // bits it had read -- every body field, every arbiter's state / age / contact hashes / accumulated impulses, the live
 // mask -- the space is at a fixed point: the next step is the identity.  (That is how a ship resting against a bank
@@ -580,7 +584,7 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
 // position.)  The full step records that as the rest bit (with the bank generation it holds for); while it stands,
 // these bodies are skipped and only the player's collide_ship test against the parked traffic is left.  A caller
 // that writes the body columns itself must clear the bit with ssg_dyn_invalidate.
-// Everything else is appended to the queue of pass 2.  In steady state that is the few steps after each reset in
+// Everything else is appended to the queue of the full step.  In steady state that is the few steps after each reset in
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kClassifyThreads = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Pass 1b: counting sort of the queue by bucket.  Every workgroup scans the 512 bucket counters itself (2 KB from L2) and
+// dyn_sort_kernel: counting sort of the queue by bucket, and collide_ship's exact test for the "SAT only" entries.  Every workgroup scans the 512 bucket counters itself (2 KB from L2) and
 // scatters its 256 queue entries to base[bucket] + arrival number.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const DynCfg d)
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Pass 2: the full cpSpaceStep of the queued envs, one lane per env, one wave per workgroup.
+// dyn_step_kernel: the full cpSpaceStep of the queued envs, one lane per env, one wave per workgroup.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
@@ -1400,7 +1404,8 @@ hipError_t prepare_dyn(const DevCfg &c)
 
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream)
 {
-    // pass 1 over every env, then pass 2 over the queue it built (grid sized for the worst case; workgroups past the
+    // (the classify pass over every env only when the host touched the envs,) the sort, then the full step over the sorted
+    // queue (grid sized for the worst case; workgroups past the
     // queue's end leave at once).  The step kernel that follows empties the queue counter.
     static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;

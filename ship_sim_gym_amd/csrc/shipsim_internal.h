@@ -95,7 +95,8 @@ struct DevCfg {
     unsigned *dyn_segcnt;         // [n_pad / 64] entries per segment; every producer writes every segment's count
     unsigned *dyn_count;          // [0] length of dyn_sorted (dyn_sort_kernel adds, the step kernel zeroes); [kDynBucket0 ..) bucket counts
     unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
-    double dyn_reach2[SSG_N_TRAFFIC]; // = DynCfg::reach2, for the step kernel's classification of resting envs
+    double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2, for the step kernel's classification of resting envs
+    double dyn_hull_r;                // the player's hull radius about its body position
     int32_t *dyn_sorted;          // the queue ordered by bucket (dyn_sort_kernel): what the full dyn step walks
     double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
 };

@@ -1389,11 +1389,17 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             }
             bool reach = false;
             if (resting) {
-                const double ppx = x + vx * c.dt, ppy = y + vy * c.dt;
+                // Can the player's hull touch a parked ship after its next cpBodyUpdatePosition?  Every hull vertex moves by at
+                // most |v dt| + (hull radius) |w dt| per axis, so the next hull lies inside this step's world box widened by that;
+                // a parked ship's hull lies inside the circle of its hull radius about its body position.  (A conservative
+                // pre-reject of cpBBIntersects: the exact test decides; tighter than the two hull-radius circles, which put a
+                // quarter of all envs "in reach" of the ship parked in mid-river.)
+                const double wr = c.dyn_hull_r * fabs(w * c.dt);
+                const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr;
 #pragma unroll
                 for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
                     const double tx = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk) * np + el_], ty = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk + 1) * np + el_];
-                    const double dx = tx - ppx, dy = ty - ppy;
+                    const double dx = dmax(dmax((sbl - mx) - tx, tx - (sbr + mx)), 0.0), dy = dmax(dmax((sbb - my) - ty, ty - (sbt + my)), 0.0);
                     reach |= (dx * dx + dy * dy) <= c.dyn_reach2[kk];
                 }
             }
