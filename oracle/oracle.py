@@ -91,6 +91,9 @@ def lib():
         L.ora_body_apply_force_at_local_point.argtypes = [C.POINTER(Body), V2, V2]
         L.ora_circle_segment_query.restype = C.c_int
         L.ora_circle_segment_query.argtypes = [V2, C.c_double, V2, V2, C.c_double, C.POINTER(SegInfo)]
+        L.ora_world_set_ship.argtypes = [C.c_void_p, C.POINTER(Body)]
+        L.ora_world_get_ship.argtypes = [C.c_void_p, C.POINTER(Body)]
+        L.ora_world_space_step.argtypes = [C.c_void_p]
         L.ora_polys_collide.restype = C.c_int
         L.ora_polys_collide.argtypes = [C.POINTER(Poly), C.POINTER(Poly)]
         L.ora_circle_poly_collide.restype = C.c_int

@@ -579,6 +579,20 @@ void ora_world_step(ora_world *w, int action, double *obs_out, double *reward, u
     if (done) *done = (uint8_t)d;
 }
 
+/* ---- hooks for tests/golden/shims/pymunk when the reference's game holds traffic ships (config 4): the stand-in keeps a
+ * shadow world, hands it the player's cpBody before each space.step and takes everything back afterwards, so that the
+ * reference's own Python runs on the oracle's full cpSpaceStep (contact solver included) ---- */
+void ora_world_set_ship(ora_world *w, const ora_body *b) { w->ship = *b; }
+void ora_world_get_ship(const ora_world *w, ora_body *b) { *b = w->ship; }
+/* ShipGame.update's `self.space.step(dt)` alone: cpSpaceStep with the begin-callbacks' effects (colliding, goal_reached, the
+ * goal list), without the action, the lidar and the ShipEnv bookkeeping around it */
+void ora_world_space_step(ora_world *w)
+{
+    w->colliding = 0;
+    w->goal_reached = 0;
+    space_step(w);
+}
+
 void ora_world_peek(const ora_world *w, double *o)
 {
     int mask = 0;

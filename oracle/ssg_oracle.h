@@ -166,6 +166,11 @@ void ora_body_update_velocity(ora_body *b, double damping, double dt);
 void ora_body_apply_force_at_local_point(ora_body *b, ora_v2 force, ora_v2 point);
 int ora_circle_segment_query(ora_v2 center, double r1, ora_v2 a, ora_v2 b, double r2, ora_seg_info *info);
 
+/* hooks of the traffic-capable pymunk stand-in (tests/golden/shims): shadow world in, cpSpaceStep, everything back out */
+void ora_world_set_ship(ora_world *w, const ora_body *b);
+void ora_world_get_ship(const ora_world *w, ora_body *b);
+void ora_world_space_step(ora_world *w);
+
 /* ---- world ---- */
 void ora_default_config(ora_config *cfg);
 void ora_world_init(ora_world *w, const ora_config *cfg);

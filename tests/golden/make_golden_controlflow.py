@@ -10,7 +10,8 @@ gen_goal_path incl. its RNG call order and `except` fallback / handle_discrete_a
 collision callbacks (game.py:140-153,185-195,232-349), LiDAR.query and Ship (models.py:39-76,87-146).  What they do
 NOT pin: Chipmunk2D's arithmetic, which under the stand-in is the oracle's own restatement ("parity unpinned").
 
-Scenarios: the eight of tools/capture_pymunk_golden.py x seeds 0..3 (random.seed(s); np.random.seed(s)), no traffic.
+Scenarios: the eight of tools/capture_pymunk_golden.py x seeds 0..3 (random.seed(s); np.random.seed(s)) without traffic,
+and six of them x seeds 0..1 with `env.game.add_default_traffic()` after every reset (BASELINE configs[3]).
 Per stream: the worlds the reference generated (river polygons handed to PolyEnv, goal centres), the reset observation
 of every episode, and (obs, reward, done) of every step; a done step is followed by env.reset() as a trainer would.
 """
@@ -40,7 +41,7 @@ def scenarios():
     yield "training_config", dict(speed=30, bounds=(1000, 1000)), fwd + [1, 0, 0, 2, 0, 0] * 10
 
 
-def run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed):
+def run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed, traffic=False):
     class G(GameConfig):
         DEBUG = False
         FPS = 100000
@@ -59,6 +60,8 @@ def run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed):
 
     def do_reset():
         o = env.reset()
+        if traffic:  # config 4: the reference expects its caller to add the traffic after every reset (game.py:279-286)
+            env.game.add_default_traffic()
         out["reset_obs"].append(np.asarray(o, dtype=np.float64))
         out["episode_start"].append(len(out["obs"]))
         out["polys"].append(np.asarray(env.game.level.poly_list, dtype=np.float64))  # the raw 12-gons handed to PolyEnv
@@ -98,6 +101,17 @@ def main():
             r = run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed)
             for k, v in r.items():
                 data["%s/seed%d/%s" % (name, seed, k)] = v
+            n_steps += len(actions)
+            n_done += int(r["done"].sum())
+    # config 4: the same Python with env.game.add_default_traffic() after every reset; the stand-in's Space.step then runs the
+    # oracle's full cpSpaceStep (contact solver for the traffic ships and goal bodies) on a shadow world
+    for name, opts, actions in scenarios():
+        if name in ("rudder_only_max_steps", "training_config"):
+            continue
+        for seed in range(2):
+            r = run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed, traffic=True)
+            for k, v in r.items():
+                data["%s_traffic/seed%d/%s" % (name, seed, k)] = v
             n_steps += len(actions)
             n_done += int(r["done"].sum())
     out = os.path.join(HERE, "ref_controlflow.npz")

@@ -7,7 +7,10 @@ Semantics stated from memory of pymunk 5.4.0 / Chipmunk 7.0.x (SURVEY.md App. A;
     callbacks on first touch, cpBodyUpdateVelocity (damping^dt), forces cleared;
   * a `begin` callback returning False suppresses the pair's response; space.remove inside a callback is deferred;
   * the PLAYER assumption of the oracle: contact response of the player is not simulated (every such contact ends
-    the episode).  Traffic ships (add_default_traffic) are NOT supported by this stand-in.
+    the episode).
+  * with traffic ships in the space (ShipGame.add_default_traffic, config 4) Space.step hands the whole scene to a shadow
+    oracle world — the reference's Python still drives everything (actions, lidar, reward, observation, resets, the
+    callbacks), the oracle's restated cpSpaceStep incl. its contact solver moves the traffic ships and goal bodies.
 """
 import ctypes as C
 import math
@@ -166,6 +169,7 @@ class Poly(Shape):
         Shape.__init__(self, body)
         self._p = _O.Poly()
         v = [(float(x), float(y)) for x, y in vertices]
+        self._verts = v
         import numpy as np
         a = np.ascontiguousarray(v, dtype=np.float64)
         _O.lib().ora_poly_init(C.byref(self._p), len(v), a.ctypes.data_as(C.POINTER(C.c_double)))  # hulls its input
@@ -287,7 +291,7 @@ class Space(object):
     def step(self, dt):
         L = _O.lib()
         if any(isinstance(s, Poly) and s.collision_type == 1 and s.body.body_type == Body.DYNAMIC for s in self.shapes):
-            raise NotImplementedError("traffic ships (add_default_traffic) need the contact solver: not in this stand-in")
+            return self._step_with_traffic(dt)
         for b in self.bodies:            # cpBodyUpdatePosition
             L.ora_body_update_position(C.byref(b._b), float(dt))
         for s in self.shapes:            # cpShapeUpdateFunc (static shapes keep their cache)
@@ -319,3 +323,54 @@ class Space(object):
 
     def debug_draw(self, options):
         pass
+
+    # ---- config 4: traffic ships in the space -> the oracle's full cpSpaceStep on a shadow world ----
+    def _build_shadow(self, dt):
+        import numpy as np
+        banks = [s for s in self.shapes if isinstance(s, Poly) and s.body.body_type == Body.STATIC]
+        goals = [s for s in self.shapes if isinstance(s, Circle)]
+        player = [s for s in self.shapes if isinstance(s, Poly) and s.collision_type == 0]
+        traffic = [s for s in self.shapes if isinstance(s, Poly) and s.collision_type == 1 and s.body.body_type == Body.DYNAMIC]
+        assert len(banks) == 2 and len(player) == 1 and len(traffic) == 3 and all(len(b._verts) == 12 for b in banks)
+        cfg = _O.default_config(dt=float(dt), space_damping=float(self.damping), n_goals=len(goals), goal_radius=goals[0].radius,
+                                n_traffic=3)
+        w = _O.World(cfg)
+        w.reset(np.asarray(banks[0]._verts), np.asarray(banks[1]._verts), np.asarray([[g.body._b.p.x, g.body._b.p.y] for g in goals]))
+        dyn = w.peek_dyn()
+        for k, t in enumerate(traffic):  # the oracle's add_default_traffic must be the reference's (game.py:279-286)
+            assert (t.body._b.p.x, t.body._b.p.y) == (dyn["traffic"][k, 0], dyn["traffic"][k, 1]), "traffic ship %d" % k
+            assert abs(1.0 / t.body._b.i_inv - t.body.moment) < 1e-9
+        self._shadow = (w, banks, goals, player[0], traffic, (1 << len(goals)) - 1)
+
+    def _step_with_traffic(self, dt):
+        L = _O.lib()
+        if not hasattr(self, "_shadow"):
+            self._build_shadow(dt)
+        w, banks, goals, player, traffic, alive0 = self._shadow
+        L.ora_world_set_ship(w._p, C.byref(player.body._b))
+        L.ora_world_space_step(w._p)
+        L.ora_world_get_ship(w._p, C.byref(player.body._b))
+        player._cache()
+        pk, dyn = w.peek(), w.peek_dyn()
+        for k, t in enumerate(traffic):
+            b = t.body._b
+            b.p, b.a = _O.V2(dyn["traffic"][k, 0], dyn["traffic"][k, 1]), dyn["traffic"][k, 2]
+            b.rot = _O.V2(math.cos(b.a), math.sin(b.a))
+            b.v, b.w = _O.V2(dyn["traffic"][k, 3], dyn["traffic"][k, 4]), dyn["traffic"][k, 5]
+            t._cache()
+        for g, s in enumerate(goals):
+            s.body._b.p = _O.V2(dyn["goals"][g, 0], dyn["goals"][g, 1])
+            s.body._b.v = _O.V2(dyn["goals"][g, 2], dyn["goals"][g, 3])
+        # the begin callbacks, as cpSpaceStep would have fired them
+        self._in_step = True
+        if pk["colliding"] and (0, 1) in self._handlers and self._handlers[(0, 1)].begin is not None:
+            self._handlers[(0, 1)].begin(Arbiter(player, banks[0]), self, None)
+        alive = int(pk["alive_mask"])
+        for g, s in enumerate(goals):
+            if (alive0 >> g) & 1 and not (alive >> g) & 1 and (0, 2) in self._handlers and self._handlers[(0, 2)].begin is not None:
+                self._handlers[(0, 2)].begin(Arbiter(player, s), self, None)
+        self._in_step = False
+        for objs in self._deferred:
+            self.remove(*objs)
+        self._deferred = []
+        self._shadow = (w, banks, goals, player, traffic, alive)

@@ -31,7 +31,8 @@ def _cfg_of(z, name):
 
 def test_fixture_shape_and_coverage():
     z, names = _streams()
-    assert len(names) == 32  # eight scenarios x seeds 0..3
+    assert len(names) == 44  # eight scenarios x seeds 0..3, and six of them x seeds 0..1 with add_default_traffic()
+    assert sum("_traffic/" in n for n in names) == 12
     seen = {"collision": 0, "goal": 0, "max_steps": 0, "oob": 0, "episodes": 0, "steps": 0}
     for n in names:
         done, rew = z[n + "/done"], z[n + "/reward"]
@@ -60,7 +61,8 @@ def test_oracle_world_replays_the_reference_streams(oracle):
     worst = 0.0
     for n in names:
         speed, bounds, max_steps, hist = _cfg_of(z, n)
-        cfg = oracle.default_config(width=float(bounds[0]), height=float(bounds[1]), dt=speed * 0.1, max_steps=max_steps, history=hist)
+        cfg = oracle.default_config(width=float(bounds[0]), height=float(bounds[1]), dt=speed * 0.1, max_steps=max_steps, history=hist,
+                                    n_traffic=3 if "_traffic/" in n else 0)
         w = oracle.World(cfg)
         acts, starts = z[n + "/actions"], list(z[n + "/episode_start"])
         polys, goals, reset_obs = z[n + "/polys"], z[n + "/goals"], z[n + "/reset_obs"]
@@ -122,13 +124,14 @@ def test_hip_ship_env_facade_replays_the_reference_streams(native):
         seed = int(n.rsplit("seed", 1)[1])
         random.seed(seed)
         np.random.seed(seed)
-        env = ShipEnv(G, E)
+        env = ShipEnv(G, E, n_ships=4) if "_traffic/" in n else ShipEnv(G, E)
         acts, starts = z[n + "/actions"], list(z[n + "/episode_start"])
         ep = -1
         for k, a in enumerate(acts):
             if ep + 1 < len(starts) and starts[ep + 1] == k:
                 ep += 1
                 o0 = env.reset()
+                env.game.add_default_traffic() if "_traffic/" in n else None  # (a no-op on the HIP path: n_ships=4 adds it at every reset)
                 np.testing.assert_allclose(o0, z[n + "/reset_obs"][ep], rtol=0, atol=ATOL, err_msg="%s reset %d" % (n, ep))
             o, r, d, _ = env.step(int(a))
             err = float(np.max(np.abs(o - z[n + "/obs"][k])))
