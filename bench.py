@@ -410,13 +410,15 @@ def main():
             # the policy-in-the-loop path: one ssg_step launch per step; median of 7 repeats of `ks` back-to-back steps
             ks = min(max(K, 100), 500)
             a1 = vec.random_actions(777, 0, ks)
+            rows = [a1[k] for k in range(ks)]  # (the row views are made outside the timed loop: it times launches, not slicing)
+            step = vec.step_tensor
             reps = []
             for _ in range(7):
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for k in range(ks):
-                    vec.step_tensor(a1[k])
+                for a in rows:
+                    step(a)
                 e1.record()
                 torch.cuda.synchronize()
                 reps.append(e0.elapsed_time(e1) * 1e3 / ks)

@@ -371,16 +371,23 @@ class ShipVecEnv(*_BASES):
         return p[1:]
 
     def step_tensor(self, actions):
-        """actions: int32 device tensor [N].  Returns (obs, reward, done, flags) device tensors (reused buffers)."""
-        torch = _torch()
-        o, r, d, f = self._out_ptrs()
-        if torch.cuda.current_device() == self._dev_index:  # (the usual case: no device switch around the launch)
-            rc = N.lib().ssg_step(self._h, C.c_void_p(actions.data_ptr()), o, r, d, f, self._stream())
-        else:
-            with torch.cuda.device(self.device):
-                rc = N.lib().ssg_step(self._h, C.c_void_p(actions.data_ptr()), o, r, d, f, self._stream())
+        """actions: int32 device tensor [N].  Returns (obs, reward, done, flags) device tensors (reused buffers).
+        This is the policy-in-the-loop path: one launch per call, so the host side is kept to one ctypes call with plain
+        integers (the cached output pointers, the actions' address, the current stream's handle)."""
+        hot = self.__dict__.get("_hot")
+        if hot is None or hot[0] != (self.obs.data_ptr(), self.reward.data_ptr()):
+            torch = _torch()
+            hot = self._hot = ((self.obs.data_ptr(), self.reward.data_ptr()), N.lib().ssg_step, torch.cuda.current_stream,
+                               self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), self.flags.data_ptr())
+        _, fn, cur_stream, o, r, d, f = hot
+        rc = fn(self._h, actions.data_ptr(), o, r, d, f, cur_stream(self.device).cuda_stream)
         if rc:
-            N.check(rc, self._h, "ssg_step")
+            torch = _torch()
+            if torch.cuda.current_device() != self._dev_index:  # called with another device current: switch and retry
+                with torch.cuda.device(self.device):
+                    rc = fn(self._h, actions.data_ptr(), o, r, d, f, cur_stream(self.device).cuda_stream)
+            if rc:
+                N.check(rc, self._h, "ssg_step")
         return self.obs, self.reward, self.done, self.flags
 
     def rollout_tensor(self, actions_kn, trajectory=False, out=None):
