@@ -365,14 +365,17 @@ def main():
                     bpe = float(tj["hbm_bytes_per_env_step"])
                     hbm_gbps = bpe * env_steps_per_s_kernel / 1e9
                     valu = float(tj["valu_wave_insts_per_env_step"]) * env_steps_per_s_kernel / VALU_ISSUE_PEAK
+                    # LDS pipe: busy cycles per env-step (summed over the CUs) x this run's rate / (256 CUs x 2.4 GHz)
+                    lds = (float(tj["lds_active_cycles_per_env_step"]) * env_steps_per_s_kernel / (256 * 2.4e9)
+                           if "lds_active_cycles_per_env_step" in tj else None)
                     roof_pmc = {"traffic": bpe * n * steps_in_launch, "traffic_bytes_per_env_step": bpe,
                                 "hbm_measured": {"GBps": hbm_gbps, "frac": hbm_gbps / HBM_PEAK_GBPS,
                                                  "note": "stored-profile HBM bytes per env-step x this run's kernel rate"},
-                                "valu_issue_frac": valu, "lds_pipe_busy_frac": tj.get("lds_pipe_busy_frac"),
+                                "valu_issue_frac": valu, "lds_pipe_busy_frac": lds,
                                 "counters_source": tj.get("source"),
                                 "counters_note": "derived from the stored rocprofv3 PMC profile of this kernel source (sha %s), "
                                                  "not measured by this run" % source_sha()}
-                    cands = {"hbm": hbm_gbps / HBM_PEAK_GBPS, "valu_issue": valu, "lds_pipe": float(tj.get("lds_pipe_busy_frac") or 0.0)}
+                    cands = {"hbm": hbm_gbps / HBM_PEAK_GBPS, "valu_issue": valu, "lds_pipe": float(lds or 0.0)}
                     bound = max(cands, key=cands.get)
             except Exception:
                 pass

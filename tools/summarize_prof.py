@@ -74,6 +74,7 @@ if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
     if "SQ_LDS_IDX_ACTIVE" in big and step_avg_ns:
         # cycles the LDS pipe of a CU is busy / cycles of the launch (256 CUs, 2.4 GHz nominal)
         cj["lds_pipe_busy_frac"] = big["SQ_LDS_IDX_ACTIVE"] / 256.0 / (step_avg_ns * 2.4)
+        cj["lds_active_cycles_per_env_step"] = big["SQ_LDS_IDX_ACTIVE"] / per  # summed over the 256 CUs' LDS pipes
         cj["lds_bank_conflict_frac_of_busy"] = big.get("SQ_LDS_BANK_CONFLICT", 0) / big["SQ_LDS_IDX_ACTIVE"]
     if "SQ_ACTIVE_INST_VALU" in big and "SQ_WAVE_CYCLES" in big:
         cj["valu_busy_frac_of_simd_cycles"] = big["SQ_ACTIVE_INST_VALU"] / (big["SQ_WAVE_CYCLES"] / 4.0)
