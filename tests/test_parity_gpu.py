@@ -308,6 +308,40 @@ def test_full_size_properties(torch_cuda, native):
     assert st["episodes"] == ep_done and ep_done > n // 2
 
 
+def test_full_size_fused_trajectory_properties(torch_cuda, native):
+    """The benchmark's own launch shape — BASELINE configs[2] at full size, 100 fused steps per launch, trajectory outputs —
+    through size-independent properties of EVERY step: history chaining between consecutive slots, reset rows, the three
+    reward values, flag / reward consistency, lidar ranges; and slot by slot equal to a second handle that gathers its bank
+    from L2 instead of staging it in LDS (an independent instantiation of the kernel)."""
+    torch = torch_cuda
+    n, K = 65536, 200
+    vec = _vec(n, n_maps=64, n_beams=8)
+    ref = _vec(n, n_maps=64, n_beams=8, bank_in_global=True)
+    F = vec.n_states
+    obs0 = vec.reset_tensor().clone(); ref.reset_tensor()
+    acts = vec.random_actions(2025, 0, K)
+    to, tr, td, tf = vec.rollout_tensor(acts, trajectory=True)
+    ro, rr, rd, rf = ref.rollout_tensor(acts, trajectory=True)
+    assert torch.equal(to, ro) and torch.equal(tr, rr) and torch.equal(td, rd) and torch.equal(tf, rf)
+    prev = obs0
+    for k in range(K):
+        obs, rew, done, flags = to[k], tr[k], td[k], tf[k]
+        cont = done == 0
+        assert torch.equal(obs[cont][:, :F], prev[cont][:, F:]), k        # oldest-first history (ship_env.py:113,181)
+        rs = ~cont
+        if rs.any():
+            assert torch.all(obs[rs][:, :F] == -1) and torch.all(obs[rs][:, F] == vec.cfg.spawn_x) and torch.all(obs[rs][:, F + 1] == vec.cfg.spawn_y)
+        assert torch.all((rew == 1.0) | (rew == -1.0) | (rew == -0.01))
+        assert torch.equal(rew == 1.0, (flags & native.EV_GOAL_REACHED) != 0)
+        assert torch.equal(done != 0, (flags & (native.EV_COLLIDING | native.EV_OUT_OF_BOUNDS | native.EV_MAX_STEPS | native.EV_NO_GOALS_LEFT)) != 0)
+        lid = obs[:, F + 6:]
+        assert torch.all((lid == -1) | ((lid >= 0) & (lid <= 100.0 + 1e-9)))
+        prev = obs
+    st = vec.stats()
+    assert st["episodes"] == int(td.sum()) and st["episodes"] > n // 2
+    assert torch.equal(to[K - 1][:, F], vec.field(native.F_X)) and torch.equal(to[K - 1][:, F + 1], vec.field(native.F_Y))
+
+
 def test_single_env_fresh_mode_matches_oracle(torch_cuda, oracle, native):
     """configs[0] analogue: the ShipEnv facade in reference-exact 'fresh' map mode against an oracle World fed the
     same RNG streams; seeds python random and numpy as SURVEY App. B-12/17 prescribes."""
