@@ -1264,12 +1264,16 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         reg_load(R0, 0);
         reg_load(R1, n_act > 1 ? 1 : 0);
         const bool two = n_act > 1;
+        // the hand-over of a shared body between the two arbiters (~200 selects per iteration) is only needed if some lane of
+        // the wave HAS a shared dynamic body (the static body's fields never change: its inverse mass and moment are 0)
+        const bool shares = two & ((((R0.a == R1.a) | (R0.a == R1.b)) & (R0.a != slot_static)) | (((R0.b == R1.a) | (R0.b == R1.b)) & (R0.b != slot_static)));
+        const bool any_shared = __any(shares);
         for (int it = 0; it < kIter; ++it) {
             reg_step(R0);
             if (two) {
-                reg_sync(R0, R1);
+                if (any_shared) reg_sync(R0, R1);
                 reg_step(R1);
-                reg_sync(R1, R0);
+                if (any_shared) reg_sync(R1, R0);
             }
         }
         reg_store(R0, 0);
