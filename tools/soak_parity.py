@@ -60,7 +60,30 @@ def soak_fused(n, chunks, seed=99, **kw):
     vec.close()
 
 
+def soak_traj(n, chunks, seed=2026, **kw):
+    """ssg_rollout_traj (round 3): EVERY step of launches of 100 fused steps against the oracle, at the full env count."""
+    vec = ShipVecEnv(n, n_maps=64, **kw)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    worst, t0, ndone = 0.0, time.time(), 0
+    for c in range(chunks):
+        acts = vec.random_actions(seed, 100 * c, 100)
+        ah = acts.cpu().numpy()
+        to, tr, td, tf = [t.cpu().numpy() for t in vec.rollout_tensor(acts, trajectory=True)]
+        for k in range(100):
+            r_obs, r_rew, r_done = ob.step(ah[k], auto_reset=True, n_threads=O.max_threads())
+            assert np.array_equal(td[k], r_done), ("done", c, k)
+            assert np.array_equal(tr[k], r_rew), ("reward", c, k)
+            worst = max(worst, float(np.abs(to[k] - r_obs).max()))
+            ndone += int(r_done.sum())
+    print(kw, "trajectory: n=%d, %d launches of 100 steps, every step: max |obs - oracle| %.3e, %d episode ends, %.1f s" % (
+        n, chunks, worst, ndone, time.time() - t0), flush=True)
+    assert worst <= 1e-9
+    vec.close()
+
+
 if __name__ == "__main__":
+    soak_traj(65536, 4, n_beams=8)
     soak_fused(65536, 4, n_beams=8)
     soak(8192, 1500, n_beams=8)
     soak(8192, 1200, n_beams=10, n_ships=4)
