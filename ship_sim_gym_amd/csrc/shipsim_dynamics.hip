@@ -177,7 +177,14 @@ struct BankShape {
     int n;
     BB box;
     unsigned hashid;
+    V2 wv[SSG_MAX_HULL]; // the vertices, fetched from the LDS columns once per shape (cache()): GJK / EPA ask for the support
+                         // point a dozen times in a dependent chain, and each call re-read all twelve
     static constexpr bool is_circle = false;
+    __device__ __forceinline__ void cache()
+    {
+#pragma unroll
+        for (int i = 0; i < SSG_MAX_HULL; ++i) wv[i] = mk(lds[base + (4 * i) * kGrp], lds[base + (4 * i + 1) * kGrp]);
+    }
     __device__ __forceinline__ V2 vert(int i) const { return mk(lds[base + (4 * i) * kGrp], lds[base + (4 * i + 1) * kGrp]); }
     __device__ __forceinline__ V2 normal(int i) const { return mk(lds[base + (4 * i + 2) * kGrp], lds[base + (4 * i + 3) * kGrp]); }
     __device__ __forceinline__ BB bb() const { return box; }
@@ -185,16 +192,12 @@ struct BankShape {
     {
         double mx = -INFINITY;
         Sup s; s.p = mk(0, 0); s.i = 0;
-        // all 12 staged slots are fetched at once (one LDS round trip instead of one per vertex); the comparisons run
-        // in vertex order over the first n, exactly as PolySupportPointIndex does
-        V2 v[SSG_MAX_HULL];
-#pragma unroll
-        for (int i = 0; i < SSG_MAX_HULL; ++i) v[i] = vert(i);
+        // the comparisons run in vertex order over the first n, exactly as PolySupportPointIndex does
 #pragma unroll
         for (int i = 0; i < SSG_MAX_HULL; ++i) {
-            const double d = dot(v[i], nn);
+            const double d = dot(wv[i], nn);
             const bool take = (i < n) & (d > mx);
-            mx = take ? d : mx; s.p.x = take ? v[i].x : s.p.x; s.p.y = take ? v[i].y : s.p.y; s.i = take ? i : s.i;
+            mx = take ? d : mx; s.p.x = take ? wv[i].x : s.p.x; s.p.y = take ? wv[i].y : s.p.y; s.i = take ? i : s.i;
         }
         return s;
     }
@@ -898,6 +901,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     EpaMem emem;
     int dbg_cnt[3] = {0, 0, 0};
     unsigned long long prof_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, prof_last = 0ull;
+#ifdef SSG_DYN_PROFILE
+    unsigned long long type_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, type_t0 = 0ull; // cycles per pair type: gb gg tb gt tt
+#define SSG_TYPE_BEGIN() do { type_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define SSG_TYPE_END(t) do { type_acc[t] += __builtin_amdgcn_s_memtime() - type_t0; } while (0)
+#else
+#define SSG_TYPE_BEGIN() do { } while (0)
+#define SSG_TYPE_END(t) do { } while (0)
+#endif
     emem.base = (abase + A_STRIDE * kLdsArb) * kGrp + lane + 2 * kBankDoubles * kGrp; emem.ov = epa_ov; emem.cnt = dbg_cnt; emem.prof = prof_acc; emem.last = &prof_last;
     auto bank_box = [&](int s) -> BB {
         BB o;
@@ -930,6 +941,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         b.n = (int)(s ? bk[1][0] : bk[0][0]);
         b.box = bank_box(s);
         b.hashid = (unsigned)s;
+        b.cache();
         return b;
     };
     auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
@@ -1058,6 +1070,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             sel = zeros ? zeros : sel;
         }
         const int o = __builtin_amdgcn_readlane(ol, __ffsll((long long)sel) - 1);
+        SSG_TYPE_BEGIN();
+        int type_ = 0;
         if ((cand >> o) & 1ull) {
             cand &= ~(1ull << o);
             if (o < kGoalBlock) {
@@ -1068,7 +1082,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                     const BankShape bs = bank_shape(r);
                     collide(cg, bs, info, emem);
                     push(info, g, slot_static, pid_gb(g, r), 0.0);
+                    type_ = 0;
                 } else {
+                    type_ = 1;
                     const int h = r - 2;
                     const CircleShape ch = goal_shape(h);
                     collide(ch, cg, info, emem);
@@ -1082,7 +1098,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                     const BankShape bs = bank_shape(r);
                     collide(sk, bs, info, emem);
                     push(info, slot_ship0 + k, slot_static, pid_tb(k, r), d.ship_friction * 0.0);
+                    type_ = 2;
                 } else if (r < 2 + SSG_MAX_GOALS) {
+                    type_ = 3;
                     const int g = r - 2;
                     const CircleShape cg = goal_shape(g);
                     collide(cg, sk, info, emem);
@@ -1092,8 +1110,22 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                     const ShipShape sj = ship_shape(j);
                     collide(sj, sk, info, emem);
                     push(info, slot_ship0 + j, slot_ship0 + k, pid_tt(j, k), d.ship_friction * d.ship_friction);
+                    type_ = 4;
                 }
             }
+        }
+        { // (the trip's pair type is wave-uniform: o is) gb gg tb gt tt
+            int tt_;
+            if (o < kGoalBlock) {
+                const int g_ = (o >= o_goal(5)) ? 5 : (o >= o_goal(4)) ? 4 : (o >= o_goal(3)) ? 3 : (o >= o_goal(2)) ? 2 : (o >= o_goal(1)) ? 1 : 0;
+                tt_ = (o - o_goal(g_) < 2) ? 0 : 1;
+            } else {
+                const int k_ = (o >= o_ship(2)) ? 2 : (o >= o_ship(1)) ? 1 : 0;
+                const int r_ = o - o_ship(k_);
+                tt_ = r_ < 2 ? 2 : (r_ < 2 + SSG_MAX_GOALS ? 3 : 4);
+            }
+            (void)tt_; (void)type_;
+            SSG_TYPE_END(tt_);
         }
     }
 
@@ -1101,6 +1133,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #ifdef SSG_DYN_PROFILE
     if (d.stop_after == -1)
         for (int i = 0; i < 6; ++i) col.f64[(size_t)(DC_ARB + 4 * 45 + i) * np + e] = (double)prof_acc[i]; // unused arbiter rows of pairs 45, 46
+    if (d.stop_after == -1)
+        for (int i = 0; i < 5; ++i) col.f64[(size_t)(DC_ARB + 4 * 47 + i) * np + e] = (double)type_acc[i]; // ... and of pairs 47, 48
 #endif
     stamp(2);
     if (d.stop_after == 3) return;

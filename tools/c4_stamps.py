@@ -65,3 +65,13 @@ print("waves: %d; total cycles p10 %.0f median %.0f p90 %.0f max %.0f" % (len(ro
 print("slowest / fastest waves: total, lanes, max n_act, max queries, max gjk it, max epa it, distinct (gjk,epa,q) signatures, load, collide, solver")
 for r in rows[-8:] + rows[:4]:
     print("   ", " ".join("%7.0f" % v for v in r))
+
+ty = cols[DC_ARB + 188: DC_ARB + 193, :n].cpu().numpy()
+if ty[:, sel].max() > 0:
+    nm = ["goal-bank", "goal-goal", "ship-bank", "goal-ship", "ship-ship"]
+    print("narrowphase trips by pair type (cycles per wave): median / p90 / max and share of waves that enter the type")
+    for i in range(5):
+        v = ty[i][sel]
+        print("   %-10s %8.0f %8.0f %8.0f   entered by %.2f of the waves" % (nm[i], np.median(v), np.percentile(v, 90), v.max(), (v > 0).mean()))
+    heavy = st[5][sel] >= np.percentile(st[5][sel], 95)
+    print("   slowest 5 %% of the waves: " + ", ".join("%s %.0f" % (nm[i], ty[i][sel][heavy].mean()) for i in range(5)))
