@@ -114,6 +114,7 @@ class ShipVecEnv(*_BASES):
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self._dev_index)  # (always with its index: tensors report `cuda:N`)
         self.map_mode = map_mode
         self.bounds = tuple(game_config.BOUNDS)
         self.width_frac = float(width_frac)
