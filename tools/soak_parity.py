@@ -17,7 +17,7 @@ from helpers import oracle_cfg
 
 
 def soak(n, K, seed=777, **kw):
-    vec = ShipVecEnv(n, n_maps=64, **kw)
+    vec = ShipVecEnv(n, n_maps=kw.pop("n_maps", 64), **kw)
     ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
     np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
     acts = vec.random_actions(seed, 0, K)
@@ -83,6 +83,19 @@ def soak_traj(n, chunks, seed=2026, **kw):
 
 
 if __name__ == "__main__":
+    if "--long" in sys.argv:  # several minutes: the round's extended soak (profiles/r3/soak_parity.txt)
+        from ship_sim_gym_amd.config import GameConfig
+
+        class Train(GameConfig):  # train/stable_baselines/ppo.py:65-69
+            SPEED = 30
+            BOUNDS = (1000, 1000)
+
+        soak_traj(65536, 20, n_beams=8)                               # 131 M env-steps, every fused step
+        soak_traj(65536, 6, seed=7, n_beams=10)                       # the default 10-beam lidar
+        soak(16384, 3000, seed=11, n_beams=10, n_ships=4)             # 49 M env-steps of config 4
+        soak(16384, 1500, seed=12, n_beams=8, game_config=Train, n_maps=32)  # the training configuration (episodes of ~6 steps)
+        soak(4096, 2500, seed=13, n_beams=16)                         # 16 beams: the bank gathered from L2, record heads in LDS
+        sys.exit(0)
     soak_traj(65536, 4, n_beams=8)
     soak_fused(65536, 4, n_beams=8)
     soak(8192, 1500, n_beams=8)
