@@ -342,6 +342,32 @@ def test_full_size_fused_trajectory_properties(torch_cuda, native):
     assert torch.equal(to[K - 1][:, F], vec.field(native.F_X)) and torch.equal(to[K - 1][:, F + 1], vec.field(native.F_Y))
 
 
+def test_trajectory_rewards_add_up_to_the_in_kernel_episode_statistics(torch_cuda, native):
+    """What train/random.py:14-27 does with the per-step tuples — accumulate `total_reward` until `done` — done on the
+    trajectory tensors of a fused rollout must give exactly the episode statistics the step kernel accumulates itself
+    (integer hundredths: returns are sums of {1, -1, -0.01})."""
+    torch = torch_cuda
+    n, K = 20000, 300
+    vec = _vec(n, n_maps=64, n_beams=8)
+    vec.reset_tensor()
+    acts = vec.random_actions(55, 0, K)
+    to, tr, td, tf = vec.rollout_tensor(acts, trajectory=True)
+    cents = torch.round(tr * 100.0).to(torch.int64)                     # [K, n] rewards in hundredths
+    running = torch.zeros(n, dtype=torch.int64, device=vec.device)
+    total_ret, total_len, episodes = 0, 0, 0
+    length = torch.zeros(n, dtype=torch.int64, device=vec.device)
+    for k in range(K):
+        running += cents[k]
+        length += 1
+        d = td[k] != 0
+        total_ret += int(running[d].sum()); total_len += int(length[d].sum()); episodes += int(d.sum())
+        running[d] = 0; length[d] = 0
+    st = vec.stats()
+    assert episodes == st["episodes"] and total_len == st["sum_length"]
+    assert total_ret == int(round(st["sum_return"] * 100.0))
+    assert int((tf & native.EV_GOAL_REACHED != 0).sum()) == st["goals_hit"]
+
+
 def test_single_env_fresh_mode_matches_oracle(torch_cuda, oracle, native):
     """configs[0] analogue: the ShipEnv facade in reference-exact 'fresh' map mode against an oracle World fed the
     same RNG streams; seeds python random and numpy as SURVEY App. B-12/17 prescribes."""
