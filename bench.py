@@ -21,6 +21,10 @@ Cache; done envs are auto-reset in-kernel.  Workload at N=1: BASELINE.json confi
 MI355X" target is quoted on.  With --gpus 8 rank 0 also times BASELINE configs[4] (131 072 envs per rank x 8 =
 1 048 576 envs, 10 beams) as `other_configs.c5_full` (all ranks step, MAX over ranks).
 
+TEST-ONLY overrides (tests/test_sharding_gpu.py; never set by the driver): SSG_BENCH_SHARE_DEVICE=1 puts every rank
+on device 0 and SSG_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on a 1-GPU box; the
+line's `data` field then says "TEST RUN ... timings meaningless".
+
 Timing: W untimed warm-up steps, then the K-step rollout is timed `--repeats` (default 5) times, every repeat
 bracketed by barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` is the
 MEDIAN repeat, all repeats are listed in `repeats_ms`.
@@ -229,7 +233,7 @@ def timed_rollouts(vec, K, W, R, use_dist, dev):
         walls.append(time.perf_counter() - t0)
         evs.append(ev0.elapsed_time(ev1))
     if use_dist:
-        t = torch.tensor(walls, dtype=torch.float64, device=dev)
+        t = torch.tensor(walls, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time, repeat by repeat
         walls = [float(v) for v in t.tolist()]
     del bufs, acts
@@ -273,7 +277,14 @@ def main():
                          % (args.gpus, world))
         sys.exit(2)
     n_dev = torch.cuda.device_count()
-    if n_dev < (local_rank + 1) or (in_dist_env and n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))):
+    # TEST-ONLY overrides (tests/test_sharding_gpu.py on a 1-GPU box): all ranks on device 0 and gloo instead of RCCL, to
+    # exercise the N > 1 control flow — barriers, MAX over ranks, the rank table, configs[4] — where no second GPU exists.
+    # The numbers of such a run mean nothing and the JSON line says so.
+    share_dev = os.environ.get("SSG_BENCH_SHARE_DEVICE") == "1"
+    backend = os.environ.get("SSG_BENCH_BACKEND", "nccl")
+    if share_dev:
+        local_rank = 0
+    if n_dev < (local_rank + 1) or (in_dist_env and not share_dev and n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))):
         sys.stderr.write("bench.py: rank %d/%d needs device %d but this node shows %d HIP device(s): one process per "
                          "GPU, no oversubscription\n" % (rank, world, local_rank, n_dev))
         sys.exit(3)
@@ -282,7 +293,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
         world = dist.get_world_size()
 
     n = args.envs_per_gpu
@@ -382,7 +396,8 @@ def main():
         out = {
             "metric": "env steps/sec (batched ShipEnv)", "value": total_steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not share_dev else "synthetic (TEST RUN: ranks share one device over %s; timings meaningless)" % backend,
             "config": {"workload": ("BASELINE configs[3]: 65536 parallel envs per GPU x 4 ships (3 traffic ships, dynamic "
                                     "goal bodies, Chipmunk contact solver), 10-beam lidar, 64-map bank, random Philox "
                                     "actions, auto-reset in-kernel") if c4 else

@@ -79,3 +79,24 @@ def test_bench_launcher_on_this_box(tmp_path):
     else:
         assert p.returncode != 0 and not lines, (p.returncode, p.stdout[-500:])
         assert "needs device" in p.stderr
+
+
+def test_bench_multi_rank_control_flow_on_one_device(tmp_path):
+    """The N>1 branch of bench.py (barriers, MAX over ranks, the rank table, the c5_full leg) exercised on whatever this
+    box has: two ranks share device 0 over gloo (SSG_BENCH_SHARE_DEVICE / SSG_BENCH_BACKEND, test-only overrides).  The
+    line says so in `data`; the timings mean nothing, the structure must be the one the driver's 8-GPU run prints."""
+    env = dict(os.environ, SSG_BENCH_SHARE_DEVICE="1", SSG_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--repeats", "1", "--envs-per-gpu", "4096", "--c5-full", "--no-cpu-baseline"], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                   # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "TEST RUN" in j["data"]
+    assert j["config"]["total_envs"] == 8192
+    ranks = j["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["env_id_base"] for r in ranks] == [0, 4096]
+    c5 = j["other_configs"]["c5_full"]
+    assert c5["n_gpus"] == 2 and c5["total_envs"] == 2 * 131072 and c5["env_steps_per_s"] > 0
+    assert "cpu_baseline" not in j or j["cpu_baseline"] is None or j["n_gpus"] == 2
