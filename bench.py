@@ -367,7 +367,8 @@ def main():
         env_steps_per_s_kernel = n * steps_in_launch / launch_s
         # PMC-derived figures: only from a stored profile of THIS kernel source, in THIS output mode
         roof_pmc = {"traffic": None, "traffic_bytes_per_env_step": None, "hbm_measured": None, "valu_issue_frac": None,
-                    "lds_pipe_busy_frac": None, "counters_source": None,
+                    "lds_pipe_busy_frac": None, "shader_clock_ghz_profiled": None, "valu_issue_frac_at_profiled_clock": None,
+                    "counters_source": None,
                     "counters_note": "PMC counters cannot be read in-process; no stored rocprofv3 profile of this kernel source "
                                      "(sha %s) in trajectory mode under profiles/" % source_sha()}
         bound = "unknown (no PMC profile of this build)"
@@ -386,6 +387,12 @@ def main():
                                 "hbm_measured": {"GBps": hbm_gbps, "frac": hbm_gbps / HBM_PEAK_GBPS,
                                                  "note": "stored-profile HBM bytes per env-step x this run's kernel rate"},
                                 "valu_issue_frac": valu, "lds_pipe_busy_frac": lds,
+                                # the shader clock the profiled launches actually ran at (SQ_WAVE_CYCLES / waves / duration:
+                                # FP64-heavy kernels do not hold the 2.4 GHz boost ceiling the peaks above are priced at), and
+                                # the VALU issue fraction against 1024 SIMDs x THAT clock / 4
+                                "shader_clock_ghz_profiled": tj.get("shader_clock_ghz"),
+                                "valu_issue_frac_at_profiled_clock": (valu * 2.4 / float(tj["shader_clock_ghz"])
+                                                                      if tj.get("shader_clock_ghz") else None),
                                 "counters_source": tj.get("source"),
                                 "counters_note": "derived from the stored rocprofv3 PMC profile of this kernel source (sha %s), "
                                                  "not measured by this run" % source_sha()}

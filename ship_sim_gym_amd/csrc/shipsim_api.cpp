@@ -510,7 +510,7 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_count = h->off_dyn_queue + np * sizeof(int32_t);
         h->off_dyn_qkey = h->off_dyn_count + (((size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
         h->off_dyn_sorted = h->off_dyn_qkey + np * sizeof(unsigned long long);
-        h->off_dyn_row = (h->off_dyn_sorted + np * sizeof(int32_t) + 255) & ~(size_t)255;
+        h->off_dyn_row = (h->off_dyn_sorted + (np + (size_t)ssg::kDynSortedPad) * sizeof(int32_t) + 255) & ~(size_t)255;
         h->off_dyn_segcnt = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
         h->nbytes = h->off_dyn_segcnt + ((np / 64 * sizeof(unsigned) + 255) & ~(size_t)255);
         const int rc = set_traffic(h);
@@ -751,8 +751,13 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
             }
             if (dyn) {
                 hipError_t e = hipSuccess;
-                if (!h->dyn_queue_valid) // the classify pass rebuilds the queue: its bucket counters and length start from zero
+                if (!h->dyn_queue_valid) { // the classify pass rebuilds the queue: its bucket counters and length start from zero,
+                                           // the sorted queue holds nothing (-1 everywhere: the sort only writes the entries)
                     e = hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
+                    if (e == hipSuccess)
+                        e = hipMemsetAsync(h->dev.dyn_sorted, 0xFF, ((size_t)h->dev.n_pad + ssg::kDynSortedPad) * sizeof(int32_t),
+                                           static_cast<hipStream_t>(stream));
+                }
                 if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
                 if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
             }

@@ -13,16 +13,20 @@
 // sequential chain (Gauss-Seidel over at most a handful of contacts), so the kernel is bound by the latency of that
 // chain, not by HBM: what matters is that nothing on the chain goes to memory.
 //  * Body state and the solver's arbiter records live in LDS, one column per field, lane-contiguous
-//    (`lds[field*kGrp + lane]`, kGrp = 64): a lane's dynamic slot index changes the field, never the LDS bank, so the per-lane
-//    gathers of the solver are conflict-free.  (A first version kept them in per-lane arrays: 8.7 KB of scratch per
-//    lane, 1 GB of HBM traffic per step, 420 us.)
+//    (`lds[field*kGrp + lane]`, kGrp = 48 envs per wave): the per-lane gathers of the solver are (nearly) conflict-free.
+//    (A first version kept them in per-lane arrays: 8.7 KB of scratch per lane, 1 GB of HBM traffic per step, 420 us.)
 //  * Shapes are never materialised: a ship's world vertices are its pose applied on the fly to the hull constants
-//    (staged once per workgroup in LDS, broadcast reads); both banks' planes are staged into the lane's LDS columns with
-//    the body loads.  EPA's growing hull has seven LDS entries per lane, scratch beyond (practically never).
+//    (staged once per workgroup in LDS, broadcast reads).  The bank planes: the sorted queue is map-major and every map's
+//    stretch starts on a wave boundary, so all lanes of a wave sit on ONE bank record, staged once per wave (96 doubles,
+//    broadcast reads) — dyn_step_kernel<true>; banks of more than 64 records and per-env rings of worlds keep the planes in
+//    per-lane columns (dyn_step_kernel<false>).  76 KB of LDS per wave: two waves per CU, each alone on its SIMD, 512 at
+//    once = 24 576 envs in one round (64 envs per wave with per-lane planes was 158 KB: 256 waves, 16 384 envs, and a
+//    second round — twice the time — whenever more than a quarter of the batch was in its post-reset transient).
+//    EPA's growing hull has seven LDS entries per lane, scratch beyond (practically never).
 //  * Arbiter records (accumulated impulses, contact hashes, state, age) persist in struct-of-arrays columns but are
 //    read or written only for pairs whose bit is set in the env's 64-bit live mask.
 //  * Which envs are stepped: the ones the step kernel's body role queued at the end of the previous step (segmented queue,
-//    DevCfg::dyn_queue), sorted by (steps since the reset, bank record) so that the lanes of a wave walk the same path
+//    DevCfg::dyn_queue), sorted by (bank record, steps since the reset) so that the lanes of a wave walk the same path
 //    (dyn_sort_kernel), read through a row-major shadow of the body columns (DevCfg::dyn_row).  Envs whose space is at a
 //    fixed point of cpSpaceStep (the rest bit) are not stepped at all.
 // Per step: dyn_sort_kernel, dyn_step_kernel, then the step kernel, which reads this step's goal positions and the
@@ -43,17 +47,16 @@ namespace {
 
 extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-uniform hull constants
 
-// Envs per workgroup of the full step (lanes kGrp..63 of its one wave would idle).  Measured at 65 536 envs: 64 ->
-// 146 us per step, 32 -> 149, 16 -> 155, 8 -> 314: a queued env costs ~5 k FP64 VALU instructions per narrowphase
-// query whatever its neighbours do, so smaller groups only add workgroups.  Kept as a build-time knob.
-#ifndef SSG_DYN_GRP
-#define SSG_DYN_GRP 64
-#endif
-constexpr int kGrp = SSG_DYN_GRP;
+// Envs per workgroup of the full step (lanes kGrp..63 of its one wave idle: a lone wave's FP64 chain takes the same time
+// whatever its width).  Measured at 65 536 envs, planes once per wave: 48 (76 KB of LDS, two waves per CU) -> 62.5 us in
+// steady state and 135 us with every env queued; 32 (51 KB, three per CU) -> 63.9 / 132; 64 with per-lane planes (158 KB,
+// one per CU; round 2 and the first half of round 3) -> 60.9 / 165, and 100 whenever the queue outgrew 16 384 envs.
+constexpr int kGrp = kDynGrp;
+static_assert(kGrp == 32 || kGrp == 48 || kGrp == 64, "lds[field * kGrp + lane]: at 32 / 64 a lane keeps its LDS banks whatever the field; 48 pays an occasional 2-way conflict on the solver's per-lane body slots");
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
 constexpr int kMaxGjk = 30, kMaxEpa = 30;
-constexpr int kLdsArb = 3;         // arbiter records per env held in LDS; further ones (rare: 98.8 % of the queued envs have <= 2) go to scratch
+constexpr int kLdsArb = 2;         // arbiter records per env held in LDS; further ones (rare: 98.8 % of the queued envs have <= 2) go to scratch
 constexpr int kMaxActive = 8;      // arbiters on one env's solver list
 enum { ST_NONE = 0, ST_FIRST = 1, ST_NORMAL = 2, ST_IGNORE = 3, ST_CACHED = 4 };
 
@@ -172,8 +175,12 @@ struct ShipShape {
 // lane's LDS columns right before the narrowphase that needs them (all 48 loads in flight at once): GJK / EPA call
 // support() a dozen times in a dependent chain, and each call straight from L2 was a round trip.
 constexpr int kBankDoubles = 4 * SSG_MAX_HULL;
+// UNI: every lane of the wave sits on the same bank record (dyn_sort_kernel's map-aligned order, banks of <= 64 records): the
+// planes are staged ONCE per wave (field stride 1, broadcast reads) instead of into per-lane columns (field stride kGrp).
+template <bool UNI>
 struct BankShape {
-    int base; // index in lds[] of this lane's staged plane 0 (field stride 64)
+    static constexpr int kS = UNI ? 1 : kGrp;
+    int base; // index in lds[] of (this lane's) staged plane 0
     int n;
     BB box;
     unsigned hashid;
@@ -183,10 +190,10 @@ struct BankShape {
     __device__ __forceinline__ void cache()
     {
 #pragma unroll
-        for (int i = 0; i < SSG_MAX_HULL; ++i) wv[i] = mk(lds[base + (4 * i) * kGrp], lds[base + (4 * i + 1) * kGrp]);
+        for (int i = 0; i < SSG_MAX_HULL; ++i) wv[i] = mk(lds[base + (4 * i) * kS], lds[base + (4 * i + 1) * kS]);
     }
-    __device__ __forceinline__ V2 vert(int i) const { return mk(lds[base + (4 * i) * kGrp], lds[base + (4 * i + 1) * kGrp]); }
-    __device__ __forceinline__ V2 normal(int i) const { return mk(lds[base + (4 * i + 2) * kGrp], lds[base + (4 * i + 3) * kGrp]); }
+    __device__ __forceinline__ V2 vert(int i) const { return mk(lds[base + (4 * i) * kS], lds[base + (4 * i + 1) * kS]); }
+    __device__ __forceinline__ V2 normal(int i) const { return mk(lds[base + (4 * i + 2) * kS], lds[base + (4 * i + 3) * kS]); }
     __device__ __forceinline__ BB bb() const { return box; }
     __device__ __forceinline__ Sup support(V2 nn) const
     {
@@ -705,8 +712,11 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// dyn_sort_kernel: counting sort of the queue by bucket, and collide_ship's exact test for the "SAT only" entries.  Every workgroup scans the 512 bucket counters itself (2 KB from L2) and
-// scatters its 256 queue entries to base[bucket] + arrival number.
+// dyn_sort_kernel: counting sort of the queue by bucket (the "SAT only" entries stay where they are: dyn_step_kernel's trailing
+// workgroups read them from the segments).  Every
+// workgroup scans the 512 bucket counters itself (2 KB from L2) and scatters its 256 queue entries to base[bucket] + arrival
+// number.  Buckets are map-major (dyn_bucket_of) and a map's eight buckets start on a multiple of kDynGrp slots: no wave of the
+// full step straddles two bank records.  The gaps are not written: the full step leaves -1 behind in every slot it read.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const DynCfg d)
 {
@@ -722,64 +732,110 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
     const unsigned long long k = valid ? c.dyn_qkey[i] : 0ull;
     const bool sat_only = valid & (k == kDynSatOnly);
     const unsigned n_full = (unsigned)__popcll(__ballot(valid & !sat_only));
-    stage_hulls(c, d, 0, t);
-    if (lane == 0) wave_tot[wv] = (cnt ? 0x10000u : 0u) | n_full;
+    if (lane == 0) wave_tot[wv] = n_full;
     __syncthreads();
     const unsigned wsum = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    if (wsum == 0u) return; // nothing queued among this workgroup's 256 envs (workgroup-uniform)
-    const unsigned wg_total = wsum & 0xFFFFu;
+    if (wsum == 0u) return; // no full step queued among this workgroup's 256 envs (workgroup-uniform)
     __syncthreads();
-    if (sat_only) { // a resting env whose player comes within reach of a parked ship: collide_ship's exact test, traffic bit of the flag
-        const int e = c.dyn_queue[i];
-        if (resting_player_hit(c, e)) c.dyn_flag[e] = (uint8_t)(4u | 1u);
-    }
     const unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
-    unsigned incl = c0 + c1;
+    static_assert(kDynAgeBuckets == 8, "four threads (two buckets each) per map");
+    // inside the map (threads 4m .. 4m+3): inclusive scan of the bucket counts, the map's total, its wave-rounded length
+    const unsigned two = c0 + c1;
+    unsigned in_map = two;
+    { const unsigned v = __shfl_up(in_map, 1); in_map += ((lane & 3) >= 1) ? v : 0u; }
+    { const unsigned v = __shfl_up(in_map, 2); in_map += ((lane & 3) >= 2) ? v : 0u; }
+    const unsigned n_map = __shfl(in_map, lane | 3);
+    const unsigned r_map = (n_map + (unsigned)(kDynGrp - 1)) / (unsigned)kDynGrp * (unsigned)kDynGrp;
+    // over the maps: inclusive scan of the rounded lengths (each map contributes once, at its last thread)
+    unsigned incl = ((lane & 3) == 3) ? r_map : 0u;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned v = __shfl_up(incl, o);
         incl += (lane >= o) ? v : 0u;
     }
+    const unsigned maps_incl = __shfl(incl, lane | 3); // ... up to and including this thread's map
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
     unsigned off = 0;
     for (int w = 0; w < wv; ++w) off += wave_tot[w];
-    const unsigned excl = off + incl - (c0 + c1);
+    const unsigned excl = off + maps_incl - r_map + in_map - two; // the map's first slot + the buckets of the map before this thread's
     base[2 * t] = excl;
     base[2 * t + 1] = excl + c0;
     __syncthreads();
-    if (t == 0 && wg_total) atomicAdd(c.dyn_count, wg_total); // the queue's length (zeroed by the step kernel)
+    // the queue's length including the gaps (zeroed by the step kernel; every workgroup that gets here stores the same number)
+    if (t == 0) c.dyn_count[0] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     if (valid & !sat_only) {
         const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
-        if (dst < (unsigned)c.n_pad) c.dyn_sorted[dst] = c.dyn_queue[i];
+        if (dst < (unsigned)c.n_pad + (unsigned)kDynSortedPad) c.dyn_sorted[dst] = c.dyn_queue[i];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // dyn_step_kernel: the full cpSpaceStep of the queued envs, one lane per env, one wave per workgroup.
+// UNI: the lanes of a wave share one bank record (see BankShape); chosen by launch_dyn_step.
 // ---------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int dyn_lane_doubles(int n_goals, bool uni)
+{
+    return B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb + (uni ? 0 : 2 * kBankDoubles) + kEpaDoubles;
+}
+
+template <bool UNI>
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
     const int lane = threadIdx.x;
     // (clamped: a counter that was never initialised must not index past the queue; include/shipsim.h ssg_bind_state)
-    const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_envs);
+    // The grid's tail — one workgroup per 64-env segment of the step kernel's queue — serves the "SAT only" entries: a resting
+    // env whose player comes within reach of a parked ship gets collide_ship's exact test and the traffic bit of its flag.
+    // These workgroups take the LDS slots the full step's waves leave free (or recycle them) and are long gone before the
+    // slowest of those finishes; inside dyn_sort_kernel the same test sat on the chain sort -> full step -> step kernel.
+    const unsigned n_step_blocks = ((unsigned)c.n_pad + (unsigned)kDynSortedPad) / (unsigned)kGrp;
+    if (blockIdx.x >= n_step_blocks) {
+        const unsigned seg = blockIdx.x - n_step_blocks;
+        const unsigned cnt = min(c.dyn_segcnt[seg], 64u);
+        if (cnt == 0u) return;
+        const bool sat = ((unsigned)lane < cnt) && c.dyn_qkey[seg * 64u + (unsigned)lane] == kDynSatOnly;
+        if (!__any(sat)) return;
+        stage_hulls(c, d, 0, lane);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (sat) {
+            const int e = c.dyn_queue[seg * 64u + (unsigned)lane];
+            if (e >= 0 && e < c.n_envs && resting_player_hit(c, e)) c.dyn_flag[e] = (uint8_t)(4u | 1u);
+        }
+        return;
+    }
+    const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_pad + (unsigned)kDynSortedPad);
     if ((unsigned)blockIdx.x * (unsigned)kGrp >= n_queued) return; // wave-uniform: nothing queued for this workgroup
-    const bool queued = (lane < kGrp) & ((unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane < n_queued);
-    const int e = queued ? c.dyn_sorted[blockIdx.x * kGrp + lane] : 0;
+    const unsigned slot = (unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane;
+    const bool in_queue = (lane < kGrp) & (slot < n_queued);
+    const int e_raw = in_queue ? c.dyn_sorted[slot] : -1; // -1: a gap in front of the next map's stretch
+    if (in_queue) c.dyn_sorted[slot] = -1;                // the next sort writes entries only
+    const bool queued = (e_raw >= 0) & (e_raw < c.n_envs);
+    const int e = queued ? e_raw : 0;
     if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
         for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
-    const int lane_doubles = B_STRIDE * (c.n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
-                             2 * kBankDoubles + kEpaDoubles;
+    const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
     const int cbase = kGrp * lane_doubles;
+    const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
     stage_hulls(c, d, cbase, lane);
-    __builtin_amdgcn_s_waitcnt(0xC07F); // one wave per workgroup: the LDS writes above are visible to its lanes
-    __builtin_amdgcn_wave_barrier();
-    if (!queued) return;
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
     const size_t np = col.np;
+    int map_id = queued ? c.i32cols[(size_t)ICOL_MAP * np + e] : 0;
+    if (UNI) {
+        const unsigned long long qm = __ballot(queued);
+        if (qm == 0ull) return;
+        map_id = __builtin_amdgcn_readlane(map_id, __ffsll((long long)qm) - 1);
+        const double *rec_u = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
+        for (int q = lane; q < 2 * kBankDoubles; q += 64) {
+            const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
+            lds[sbank + q] = rec_u[SSG_MAP_OFF_PLANES + sd * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave per workgroup: the LDS writes above are visible to its lanes
+    __builtin_amdgcn_wave_barrier();
+    if (!queued) return;
     const double dt = c.dt;
     const int ng = c.n_goals;
-    const int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
     const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
     // development aid (SSG_DYN_STOP=-1): phase stamps of this lane's wave into the unused arbiter rows of pair 50..53
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -896,7 +952,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
         for (int f = 0; f < 4; ++f) bk[s][1 + f] = rec[SSG_MAP_OFF_AABB + 4 * s + f];
     }
-    const int bbase = (abase + A_STRIDE * kLdsArb) * kGrp + lane; // this lane's staged bank planes; EPA's hull follows
+    const int bbase = (abase + A_STRIDE * kLdsArb) * kGrp + lane; // !UNI: this lane's staged bank planes; EPA's hull follows
     Mink epa_ov[2 * (kMaxEpa + 4 - kEpaLds)];
     EpaMem emem;
     int dbg_cnt[3] = {0, 0, 0};
@@ -909,13 +965,13 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #define SSG_TYPE_BEGIN() do { } while (0)
 #define SSG_TYPE_END(t) do { } while (0)
 #endif
-    emem.base = (abase + A_STRIDE * kLdsArb) * kGrp + lane + 2 * kBankDoubles * kGrp; emem.ov = epa_ov; emem.cnt = dbg_cnt; emem.prof = prof_acc; emem.last = &prof_last;
+    emem.base = (abase + A_STRIDE * kLdsArb) * kGrp + lane + (UNI ? 0 : 2 * kBankDoubles * kGrp); emem.ov = epa_ov; emem.cnt = dbg_cnt; emem.prof = prof_acc; emem.last = &prof_last;
     auto bank_box = [&](int s) -> BB {
         BB o;
         o.l = s ? bk[1][1] : bk[0][1]; o.b = s ? bk[1][2] : bk[0][2]; o.r = s ? bk[1][3] : bk[0][3]; o.t = s ? bk[1][4] : bk[0][4];
         return o;
     };
-    {
+    if (!UNI) {
         // Both banks' planes go to this lane's LDS columns up front, requested together with the body row: staged on demand
         // (one bank at a time, again whenever the pair loops switched side) the 48 gathers from the map record were an exposed
         // L2 round trip in front of every narrowphase query.
@@ -935,9 +991,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
         for (int q = 0; q < 2 * kBankDoubles; ++q) lds[bbase + q * kGrp] = tmp[q];
     }
-    auto bank_shape = [&](int s) -> BankShape {
-        BankShape b;
-        b.base = bbase + s * kBankDoubles * kGrp;
+    auto bank_shape = [&](int s) -> BankShape<UNI> {
+        BankShape<UNI> b;
+        b.base = UNI ? sbank + s * kBankDoubles : bbase + s * kBankDoubles * kGrp;
         b.n = (int)(s ? bk[1][0] : bk[0][0]);
         b.box = bank_box(s);
         b.hashid = (unsigned)s;
@@ -1079,7 +1135,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                 const int r = o - (2 * g + g * (g - 1) / 2);
                 const CircleShape cg = goal_shape(g);
                 if (r < 2) {
-                    const BankShape bs = bank_shape(r);
+                    const BankShape<UNI> bs = bank_shape(r);
                     collide(cg, bs, info, emem);
                     push(info, g, slot_static, pid_gb(g, r), 0.0);
                     type_ = 0;
@@ -1095,7 +1151,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                 const int r = o - (kGoalBlock + (2 + SSG_MAX_GOALS) * k + k * (k - 1) / 2);
                 const ShipShape sk = ship_shape(k);
                 if (r < 2) {
-                    const BankShape bs = bank_shape(r);
+                    const BankShape<UNI> bs = bank_shape(r);
                     collide(sk, bs, info, emem);
                     push(info, slot_ship0 + k, slot_static, pid_tb(k, r), d.ship_friction * 0.0);
                     type_ = 2;
@@ -1425,25 +1481,26 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     col.flag[e] = (uint8_t)((hit ? 1u : 0u) | (changed ? 0u : 4u)); // unchanged = a fixed point of cpSpaceStep: at rest
 }
 
-size_t dyn_lds_bytes(int n_goals)
+size_t dyn_lds_bytes(int n_goals, bool uni)
 {
-    const int doubles = B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb +
-                        2 * kBankDoubles + kEpaDoubles;
-    return ((size_t)doubles * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
+    return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) + (uni ? 2 * kBankDoubles : 0)) * sizeof(double);
 }
 
-// Raise the dynamic-LDS cap of the full-step kernel to the CU's whole 160 KiB (once per handle, like prepare_step).
+// Raise the dynamic-LDS cap of the full-step kernel (once per handle, like prepare_step).
 hipError_t prepare_dyn(const DevCfg &c)
 {
-    if (dyn_lds_bytes(c.n_goals) > 160u * 1024u) return hipErrorInvalidValue;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (dyn_lds_bytes(c.n_goals, false) > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024);
 }
 
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream)
 {
     // (the classify pass over every env only when the host touched the envs,) the sort, then the full step over the sorted
-    // queue (grid sized for the worst case; workgroups past the
+    // queue (grid sized for the worst case: every env queued and every map's stretch rounded up to a wave; workgroups past the
     // queue's end leave at once).  The step kernel that follows empties the queue counter.
     static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
@@ -1451,8 +1508,13 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipS
     if (classify)
         hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_pad + kClassifyThreads - 1) / kClassifyThreads)),
                            dim3(kClassifyThreads), 0, stream, c, dd);
-    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)(c.n_pad / 256)), dim3(256), (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) * sizeof(double), stream, c, dd);
-    hipLaunchKernelGGL(dyn_step_kernel, dim3((unsigned)((c.n_envs + kGrp - 1) / kGrp)), dim3(64), dyn_lds_bytes(c.n_goals), stream, c, dd);
+    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)(c.n_pad / 256)), dim3(256), 0, stream, c, dd);
+    // one bank record per wave: the sort's buckets tell records apart only when the bank holds at most kDynMapBuckets of them
+    // (a per-env ring of worlds never does)
+    const bool uni = c.map_ring == 0 && c.n_maps <= kDynMapBuckets;
+    const dim3 grid((unsigned)((c.n_pad + kDynSortedPad) / kGrp + c.n_pad / 64)); // the full step's waves, then the SAT-only segments
+    if (uni) hipLaunchKernelGGL(dyn_step_kernel<true>, grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
+    else hipLaunchKernelGGL(dyn_step_kernel<false>, grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
     return hipGetLastError();
 }
 

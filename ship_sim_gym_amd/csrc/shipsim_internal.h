@@ -32,10 +32,14 @@ enum {
 enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* contact hashes, polygon pairs */,
        DU_COUNT = kDynPairs + kPolyPairs };
 
-// The queue of the full dyn step is sorted by (steps since the reset, bank record): after a reset the traffic ships and goal
+// The queue of the full dyn step is sorted by (bank record, steps since the reset): after a reset the traffic ships and goal
 // bodies of an env replay a transient that depends on its world and age only (the player pushes nothing), so envs of one
-// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.
+// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.  The order is
+// MAP-MAJOR and every map's stretch of the sorted queue starts on a wave boundary (kDynGrp slots; the gaps hold -1): the
+// lanes of a wave of the full step all sit on one bank record, which it then keeps once per wave instead of once per lane.
 constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuckets * kDynMapBuckets;
+constexpr int kDynGrp = 48;       // envs per wave of the full step (shipsim_dynamics.hip: kGrp)
+constexpr int kDynSortedPad = kDynMapBuckets * kDynGrp; // slots of dyn_sorted beyond n_pad: every map's stretch rounded up to a wave
 constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
@@ -44,7 +48,7 @@ constexpr unsigned long long kDynSatOnly = ~0ull; // queue entry key of a restin
 __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 {
     const unsigned agek = (unsigned)(age < kDynAgeBuckets - 1 ? (age < 0 ? 0 : age) : kDynAgeBuckets - 1);
-    return agek * (unsigned)kDynMapBuckets + ((unsigned)map_id & (unsigned)(kDynMapBuckets - 1));
+    return ((unsigned)map_id & (unsigned)(kDynMapBuckets - 1)) * (unsigned)kDynAgeBuckets + agek;
 }
 // The sorted queue scatters the envs of a wave over the whole batch: gathered from the struct-of-arrays columns, an env's 75
 // body fields cost the wave 75 x 64 cache lines.  The full dyn step therefore keeps a ROW-MAJOR shadow of them, five 128-byte
@@ -93,11 +97,12 @@ struct DevCfg {
     // arrival number; dyn_sort_kernel turns it into dyn_sorted and counts it.
     int32_t *dyn_queue;
     unsigned *dyn_segcnt;         // [n_pad / 64] entries per segment; every producer writes every segment's count
-    unsigned *dyn_count;          // [0] length of dyn_sorted (dyn_sort_kernel adds, the step kernel zeroes); [kDynBucket0 ..) bucket counts
+    unsigned *dyn_count;          // [0] length of dyn_sorted incl. its gaps (dyn_sort_kernel writes, the step kernel zeroes); [kDynBucket0 ..) bucket counts
     unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
     double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2, for the step kernel's classification of resting envs
     double dyn_hull_r;                // the player's hull radius about its body position
-    int32_t *dyn_sorted;          // the queue ordered by bucket (dyn_sort_kernel): what the full dyn step walks
+    int32_t *dyn_sorted;          // [n_pad + kDynSortedPad] the queue ordered by bucket (dyn_sort_kernel), -1 in the gaps: what the full dyn
+                                  // step walks (and resets to -1 behind itself)
     double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
 };
 

@@ -47,11 +47,12 @@ def _compare_dyn(N, vec, ob, just_reset=None, atol=1e-9):
         np.testing.assert_allclose(g_g[alive, g], g_o[alive, g], atol=atol, rtol=0)
 
 
-@pytest.mark.parametrize("n,nb,K", [(4096, 10, 160), (777, 8, 120)])
-def test_config4_parity(n, nb, K):
+# (banks of more than 64 records: the full dyn step's waves no longer sit on ONE record each — its per-lane-planes variant)
+@pytest.mark.parametrize("n,nb,K,n_maps", [(4096, 10, 160, 64), (777, 8, 120, 64), (2048, 10, 100, 96)])
+def test_config4_parity(n, nb, K, n_maps):
     torch, O, N, ShipVecEnv = _mods()
     from helpers import oracle_cfg
-    vec = ShipVecEnv(n, n_beams=nb, n_maps=64, n_ships=4)
+    vec = ShipVecEnv(n, n_beams=nb, n_maps=n_maps, n_ships=4)
     ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
     np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
     _compare_dyn(N, vec, ob, atol=0)

@@ -12,5 +12,11 @@ import csv,glob
 for f in glob.glob("/tmp/c4p_$V/**/*kernel_stats.csv", recursive=True):
     for r in list(csv.DictReader(open(f)))[:4]:
         print("   %-58s calls %5s avg %8.1f us" % (r["Name"][:58], r["Calls"], float(r["AverageNs"]) / 1e3))
+# the full step launch by launch (the first ones after the reset step every env; later bursts = episodes still in phase)
+for f in glob.glob("/tmp/c4p_$V/**/*kernel_trace.csv", recursive=True):
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if "dyn_step_kernel" in r["Kernel_Name"])
+    if d:
+        u = [x[1] / 1e3 for x in d]
+        print("   dyn_step launches: median %.1f us; first 60:" % sorted(u)[len(u) // 2], " ".join("%.0f" % x for x in u[:60]))
 PY
 done

@@ -75,3 +75,23 @@ if ty[:, sel].max() > 0:
         print("   %-10s %8.0f %8.0f %8.0f   entered by %.2f of the waves" % (nm[i], np.median(v), np.percentile(v, 90), v.max(), (v > 0).mean()))
     heavy = st[5][sel] >= np.percentile(st[5][sel], 95)
     print("   slowest 5 %% of the waves: " + ", ".join("%s %.0f" % (nm[i], ty[i][sel][heavy].mean()) for i in range(5)))
+
+# which (age, world) make a wave slow?  Only the envs stepped by the LAST full step (not at rest now) carry stamps of one and
+# the same launch; their age at that step = step_count now (the step kernel that followed incremented it) - 1.
+mp = vec.field(N.F_MAP_ID).cpu().numpy() if hasattr(N, "F_MAP_ID") else None
+lastm = sel & (q == 0)
+print("envs in the last full step: %d" % lastm.sum())
+keys, inv = np.unique(tot[lastm], return_inverse=True)
+rw = []
+for w in range(len(keys)):
+    m = np.nonzero(lastm)[0][inv == w]
+    rw.append((keys[w], len(m), age[m].min(), age[m].max(), (mp[m].min() if mp is not None else -1), (mp[m].max() if mp is not None else -1),
+               st[9][m].max(), st[7][m].max(), st[8][m].max(), st[6][m].max(), (st[2] - st[1])[m][0], (st[4] - st[3])[m][0]))
+rw.sort()
+print("last step's waves: %d; slowest 14 and fastest 3: total, lanes, age min..max (now), map min..max, queries, gjk, epa, n_act, collide, solver" % len(rw))
+for r in rw[-14:] + rw[:3]:
+    print("   ", " ".join("%7.0f" % v for v in r))
+for lo, hi in ((1, 2), (2, 3), (3, 4), (4, 5), (5, 7), (7, 9), (9, 2000)):
+    v = [r[0] for r in rw if r[2] >= lo and r[3] < hi]
+    if v:
+        print("   waves with all lanes at age(now) in [%d,%d): %4d, total cycles median %.0f max %.0f" % (lo, hi, len(v), np.median(v), max(v)))

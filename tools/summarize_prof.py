@@ -26,10 +26,19 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
 print("== PMC (mean per dispatch of the step kernel) ==")
 for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
+    dur = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
         if "step_kernel" not in row.get("Kernel_Name", ""):
             continue
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if row.get("End_Timestamp"):
+            dur[row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if "SQ_WAVE_CYCLES" in acc and "SQ_WAVES" in acc and dur["SQ_WAVE_CYCLES"]:
+        # every wave of a launch is resident from its start to its end (one workgroup per CU, 4 waves per SIMD), SQ_WAVE_CYCLES
+        # counts in units of 4 cycles: wave-cycles * 4 / waves = shader cycles of the launch; / its duration in THIS pass = the
+        # shader clock the kernel actually ran at (the 2.4 GHz of the data sheet is the boost ceiling)
+        big["shader_clock_ghz"] = (sum(acc["SQ_WAVE_CYCLES"]) * 4.0 / sum(acc["SQ_WAVES"])) / (sum(dur["SQ_WAVE_CYCLES"]) / len(dur["SQ_WAVE_CYCLES"]))
+        print("shader clock during the launches of this pass: %.3f GHz" % big["shader_clock_ghz"])
     for k, v in acc.items():
         print("%-28s mean %.6g  (n=%d)   largest dispatch %.6g" % (k, sum(v) / len(v), len(v), max(v)))
         if k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
@@ -79,6 +88,8 @@ if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
     if "SQ_ACTIVE_INST_VALU" in big and "SQ_WAVE_CYCLES" in big:
         cj["valu_busy_frac_of_simd_cycles"] = big["SQ_ACTIVE_INST_VALU"] / (big["SQ_WAVE_CYCLES"] / 4.0)
         cj["wait_any_frac_of_wave_cycles"] = big.get("SQ_WAIT_ANY", 0) / big["SQ_WAVE_CYCLES"]
+    if "shader_clock_ghz" in big:
+        cj["shader_clock_ghz"] = big["shader_clock_ghz"]
     json.dump(cj, open(os.path.join(out, "counters.json"), "w"), indent=1)
     print("== counters.json ==")
     print(json.dumps(cj, indent=1))
