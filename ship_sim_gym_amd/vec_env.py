@@ -399,6 +399,21 @@ class ShipVecEnv(*_BASES):
         rollout loop sees them (train/random.py:14-27) — returns (obs [K, N, D], reward [K, N], done [K, N], flags [K, N])
         device tensors; `out` = a tuple of four such preallocated tensors (first dimension >= K, contiguous) to write
         into instead of allocating.  self.obs / reward / done / flags are left untouched in trajectory mode."""
+        if trajectory and out is not None:
+            # a buffer set seen before (the same tuple object, kept alive by the cache, so its id cannot have been recycled):
+            # one ctypes call with plain integers, like step_tensor — a 20-step launch is ~140 us, and everything the host does
+            # before the launch is GPU idle time inside a caller's timed region
+            plan = self.__dict__.setdefault("_traj_plans", {}).get(id(out))
+            if plan is not None and plan[0] is out:
+                K = actions_kn.shape[0]
+                _, fn, cur_stream, po, pr, pd, pf, cap, views = plan
+                if K <= cap and out[0].data_ptr() == po:
+                    if fn(self._h, actions_kn.data_ptr(), K, po, pr, pd, pf, self.num_envs, cur_stream(self.device).cuda_stream) == 0:
+                        v = views.get(K)
+                        if v is None:
+                            v = views[K] = tuple(t[:K] for t in out)
+                        return v
+                    # (an error — e.g. another device is current: the checked path below repeats the call and reports)
         torch = _torch()
         K = int(actions_kn.shape[0])
         if not trajectory:
@@ -427,6 +442,12 @@ class ShipVecEnv(*_BASES):
                                           n, self._stream())
         if rc:
             N.check(rc, self._h, "ssg_rollout_traj")
+        if isinstance(out, tuple):
+            plans = self.__dict__.setdefault("_traj_plans", {})
+            if len(plans) >= 8:  # (a handful of rotating buffer sets at most; the cache holds them alive)
+                plans.pop(next(iter(plans)))
+            plans[id(out)] = (out, N.lib().ssg_rollout_traj, torch.cuda.current_stream, to.data_ptr(), tr.data_ptr(), td.data_ptr(),
+                              tf.data_ptr(), min(int(t.shape[0]) for t in out), {})
         return to[:K], tr[:K], td[:K], tf[:K]
 
     def random_actions(self, seed, step0, K):
@@ -477,6 +498,7 @@ class ShipVecEnv(*_BASES):
         return self.step_wait()
 
     def close(self):
+        self.__dict__.pop("_traj_plans", None)  # (the cache holds the callers' trajectory buffers alive)
         if not self._closed and self._h:
             N.lib().ssg_destroy(self._h)
             self._h = None

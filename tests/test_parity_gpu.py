@@ -250,6 +250,34 @@ def test_trajectory_mode_other_paths_and_strides(torch_cuda, native):
     assert rc == -1 and b"step_stride_envs" in L.ssg_last_error(b._h)
 
 
+def test_trajectory_buffer_set_reused(torch_cuda, native):
+    """A caller's buffer set handed to rollout_tensor again (bench.py rotates a few): the second and later calls take the
+    lean path (cached pointers, one ctypes call) — same results as a twin env stepped one launch at a time, for different
+    K, including K longer than the buffers (falls back to the checked path, which refuses)."""
+    torch = torch_cuda
+    a, b = _vec(1500, n_maps=16, n_beams=8), _vec(1500, n_maps=16, n_beams=8)
+    a.reset_tensor(); b.reset_tensor()
+    n, D, cap = a.num_envs, a.states_history, 40
+    out = (torch.empty((cap, n, D), dtype=torch.float64, device=a.device), torch.empty((cap, n), dtype=torch.float64, device=a.device),
+           torch.empty((cap, n), dtype=torch.uint8, device=a.device), torch.empty((cap, n), dtype=torch.uint8, device=a.device))
+    acts = a.random_actions(77, 0, 200)
+    k0 = 0
+    for i, K in enumerate((40, 20, 40, 7, 33)):
+        to, tr, td, tf = b.rollout_tensor(acts[k0: k0 + K], trajectory=True, out=out)
+        assert to.shape[0] == K and to.data_ptr() == out[0].data_ptr()
+        if i >= 1:
+            assert id(out) in b._traj_plans and b._traj_plans[id(out)][0] is out
+        for k in range(K):
+            o, r, d, f = a.step_tensor(acts[k0 + k])
+            assert torch.equal(o, to[k]) and torch.equal(r, tr[k]) and torch.equal(d, td[k]) and torch.equal(f, tf[k]), (i, k)
+        k0 += K
+    assert torch.equal(a.state, b.state)
+    with pytest.raises(AssertionError):
+        b.rollout_tensor(acts[:41], trajectory=True, out=out)
+    b.close()
+    assert "_traj_plans" not in b.__dict__
+
+
 def test_shard_equivalence(torch_cuda, native):
     """N envs on one handle == the same envs split over two handles (env_id_base keyed), bitwise."""
     n = 1024
