@@ -117,9 +117,21 @@ def cpu_baseline(vec, seconds_target=10.0):
     t0 = time.perf_counter()
     done_steps = ob.rollout(12345, 0, K, n_threads=threads)
     dt = time.perf_counter() - t0
+    # "1 thread and os.cpu_count() threads" — the scalar figure on a ~3 s sample of the same stream
+    n1 = 1024
+    o1 = O.Batch(n1, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n1) % vec.n_maps)
+    o1.reset()
+    t1 = time.perf_counter()
+    o1.rollout(12345, 0, 50, n_threads=1)
+    K1 = max(50, min(100000, int(3.0 / max((time.perf_counter() - t1) / 50, 1e-9))))
+    o1.reset()
+    t1 = time.perf_counter()
+    s1 = o1.rollout(12345, 0, K1, n_threads=1)
+    d1 = time.perf_counter() - t1
     return {"value": done_steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": "%d envs x %d steps, 8-beam lidar, same 64-map bank and Philox action stream, OpenMP over envs, "
-                      "%.1f s" % (n, K, dt)}
+                      "%.1f s" % (n, K, dt),
+            "single_thread": {"value": s1 / d1, "cores": 1, "sample": "%d envs x %d steps, %.1f s" % (n1, K1, d1)}}
 
 
 def measured_copy_gbps(dev):

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ship_sim_gym_amd.vec_env import ShipVecEnv
 n = int(os.environ.get("SSG_N", "65536")); nb = int(os.environ.get("SSG_NB", "8"))
-vec = ShipVecEnv(n, n_maps=64, n_beams=nb)
+vec = ShipVecEnv(n, n_maps=64, n_beams=nb, bank_in_global=bool(int(os.environ.get("SSG_BIG", "0"))))  # SSG_BIG=1: bank gathered from L2, no LDS staging
 if os.environ.get("SSG_ABLATE"):  # timing-only (needs a -DSSG_ABLATION build)
     import ctypes as C
     from ship_sim_gym_amd import _native as N
