@@ -445,7 +445,9 @@ def main():
         other = {}
         if world == 1 and not args.no_single_step:
             # the policy-in-the-loop path: one ssg_step launch per step; median of 7 repeats of `ks` back-to-back steps
-            ks = min(max(K, 100), 500)
+            # (500 whatever --steps says: every repeat starts from an idle, synchronized GPU and pays ~80 us for it once —
+            # 0.8 us per step over 100 steps, 0.16 over 500; a trainer's stream of steps has no such restarts)
+            ks = 500
             a1 = vec.random_actions(777, 0, ks)
             rows = [a1[k] for k in range(ks)]  # (the row views are made outside the timed loop: it times launches, not slicing)
             step = vec.step_tensor

@@ -1025,7 +1025,27 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         ObsTile<NB> ot;
         ot.init(lane);
         constexpr int kObsPasses = (2 * F + ObsTile<NB>::CP - 1) / ObsTile<NB>::CP; // passes of the widest row
+        // A launch ends with the observer's rows of its LAST step (nobody is left to overlap them with).  Half of such a row
+        // is the previous frame, in this wave's registers since the step before: on the last step those columns go out
+        // EARLY, while the body role still integrates — speculatively, because an env that turns out to be done at this step
+        // shows a history of -1 instead (ShipEnv.reset); its lanes rewrite their 6 + NB doubles after the rendezvous.
+        // (Only when the previous frame is a whole number of column passes: 8 and 10 beams are.)
+        constexpr bool kSplitOk = (F % ObsTile<NB>::CP) == 0;
+        const bool split_last = kSplitOk && hist2 && c.history == 2 && !SSG_ABL(7);
         for (int k = 0; k < K; ++k) {
+            const bool early = split_last && (k == K - 1);
+            if constexpr (kSplitOk) {
+                if (early) {
+                    int tw = __builtin_amdgcn_readfirstlane(tl >> 6);
+                    int te0 = blockIdx.x * EPW + 64 * tw;
+                    asm volatile("" : "+s"(tw), "+s"(te0));
+                    // the other parity's result buffer: emptied by this wave a step ago, written again only after B(k)
+                    double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + ((k + 1) & 1) * lds_res_bytes(NB));
+                    double *__restrict__ ob = obs + ((size_t)te0 + (size_t)k * (size_t)traj) * (size_t)(2 * F);
+                    write_obs_tile<NB, true, 0, F / ObsTile<NB>::CP>(ot, colbuf, [&](int j) -> double { return pv[(j < F) ? j : 0]; }, ob,
+                                                                    min(64, c.n_envs - te0), lane);
+                }
+            }
             wait_pose(k);
             SSG_STAMP_K(0);
             const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl];
@@ -1116,7 +1136,17 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                     // (the result keys are in registers by now; in a single-step launch the lidar waves still read them for
                     // the sticky columns, and the other parity's buffer is free)
                     double *colbuf = reinterpret_cast<double *>((K == 1) ? res_k + lds_res_bytes(NB) : res_k);
-                    if (hist2)
+                    if (kSplitOk && early) {
+                        write_obs_tile<NB, true, kSplitOk ? F / ObsTile<NB>::CP : 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
+                            return nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
+                        if (__any(do_reset)) { // the history of an env that starts a new episode: -1 over what went out early
+                            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the early stores of these addresses have completed
+                            if (do_reset && lane < rows_live) {
+#pragma unroll
+                                for (int j = 0; j < F; ++j) st_out(&obase[(unsigned)(lane * 2 * F + j)], -1.0);
+                            }
+                        }
+                    } else if (hist2)
                         write_obs_tile<NB, true, 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
                             return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
                             obase, rows_live, lane);
