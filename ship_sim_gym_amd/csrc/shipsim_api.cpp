@@ -759,7 +759,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                                            static_cast<hipStream_t>(stream));
                 }
                 if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
-                if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
+                if (e != hipSuccess) {
+                    h->dyn_queue_valid = false; // (a sorted queue the full step never consumed must not survive: the next call starts over)
+                    return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
+                }
             }
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
                                             shift ? h->dev.obs2 : obs_at(k), rew_at(k), done_at(k), flags_at(k), 0,

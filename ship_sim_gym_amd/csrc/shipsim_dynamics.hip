@@ -804,13 +804,15 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
         return;
     }
-    const unsigned n_queued = min(*c.dyn_count, (unsigned)c.n_pad + (unsigned)kDynSortedPad);
-    if ((unsigned)blockIdx.x * (unsigned)kGrp >= n_queued) return; // wave-uniform: nothing queued for this workgroup
+    // The queue's length is not read: every slot the sort did not write holds -1 (a gap in front of the next map's stretch, or
+    // past the end: this kernel leaves -1 behind in what it read, ssg_step memsets the array whenever the host rebuilt the
+    // queue) — one memory round trip less at the head of every wave's chain.
     const unsigned slot = (unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane;
-    const bool in_queue = (lane < kGrp) & (slot < n_queued);
-    const int e_raw = in_queue ? c.dyn_sorted[slot] : -1; // -1: a gap in front of the next map's stretch
-    if (in_queue) c.dyn_sorted[slot] = -1;                // the next sort writes entries only
+    const bool in_queue = lane < kGrp;
+    const int e_raw = in_queue ? c.dyn_sorted[slot] : -1;
     const bool queued = (e_raw >= 0) & (e_raw < c.n_envs);
+    if (!__any(queued) && blockIdx.x != 0) return; // wave-uniform: nothing queued for this workgroup
+    if (queued) c.dyn_sorted[slot] = -1;           // the next sort writes entries only
     const int e = queued ? e_raw : 0;
     if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
         for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
@@ -1447,12 +1449,15 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         // (columns and row hold what was loaded: only the fields this step changed are stored — in the post-reset transient
         // that is ship 1 and whatever it shoves, not the 75 fields of the env)
         double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
+        // (one branch per BODY, not per field: a body either moved — nearly all of its fields differ — or it did not)
+        bool dfb = false;
 #pragma unroll
-        for (int f = 0; f < 9; ++f) {
-            const bool df = differs(v[f], tin[k][f]);
-            if (df | fresh) { t[(size_t)f * np] = v[f]; row[f] = v[f]; }
-            changed |= df;
+        for (int f = 0; f < 9; ++f) dfb |= differs(v[f], tin[k][f]);
+        if (dfb | fresh) {
+#pragma unroll
+            for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; row[f] = v[f]; }
         }
+        changed |= dfb;
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -1461,12 +1466,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const double v[DC_GOAL_COLS] = {BF(g, B_PX), BF(g, B_PY), BF(g, B_VX), BF(g, B_VY), BF(g, B_VBX), BF(g, B_VBY),
                                         BF(g, B_W), BF(g, B_WB)};
         double *row = c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g;
+        bool dfb = false;
 #pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS; ++f) {
-            const bool df = differs(v[f], gin[g][f]);
-            if (df | fresh) { q[(size_t)f * np] = v[f]; row[f] = v[f]; }
-            changed |= df;
+        for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= differs(v[f], gin[g][f]);
+        if (dfb | fresh) {
+#pragma unroll
+            for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; row[f] = v[f]; }
         }
+        changed |= dfb;
     }
     changed |= (live != live0) | (ain != aout);
     stamp(5);
