@@ -26,7 +26,8 @@ on device 0 and SSG_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow ca
 line's `data` field then says "TEST RUN ... timings meaningless".
 
 Timing: W untimed warm-up steps, then the K-step rollout is timed `--repeats` (default 5) times, every repeat
-bracketed by barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` is the
+bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's interval runs from the opening barrier + synchronize
+to its own closing synchronize; the closing barrier follows) and reduced with MAX over ranks; `value` is the
 MEDIAN repeat, all repeats are listed in `repeats_ms`.
 
 Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
@@ -240,9 +241,10 @@ def timed_rollouts(vec, K, W, R, use_dist, dev):
         vec.rollout_tensor(a, trajectory=True, out=out)  # exactly K steps: ceil(K / steps_per_launch) launches of the step kernel
         ev1.record()
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        walls.append(time.perf_counter() - t0)
+        t1 = time.perf_counter()  # this rank's K steps are complete; the job's time is the MAX over ranks (below), so the
+        if use_dist:              # closing barrier's own latency (an RCCL all-reduce: tens of us against a 150 us region at
+            dist.barrier()        # K = 20) is bracketing, not stepping, and stays outside the interval
+        walls.append(t1 - t0)
         evs.append(ev0.elapsed_time(ev1))
     if use_dist:
         t = torch.tensor(walls, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
