@@ -10,7 +10,8 @@ gen_goal_path incl. its RNG call order and `except` fallback / handle_discrete_a
 collision callbacks (game.py:140-153,185-195,232-349), LiDAR.query and Ship (models.py:39-76,87-146).  What they do
 NOT pin: Chipmunk2D's arithmetic, which under the stand-in is the oracle's own restatement ("parity unpinned").
 
-Scenarios: the eight of tools/capture_pymunk_golden.py x seeds 0..3 (random.seed(s); np.random.seed(s)) without traffic,
+Scenarios: the eight of tools/capture_pymunk_golden.py and two with HISTORY_SIZE 1 / 3, x seeds 0..3 (random.seed(s);
+np.random.seed(s)) without traffic,
 and six of them x seeds 0..1 with `env.game.add_default_traffic()` after every reset (BASELINE configs[3]).
 Per stream: the worlds the reference generated (river polygons handed to PolyEnv, goal centres), the reset observation
 of every episode, and (obs, reward, done) of every step; a done step is followed by env.reset() as a trainer would.
@@ -39,6 +40,9 @@ def scenarios():
     rng = np.random.RandomState(6)
     yield "random_actions", {}, [int(a) for a in rng.randint(0, 3, size=400)]
     yield "training_config", dict(speed=30, bounds=(1000, 1000)), fwd + [1, 0, 0, 2, 0, 0] * 10
+    # EnvConfig.HISTORY_SIZE other than the default 2: the deque of ship_env.py:50,100-113 (history of -1 after a reset)
+    yield "history_1", dict(history=1), ([1] * 2 + [0] * 7 + [2] * 4 + [0] * 7) * 6
+    yield "history_3", dict(history=3), [2, 2] + [0] * 100
 
 
 def run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed, traffic=False):
@@ -50,6 +54,7 @@ def run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed, traffic=False):
 
     class E(EnvConfig):
         MAX_STEPS = opts.get("max_steps", EnvConfig.MAX_STEPS)
+        HISTORY_SIZE = opts.get("history", EnvConfig.HISTORY_SIZE)
 
     random.seed(seed)
     np.random.seed(seed)
@@ -106,7 +111,7 @@ def main():
     # config 4: the same Python with env.game.add_default_traffic() after every reset; the stand-in's Space.step then runs the
     # oracle's full cpSpaceStep (contact solver for the traffic ships and goal bodies) on a shadow world
     for name, opts, actions in scenarios():
-        if name in ("rudder_only_max_steps", "training_config"):
+        if name in ("rudder_only_max_steps", "training_config", "history_1", "history_3"):
             continue
         for seed in range(2):
             r = run(ShipEnv, GameConfig, EnvConfig, opts, actions, seed, traffic=True)

@@ -31,7 +31,7 @@ def _cfg_of(z, name):
 
 def test_fixture_shape_and_coverage():
     z, names = _streams()
-    assert len(names) == 44  # eight scenarios x seeds 0..3, and six of them x seeds 0..1 with add_default_traffic()
+    assert len(names) == 52  # ten scenarios (two of them with HISTORY_SIZE 1 / 3) x seeds 0..3, and six x seeds 0..1 with add_default_traffic()
     assert sum("_traffic/" in n for n in names) == 12
     seen = {"collision": 0, "goal": 0, "max_steps": 0, "oob": 0, "episodes": 0, "steps": 0}
     for n in names:
@@ -42,7 +42,7 @@ def test_fixture_shape_and_coverage():
         assert obs.shape == (len(done), 16 * hist) and set(np.unique(rew)) <= {-1.0, -0.01, 1.0}
         seen["collision"] += int(col.sum()); seen["goal"] += int(goal.sum()); seen["episodes"] += int(done.sum())
         seen["steps"] += len(done)
-        x, y = obs[:, 16], obs[:, 17]
+        x, y = obs[:, 16 * (hist - 1)], obs[:, 16 * (hist - 1) + 1]  # the newest frame
         seen["oob"] += int(((x < 0) | (x > bounds[0]) | (y < 0) | (y > bounds[1])).sum())
         # the reward-overwrite quirk of determine_reward, as the reference itself produced it: an in-bounds collision that
         # reaches no goal is rewarded -0.01, not -1 (ship_env.py:66-77)
@@ -120,6 +120,7 @@ def test_hip_ship_env_facade_replays_the_reference_streams(native):
 
         class E(EnvConfig):
             MAX_STEPS = max_steps
+            HISTORY_SIZE = hist
 
         seed = int(n.rsplit("seed", 1)[1])
         random.seed(seed)
