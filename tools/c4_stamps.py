@@ -29,9 +29,7 @@ for i, nm in enumerate(names):
 print("total median %8.0f max %8.0f ; n_act hist" % (np.median(st[5][sel]), st[5][sel].max()), np.bincount(st[6][sel].astype(int)))
 print("per env: gjk iterations mean %.2f max %d | epa iterations mean %.2f max %d | narrowphase queries mean %.2f max %d" % (
     st[7][sel].mean(), st[7][sel].max(), st[8][sel].mean(), st[8][sel].max(), st[9][sel].mean(), st[9][sel].max()))
-w = st[7:10, :n].reshape(3, -1, 64)
-print("per wave (sum over the sites a wave enters is what it pays): max-lane gjk it %.1f, epa it %.1f, queries %.1f" % (
-    w[0].max(axis=1).mean(), w[1].max(axis=1).mean(), w[2].max(axis=1).mean()))
+# (per-wave figures: see the wave table below — waves are 48 envs of the SORTED queue, not 64 neighbours of the batch)
 
 pr = cols[DC_ARB + 180: DC_ARB + 186, :n].cpu().numpy()
 if pr[1][sel].max() > 0:
