@@ -73,3 +73,35 @@ def _imports_of(fn):
                 yield a.name
         elif isinstance(node, ast.ImportFrom):
             yield node.module or ""
+
+
+def test_product_fails_loudly_without_the_hip_library_or_a_device(tmp_path):
+    """No CPU fallback: a missing libshipsim.so is a ShipSimError naming the build command, and ShipVecEnv on a box without
+    a HIP device refuses (checked in a child process so that this process's loaded library is left alone)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ["SSG_LIB_PATH"] = %r
+from ship_sim_gym_amd import _native as N
+try:
+    N.lib()
+except N.ShipSimError as e:
+    assert "no CPU fallback" in str(e) and "build" in str(e), str(e)
+    print("MISSING_LIB_OK")
+import torch
+if not torch.cuda.is_available():
+    os.environ.pop("SSG_LIB_PATH")
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    try:
+        ShipVecEnv(4)
+    except N.ShipSimError as e:
+        assert "no CPU fallback" in str(e), str(e)
+        print("NO_DEVICE_OK")
+else:
+    print("NO_DEVICE_OK")  # (a GPU box: nothing to refuse)
+''' % (ROOT, str(tmp_path / "nowhere" / "libshipsim.so"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "MISSING_LIB_OK" in p.stdout and "NO_DEVICE_OK" in p.stdout, p.stdout
