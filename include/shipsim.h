@@ -160,6 +160,8 @@ const char *ssg_last_error(const ssg_handle *h);
 /* Replaces: ShipEnv.__init__ + ShipGame.__init__ (ship_env.py:23-48, game.py:32-58) and the pm.Space()/Body/
  * Poly construction inside them (game.py:269-270, models.py:87-111,153-196).  Host only: no GPU work. */
 int ssg_create(const ssg_config *cfg, ssg_handle **out);
+/* Replaces: the garbage collection of a ShipEnv and its pm.Space (the reference never closes one explicitly:
+ * ship_env.py:23-48 creates, nothing destroys).  Frees the handle only — the state blob and the bank are the caller's. */
 int ssg_destroy(ssg_handle *h);
 
 /* Fill *cfg with the reference defaults (config.py:8-24, models.py:6,29,87-110, game.py:17,82,274-275). */
@@ -170,6 +172,10 @@ int ssg_config_set_ship(ssg_config *cfg, double width_scale, double height_scale
 
 /* ---------------------------------------------------------------------------------------------------
  * Memory binding (caller-owned device memory)
+ * What the reference keeps inside pymunk objects — cpBody position / velocity / angle per ship (models.py:87-111), the
+ * goal list and its bodies (game.py:77-95), LiDAR.vals (models.py:36), ShipEnv.step_count / cumulative_reward / states
+ * (ship_env.py:171-184) — lives here as struct-of-arrays columns in ONE blob the caller allocates; these three calls have
+ * no reference counterpart beyond that.
  * ------------------------------------------------------------------------------------------------- */
 int ssg_state_nbytes(const ssg_handle *h, size_t *nbytes);
 /* offset (bytes) of a field's first column in the blob, element size, columns per env-field. */
@@ -261,7 +267,8 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
  * the records on the host and compare bit for bit.  NOT seed-compatible with the reference's Mersenne-Twister draws. */
 int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *dev_raw, void *stream);
 
-/* Config 4 only.  The traffic ships and goal bodies of an env whose space has reached a fixed point of cpSpaceStep are
+/* Config 4 only; no reference counterpart (writing `ship.body.position` on a pymunk body, game.py:117-131, needs no
+ * announcement there).  The traffic ships and goal bodies of an env whose space has reached a fixed point of cpSpaceStep are
  * not stepped again until something changes (SSG_F_DYN_FLAGS bit 2).  The library sees resets, goal removals and bank
  * changes itself; a caller that WRITES the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns (tests, scenario set-up) tells it
  * with this call.  dev_mask: u8[n_envs], non-zero = invalidate; NULL = all envs. */
@@ -274,7 +281,7 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
  * ship_env.py:18); not a hot path. */
 int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream);
 
-/* Inspection aid: how ssg_set_map_bank laid the step kernel out for this handle — envs per workgroup (256, 128 or 64: halved
+/* Inspection aid (no reference counterpart): how ssg_set_map_bank laid the step kernel out for this handle — envs per workgroup (256, 128 or 64: halved
  * until the staged bank fits the CU's 160 KiB of LDS beside the exchange and lidar buffers), whether the bank is staged in LDS
  * (0 = gathered from L2 / HBM) and the dynamic LDS bytes per workgroup. */
 int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int *bank_in_lds, size_t *lds_bytes);
@@ -293,10 +300,14 @@ int ssg_host_moment_for_poly(double mass, int count, const double *verts_xy, dou
 /* Replaces Space.segment_query((W/2,y),(edge,y),10,filter)[0] over the two bank shapes (game.py:322-323):
  * hulls are the records' planes.  hit=0 -> the reference's IndexError fallback applies. */
 int ssg_host_goal_x_range(const double *map_record, double width, double y, double *lo, double *hi, int *hit);
-/* Builds one bank record from the two raw 12-gons of gen_river_poly and the goal centres. */
+/* Builds one bank record from the two raw 12-gons of gen_river_poly (game_map.py:22-73) and the goal centres of
+ * gen_goal_path (game.py:300-330): what PolyEnv.__init__ (models.py:153-196: pm.Poly hulls the points, one static shape per
+ * bank) and add_goal (game.py:77-95) leave in the pm.Space at reset. */
 int ssg_host_build_map(const double *left_xy, int n_left, const double *right_xy, int n_right,
                        const double *goals_xy, int n_goals, double spawn_x, double spawn_y, double *record_out);
-/* Generic fat/thin segment query against one hull of a record (side 0 = left, 1 = right); cpShapeSegmentQuery. */
+/* Generic fat/thin segment query against one hull of a record (side 0 = left, 1 = right): cpShapeSegmentQuery as reached by
+ * Shape.segment_query (the lidar beams, models.py:67, radius 0) and Space.segment_query (the goal path's fat rays,
+ * game.py:322-323, radius 10). */
 int ssg_host_segment_query(const double *map_record, int side, double ax, double ay, double bx, double by,
                            double radius, int *hit, double *px, double *py, double *alpha);
 

@@ -171,3 +171,22 @@ def test_worldgen_reset_sequence_matches_oracle_and_rng_order(native, oracle):
         obs0 = w.reset(p2[0], p2[1], goals)
         assert (rec[native.MAP_OFF_SPAWN_GOAL], rec[native.MAP_OFF_SPAWN_GOAL + 1]) == (obs0[20], obs0[21])
         np.testing.assert_array_equal(rec[native.MAP_OFF_GOALS:native.MAP_OFF_GOALS + 10], goals.reshape(-1))
+
+
+def test_every_entry_point_cites_what_it_replaces():
+    """include/shipsim.h: every exported function's comment names the reference interface it replaces (file:line), or says
+    that the reference has no counterpart (memory binding, diagnostics)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "shipsim.h")).read()
+    decls = [(m.start(), m.group(1)) for m in re.finditer(r'^\s*(?:int|const char\s*\*)\s+(ssg_\w+)\s*\(', src, flags=re.M)]
+    assert len(decls) >= 26
+    section = src.index("Memory binding (caller-owned device memory)")
+    assert re.search(r'\w+\.py:\d+', src[section: section + 900])          # the section's own comment cites the reference's state
+    prev, missing = 0, []
+    for pos, name in decls:
+        chunk = src[prev:pos]
+        ok = re.search(r'\w+\.py:\d+', chunk) or re.search(r'no reference counterpart|Replaces nothing', chunk, flags=re.I)
+        if not ok and name not in ("ssg_state_field", "ssg_bind_state", "ssg_abi_version", "ssg_strerror", "ssg_last_error"):
+            missing.append(name)
+        prev = pos
+    assert not missing, missing
