@@ -42,6 +42,8 @@ Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
   other_configs — informational (N=1 only, outside the timed region): BASELINE configs[1] (4 096 envs, 10 beams),
                   configs[3] (65 536 envs x 4 ships), the per-GPU share of configs[4], configs[2] with a brand-new world
                   per episode (map_mode="fresh_device"), and the one-launch-per-step (policy-in-the-loop) path.
+  config.ranks  — per rank: device, HIP ordinal, the RCCL world size it saw, its env range and the HSA / HIP / NCCL / RCCL /
+                  rendezvous environment it ran under (a rank that cannot join the job prints the same to stderr, exit 4).
   cpu_baseline  — the CPU oracle ("port": our C restatement of the reference path, NOT pymunk) timed on this box's
                   host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -203,15 +205,39 @@ def free_port():
     return p
 
 
-def launch_ranks(args, argv):
-    """--gpus N > 1 without a torch.distributed environment: start N ranks as a CHILD job and return its exit code.
-    This process never touches a GPU (no HIP call, no torch.cuda query), so nothing GPU-initialised is re-executed."""
+ENV_PREFIXES = ("HSA_", "HIP_", "ROCR_", "NCCL_", "RCCL_", "GPU_", "MASTER_", "TORCH_NCCL", "CUDA_VISIBLE")
+ENV_NAMES = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "SSG_BENCH_SHARE_DEVICE", "SSG_BENCH_BACKEND")
+
+
+def comm_env(env=None):
+    """The environment variables that decide how a rank finds its GPU and its peers (HSA / HIP / ROCR / NCCL / RCCL /
+    rendezvous): recorded per rank in the JSON line and printed when a rank fails, so that a failed multi-GPU run can be
+    diagnosed from its tail."""
+    env = os.environ if env is None else env
+    return {k: env[k] for k in sorted(env) if k.startswith(ENV_PREFIXES) or k in ENV_NAMES}
+
+
+def rank_command(args, argv, port=None):
+    """(command line, environment) of the N-rank child job: what the driver itself runs for N > 1."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
     env["MASTER_ADDR"] = "127.0.0.1"
+    argv = [a for a in argv if a != "--dry-launch"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port() if port is None else port), os.path.abspath(__file__)] + argv
+    return cmd, env
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a torch.distributed environment: start N ranks as a CHILD job and return its exit code.
+    This process never touches a GPU (no HIP call, no torch.cuda query), so nothing GPU-initialised is re-executed."""
+    cmd, env = rank_command(args, argv)
+    if args.dry_launch:  # what WOULD be started, as one JSON line; nothing runs, no GPU is touched
+        print(json.dumps({"dry_launch": True, "n_ranks": args.gpus, "cmd": cmd, "env": comm_env(env),
+                          "refusals": {"2": "WORLD_SIZE != --gpus", "3": "fewer HIP devices than ranks"}}))
+        return 0
     sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.write("bench.py: comm env of the ranks: %s\n" % json.dumps(comm_env(env)))
     return subprocess.call(cmd, env=env)
 
 
@@ -267,6 +293,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C4 timings")
     ap.add_argument("--c5-full", action="store_true", help="also time BASELINE configs[4]'s per-rank share (131 072 envs, 10 beams) "
                     "on every rank and report other_configs.c5_full (automatic when --gpus 8)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1: print the N-rank child command line and its "
+                    "communication environment as one JSON line and exit without starting anything")
     ap.add_argument("--workload", choices=("c3", "c4"), default="c3",
                     help="c3 (default, the BASELINE metric's config): 1 ship, 8 beams; c4: BASELINE configs[3], 4 ships "
                          "(traffic + dynamic goals + contact solver), 10 beams — informational, not the headline line")
@@ -307,11 +335,23 @@ def main():
     dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(backend=backend)
-        world = dist.get_world_size()
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group(backend=backend)
+            world = dist.get_world_size()
+            if world != args.gpus:
+                raise RuntimeError("the process group has %d ranks, --gpus says %d" % (world, args.gpus))
+            # one small collective before anything is timed: a rank that cannot reach its peers fails HERE, with its environment
+            probe = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError("all_reduce over %d ranks returned %r" % (world, probe.item()))
+        except Exception as ex:
+            sys.stderr.write("bench.py: rank %d/%d (device %d of %d, backend %s) could not join the job: %r\n"
+                             "bench.py: comm env: %s\n" % (rank, args.gpus, local_rank, n_dev, backend, ex, json.dumps(comm_env())))
+            sys.exit(4)
 
     n = args.envs_per_gpu
     c4 = args.workload == "c4"
@@ -341,7 +381,7 @@ def main():
     wall, ev_ms = walls[med], evs[med]
 
     ranks_info = [{"rank": rank, "device": torch.cuda.get_device_name(dev), "hip_device": local_rank, "rccl_world_size": world,
-                   "envs": n, "env_id_base": rank * n}]
+                   "backend": (backend if use_dist else None), "envs": n, "env_id_base": rank * n, "env": comm_env()}]
     if use_dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, ranks_info[0])

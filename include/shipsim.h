@@ -269,9 +269,13 @@ int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *d
 
 /* Config 4 only; no reference counterpart (writing `ship.body.position` on a pymunk body, game.py:117-131, needs no
  * announcement there).  The traffic ships and goal bodies of an env whose space has reached a fixed point of cpSpaceStep are
- * not stepped again until something changes (SSG_F_DYN_FLAGS bit 2).  The library sees resets, goal removals and bank
- * changes itself; a caller that WRITES the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns (tests, scenario set-up) tells it
- * with this call.  dev_mask: u8[n_envs], non-zero = invalidate; NULL = all envs. */
+ * not stepped again until something changes (SSG_F_DYN_FLAGS bit 2), and WHICH envs the next step's dyn kernels visit is
+ * decided at the end of each step from the player state the step kernel holds in registers.  The library sees resets, goal
+ * removals and bank changes itself; a caller that WRITES ANY state column of a config-4 handle between two steps — the
+ * SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns, but also the player's own SSG_F_X .. SSG_F_W, SSG_F_GOAL_MASK, SSG_F_STEP_COUNT
+ * or SSG_F_MAP_ID (scenario set-up, curriculum placement, tests) — tells it with this call: the queue of the next step is then
+ * rebuilt from the columns (a resting env whose player was moved next to a parked ship gets collide_ship's test again).
+ * dev_mask: u8[n_envs], non-zero = also clear the env's rest bit and refresh its row-major shadow; NULL = all envs. */
 int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
 
 /* Replaces: ShipGame.render + ShipGame.get_screen (game.py:133-138,197-229) for ONE env: an RGB frame of `width` x

@@ -298,6 +298,14 @@ class Batch:
         lib().ora_world_poke_traffic(lib().ora_world_at(self._p, int(i)), int(k),
                                      _dp(np.array([x, y, angle, vx, vy, w], dtype=np.float64)))
 
+    def poke_player(self, i, x, y, vx=0.0, vy=0.0):
+        """Move env i's player body (position, velocity; angle and spin kept) as a test writes the SSG_F_X.. columns."""
+        w = lib().ora_world_at(self._p, int(i))
+        b = Body()
+        lib().ora_world_get_ship(w, C.byref(b))
+        b.p = V2(float(x), float(y)); b.v = V2(float(vx), float(vy))
+        lib().ora_world_set_ship(w, C.byref(b))
+
     def counters(self):
         """ORA_VAR_CHECK_SAT census summed over the batch: player pairs checked, SAT != cpCollide(player, other),
         SAT != cpCollide(other, player), pairs with |signed distance| < 1e-9."""

@@ -30,6 +30,7 @@ Two map modes:
 import ctypes as C
 import inspect
 import math
+import warnings
 
 import numpy as np
 
@@ -219,14 +220,16 @@ class ShipVecEnv(*_BASES):
         pin) none: each is called with the KEYWORDS its signature names, never positionally, and our own attributes are
         re-asserted afterwards so that no base can have swapped them."""
         mine = {"num_envs": self.num_envs, "observation_space": self.observation_space, "action_space": self.action_space}
-        for base in type(self).__mro__[1:]:
+        # (the bases of ShipVecEnv itself, not of type(self): for a subclass the latter would list ShipVecEnv and re-enter
+        # this constructor)
+        for base in ShipVecEnv.__mro__[1:]:
             if base is object or "__init__" not in vars(base):
                 continue
             try:
                 params = inspect.signature(base.__init__).parameters
                 base.__init__(self, **{k: v for k, v in mine.items() if k in params})
-            except Exception:
-                pass
+            except TypeError as ex:  # a signature this dispatch does not know: say so, keep our own attributes
+                warnings.warn("ShipVecEnv: %s.__init__ not called (%s)" % (base.__name__, ex))
         self.num_envs, self.observation_space, self.action_space = mine["num_envs"], mine["observation_space"], mine["action_space"]
 
     @classmethod
@@ -316,7 +319,9 @@ class ShipVecEnv(*_BASES):
         return epw.value, bool(lds.value), nb.value
 
     def field(self, fid):
-        """Typed torch view [n_columns, num_envs] (or [num_envs]) into the state blob."""
+        """Typed torch view [n_columns, num_envs] (or [num_envs]) into the state blob.  Config 4 (n_ships = 4): after WRITING
+        any column through such a view — the player's pose as much as the traffic / goal bodies — call wake_dynamics():
+        which envs the dyn kernels visit next step was decided from the state the last step ended with (ssg_dyn_invalidate)."""
         torch = _torch()
         off, es, nc, stride = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t()
         N.check(N.lib().ssg_state_field(self._h, fid, C.byref(off), C.byref(es), C.byref(nc), C.byref(stride)), self._h,
@@ -329,8 +334,10 @@ class ShipVecEnv(*_BASES):
         return v[0] if nc.value == 1 else v
 
     def wake_dynamics(self, mask=None):
-        """Config 4: call after writing the SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns through field() — envs whose bodies
-        had come to rest are otherwise not stepped (ssg_dyn_invalidate).  mask: uint8 device tensor [num_envs] or None."""
+        """Config 4: call after writing ANY state column through field() — the traffic / goal-body columns (envs whose
+        bodies had come to rest are otherwise not stepped) and the player's own columns (a resting env whose player was moved
+        next to a parked ship is otherwise not tested against it): ssg_dyn_invalidate.  mask: uint8 device tensor [num_envs]
+        (envs whose rest bit is cleared) or None = all; the next step's queue is rebuilt from the columns either way."""
         with _torch().cuda.device(self.device):
             mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
             N.check(N.lib().ssg_dyn_invalidate(self._h, mp, self._stream()), self._h, "ssg_dyn_invalidate")
@@ -400,19 +407,19 @@ class ShipVecEnv(*_BASES):
         device tensors; `out` = a tuple of four such preallocated tensors (first dimension >= K, contiguous) to write
         into instead of allocating.  self.obs / reward / done / flags are left untouched in trajectory mode."""
         if trajectory and out is not None:
-            # a buffer set seen before (the same tuple object, kept alive by the cache, so its id cannot have been recycled):
-            # one ctypes call with plain integers, like step_tensor — a 20-step launch is ~140 us, and everything the host does
-            # before the launch is GPU idle time inside a caller's timed region
-            plan = self.__dict__.setdefault("_traj_plans", {}).get(id(out))
-            if plan is not None and plan[0] is out:
+            # a buffer set seen before: one ctypes call with plain integers, like step_tensor — a 20-step launch is ~140 us, and
+            # everything the host does before the launch is GPU idle time inside a caller's timed region.  The cache holds
+            # POINTERS and shapes only, never the tensors (a caller's `del bufs` really frees them), and a hit needs all four
+            # buffers to sit where they sat when the plan was made, with the shapes checked then.
+            po = out[0].data_ptr()
+            plan = self.__dict__.setdefault("_traj_plans", {}).get(po)
+            if plan is not None:
                 K = actions_kn.shape[0]
-                _, fn, cur_stream, po, pr, pd, pf, cap, views = plan
-                if K <= cap and out[0].data_ptr() == po:
+                fn, cur_stream, pr, pd, pf, cap, shp = plan
+                if (K <= cap and out[1].data_ptr() == pr and out[2].data_ptr() == pd and out[3].data_ptr() == pf
+                        and tuple(out[0].shape) == shp and out[1].shape[0] == shp[0] and out[2].shape[0] == shp[0] and out[3].shape[0] == shp[0]):
                     if fn(self._h, actions_kn.data_ptr(), K, po, pr, pd, pf, self.num_envs, cur_stream(self.device).cuda_stream) == 0:
-                        v = views.get(K)
-                        if v is None:
-                            v = views[K] = tuple(t[:K] for t in out)
-                        return v
+                        return out[0][:K], out[1][:K], out[2][:K], out[3][:K]  # (sliced after the launch: the GPU is already busy)
                     # (an error — e.g. another device is current: the checked path below repeats the call and reports)
         torch = _torch()
         K = int(actions_kn.shape[0])
@@ -428,6 +435,7 @@ class ShipVecEnv(*_BASES):
             return self.obs, self.reward, self.done, self.flags
         n, D = self.num_envs, self.states_history
         with torch.cuda.device(self.device):
+            caller_out = out is not None
             if out is None:
                 out = (torch.empty((K, n, D), dtype=torch.float64, device=self.device),
                        torch.empty((K, n), dtype=torch.float64, device=self.device),
@@ -442,13 +450,18 @@ class ShipVecEnv(*_BASES):
                                           n, self._stream())
         if rc:
             N.check(rc, self._h, "ssg_rollout_traj")
-        if isinstance(out, tuple):
-            plans = self.__dict__.setdefault("_traj_plans", {})
-            if len(plans) >= 8:  # (a handful of rotating buffer sets at most; the cache holds them alive)
-                plans.pop(next(iter(plans)))
-            plans[id(out)] = (out, N.lib().ssg_rollout_traj, torch.cuda.current_stream, to.data_ptr(), tr.data_ptr(), td.data_ptr(),
-                              tf.data_ptr(), min(int(t.shape[0]) for t in out), {})
+        plans = self.__dict__.setdefault("_traj_plans", {})
+        if len(plans) >= 8:  # (a handful of rotating buffer sets at most)
+            plans.pop(next(iter(plans)))
+        if caller_out:
+            plans[to.data_ptr()] = (N.lib().ssg_rollout_traj, torch.cuda.current_stream, tr.data_ptr(), td.data_ptr(), tf.data_ptr(),
+                                min(int(t.shape[0]) for t in out), tuple(to.shape))
         return to[:K], tr[:K], td[:K], tf[:K]
+
+    def clear_traj_cache(self):
+        """Forget the cached launch plans of rollout_tensor(trajectory=True, out=...).  They hold no tensors (pointers and
+        shapes only), so this is never needed to free memory; it exists for callers that recycle addresses deliberately."""
+        self.__dict__.pop("_traj_plans", None)
 
     def random_actions(self, seed, step0, K):
         """int32 [K, N] Philox action stream keyed by (seed, step, global env id), generated on the device."""
@@ -498,7 +511,7 @@ class ShipVecEnv(*_BASES):
         return self.step_wait()
 
     def close(self):
-        self.__dict__.pop("_traj_plans", None)  # (the cache holds the callers' trajectory buffers alive)
+        self.__dict__.pop("_traj_plans", None)
         if not self._closed and self._h:
             N.lib().ssg_destroy(self._h)
             self._h = None

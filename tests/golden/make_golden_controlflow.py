@@ -24,6 +24,7 @@ from contextlib import redirect_stdout
 
 import numpy as np
 
+SCOPE = ("scope: PYTHON LAYER ONLY. Streams recorded by executing the reference's ship_env.py / game.py / models.py under stand-in pymunk / pygame / gym modules whose physics IS this repository's CPU oracle (oracle/ssg_oracle.c, ssg_dynamics.c). They pin action decoding, reward / done order, the history deque, lidar stickiness, RNG call order. They are CIRCULAR for every Chipmunk2D computation (integrator, segment queries, narrowphase, the config-4 contact solver) and are NOT Chipmunk parity evidence.")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REFERENCE = os.environ.get("SHIP_SIM_GYM", "/root/reference")
@@ -120,8 +121,10 @@ def main():
             n_steps += len(actions)
             n_done += int(r["done"].sum())
     out = os.path.join(HERE, "ref_controlflow.npz")
+    n_arrays = len(data)
+    data["__scope__"] = np.array(SCOPE)  # what these streams do and do not pin, carried inside the fixture
     np.savez_compressed(out, **data)
-    print("wrote %s: %d streams, %d steps, %d episode ends, %d bytes" % (out, len(data) // 11, n_steps, n_done, os.path.getsize(out)))
+    print("wrote %s: %d streams, %d steps, %d episode ends, %d bytes" % (out, n_arrays // 11, n_steps, n_done, os.path.getsize(out)))
 
 
 if __name__ == "__main__":

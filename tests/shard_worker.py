@@ -53,7 +53,8 @@ def main():
              bank=vec.bank.cpu().numpy(), x=vec.field(0).cpu().numpy(),
              local=np.array([local["sum_return"], local["sum_length"], local["episodes"], local["goals_hit"]]),
              glob=np.array([glob["sum_return"], glob["sum_length"], glob["episodes"], glob["goals_hit"]]),
-             backend=np.array([1 if use_rccl else 0]))
+             backend=np.array([1 if use_rccl else 0]), n_dev=np.array([n_dev]),
+             seen_world=np.array([dist.get_world_size()]), seen_backend=np.array(dist.get_backend()))
     dist.barrier()
     dist.destroy_process_group()
     vec.close()

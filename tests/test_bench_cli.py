@@ -1,5 +1,6 @@
 """bench.py's command-line contract that can be checked without a GPU: `--gpus N` launches N ranks itself, the
 parent touches no GPU, a rank refuses a mismatching WORLD_SIZE, and a failing rank makes the launcher exit non-zero."""
+import json
 import os
 import subprocess
 import sys
@@ -35,3 +36,29 @@ def test_parent_mode_never_imports_torch_cuda_state():
     src = open(BENCH).read().split("def main():", 1)[1]
     head = src.split("import torch", 1)[0]
     assert "launch_ranks(args" in head, "the N-rank launcher must run before torch is imported"
+
+
+def test_dry_launch_shows_the_child_job_and_starts_nothing():
+    """`--gpus N --dry-launch`: one JSON line with the exact N-rank command (torch.distributed.run, one process per GPU,
+    127.0.0.1 rendezvous, the caller's own flags passed through) and the communication environment the ranks would get
+    (HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC); exit 0, nothing launched."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-launch"], capture_output=True,
+                       text=True, timeout=120, env=_env(NCCL_DEBUG="INFO"))
+    assert p.returncode == 0, p.stderr
+    assert "launching" not in p.stderr
+    j = json.loads(p.stdout.strip())
+    cmd = j["cmd"]
+    assert j["dry_launch"] and j["n_ranks"] == 8
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(BENCH) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "20", "--warmup", "5"]          # --dry-launch itself is not passed on
+    assert j["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and j["env"]["MASTER_ADDR"] == "127.0.0.1" and j["env"]["NCCL_DEBUG"] == "INFO"
+    assert set(j["refusals"]) == {"2", "3"}
+
+
+def test_failing_rank_prints_its_comm_env():
+    # a rank whose device is missing says which device it wanted; the launcher's stderr carries the ranks' comm env
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=600, env=_env())
+    assert p.returncode != 0 and "comm env of the ranks" in p.stderr and "HSA_ENABLE_IPC_MODE_LEGACY" in p.stderr

@@ -191,6 +191,53 @@ def test_config4_rest_bit_and_poke_at_rest():
     vec.close()
 
 
+def test_config4_player_moved_next_to_parked_ship():
+    """Which envs the dyn kernels visit is decided at the end of a step from the player state the step kernel holds in
+    registers: a caller that moves the PLAYER of a resting env (SSG_F_X .. SSG_F_VY) next to a parked ship must announce it
+    (wake_dynamics / ssg_dyn_invalidate, include/shipsim.h) — then collide_ship (game.py:232-241) fires as in the oracle;
+    masked form: only the written envs lose their rest bit."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    n = 512
+    vec = ShipVecEnv(n, n_maps=32, n_ships=4, auto_reset=True)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    vec.reset_tensor(); ob.reset()
+    ones = torch.ones(n, dtype=torch.int32, device=vec.device)   # rudder only: nobody moves, every space settles
+    for k in range(14):
+        vec.step_tensor(ones)
+        ob.step(np.ones(n, dtype=np.int32))
+    assert ((vec.field(N.F_DYN_FLAGS).cpu().numpy() & 4) != 0).mean() > 0.8
+    F = 6 + vec.cfg.n_beams
+    for rnd, masked in enumerate((False, True)):
+        # every 2nd env's player onto ship 2 (parked at (300, 200), hull 15 x 30), every 5th well clear of everything
+        hit = np.arange(rnd, n, 2); far = np.setdiff1d(np.arange(0, n, 5), hit)
+        X, Y, VX, VY = vec.field(N.F_X), vec.field(N.F_Y), vec.field(N.F_VX), vec.field(N.F_VY)
+        hi, fi = torch.as_tensor(hit, device=vec.device), torch.as_tensor(far, device=vec.device)
+        X[hi] = 292.0; Y[hi] = 190.0; VX[hi] = 0.0; VY[hi] = 0.0
+        X[fi] = 350.0; Y[fi] = 60.0; VX[fi] = 0.0; VY[fi] = 0.0
+        for e in hit: ob.poke_player(int(e), 292.0, 190.0)
+        for e in far: ob.poke_player(int(e), 350.0, 60.0)
+        if masked:
+            m = torch.zeros(n, dtype=torch.uint8, device=vec.device); m[hi] = 1; m[fi] = 1
+            vec.wake_dynamics(m)
+        else:
+            vec.wake_dynamics()
+        for k in range(3):
+            obs, rew, done, flags = vec.step_tensor(ones)
+            r_obs, r_rew, r_done = ob.step(np.ones(n, dtype=np.int32))
+            g_done, g_flags = done.cpu().numpy(), flags.cpu().numpy()
+            np.testing.assert_array_equal(g_done, r_done, err_msg="round %d step %d" % (rnd, k))
+            np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
+            if k == 0:
+                assert r_done[hit].all() and ((g_flags[hit] & N.EV_COLLIDING) != 0).all() and not r_done[far].any()
+                # the newest frame agrees everywhere; the OLDER frame of a moved env is whatever its columns held (the oracle's
+                # deque still holds the frame from before the move)
+                np.testing.assert_allclose(obs.cpu().numpy()[:, F:], r_obs[:, F:], atol=1e-9, rtol=0)
+            else:
+                np.testing.assert_allclose(obs.cpu().numpy(), r_obs, atol=1e-9, rtol=0)
+    vec.close()
+
+
 def test_config4_curriculum_maps():
     """BASELINE configs[3] in full: 4 ships AND curriculum maps — a lesson change installs the next river width's bank
     (wider banks: traffic ship 1 starts deeper inside the left one) and resets; parity on the new bank."""

@@ -20,8 +20,13 @@ ATOL = 1e-5  # north_star tolerance (HIP path); the oracle replay is held to 1e-
 
 def _streams():
     z = np.load(PATH)
-    names = sorted({k.rsplit("/", 1)[0] for k in z.files})
+    names = sorted({k.rsplit("/", 1)[0] for k in z.files if "/" in k})
     return z, names
+
+
+# every assertion message below carries this: a failure here is a failure of the Python layer's restatement, and a pass says
+# nothing about Chipmunk2D (the recorded physics is the oracle's own)
+CAVEAT = " [control-flow golden: python layer only, physics = oracle stand-in, not Chipmunk parity evidence]"
 
 
 def _cfg_of(z, name):
@@ -31,6 +36,8 @@ def _cfg_of(z, name):
 
 def test_fixture_shape_and_coverage():
     z, names = _streams()
+    scope = str(z["__scope__"])  # the fixture says itself what it pins
+    assert "PYTHON LAYER ONLY" in scope and "NOT Chipmunk parity evidence" in scope
     assert len(names) == 52  # ten scenarios (two of them with HISTORY_SIZE 1 / 3) x seeds 0..3, and six x seeds 0..1 with add_default_traffic()
     assert sum("_traffic/" in n for n in names) == 12
     seen = {"collision": 0, "goal": 0, "max_steps": 0, "oob": 0, "episodes": 0, "steps": 0}
@@ -71,11 +78,11 @@ def test_oracle_world_replays_the_reference_streams(oracle):
             if ep + 1 < len(starts) and starts[ep + 1] == k:
                 ep += 1
                 o0 = w.reset(polys[ep][0], polys[ep][1], goals[ep])
-                np.testing.assert_allclose(o0, reset_obs[ep], rtol=0, atol=1e-9, err_msg="%s reset %d" % (n, ep))
+                np.testing.assert_allclose(o0, reset_obs[ep], rtol=0, atol=1e-9, err_msg="%s reset %d" % (n, ep) + CAVEAT)
             o, r, d = w.step(int(a))
             err = float(np.max(np.abs(o - z[n + "/obs"][k])))
-            assert err <= 1e-9, "%s step %d: obs differ by %g" % (n, k, err)
-            assert r == z[n + "/reward"][k] and d == bool(z[n + "/done"][k]), "%s step %d" % (n, k)
+            assert err <= 1e-9, "%s step %d: obs differ by %g" % (n, k, err) + CAVEAT
+            assert r == z[n + "/reward"][k] and d == bool(z[n + "/done"][k]), "%s step %d" % (n, k) + CAVEAT
             pk = w.peek()
             assert bool(pk["colliding"]) == bool(z[n + "/colliding"][k]) and bool(pk["goal_reached"]) == bool(z[n + "/goal_reached"][k])
             worst = max(worst, err)
@@ -96,8 +103,8 @@ def test_host_worldgen_draws_the_worlds_the_reference_drew(native):
         worldgen.generate_world(bounds)  # ShipGame.__init__ ends with reset(): the constructor's world
         for ep in range(len(z[n + "/polys"])):
             rec, polys, goals = worldgen.generate_world(bounds)
-            np.testing.assert_array_equal(polys, z[n + "/polys"][ep], err_msg="%s world %d polygons" % (n, ep))
-            np.testing.assert_allclose(goals, z[n + "/goals"][ep], rtol=0, atol=1e-9, err_msg="%s world %d goals" % (n, ep))
+            np.testing.assert_array_equal(polys, z[n + "/polys"][ep], err_msg="%s world %d polygons" % (n, ep) + CAVEAT)
+            np.testing.assert_allclose(goals, z[n + "/goals"][ep], rtol=0, atol=1e-9, err_msg="%s world %d goals" % (n, ep) + CAVEAT)
             n_worlds += 1
     assert n_worlds > 100
 
@@ -133,11 +140,11 @@ def test_hip_ship_env_facade_replays_the_reference_streams(native):
                 ep += 1
                 o0 = env.reset()
                 env.game.add_default_traffic() if "_traffic/" in n else None  # (a no-op on the HIP path: n_ships=4 adds it at every reset)
-                np.testing.assert_allclose(o0, z[n + "/reset_obs"][ep], rtol=0, atol=ATOL, err_msg="%s reset %d" % (n, ep))
+                np.testing.assert_allclose(o0, z[n + "/reset_obs"][ep], rtol=0, atol=ATOL, err_msg="%s reset %d" % (n, ep) + CAVEAT)
             o, r, d, _ = env.step(int(a))
             err = float(np.max(np.abs(o - z[n + "/obs"][k])))
-            assert err <= ATOL, "%s step %d: obs differ by %g" % (n, k, err)
-            assert r == z[n + "/reward"][k] and d == bool(z[n + "/done"][k]), "%s step %d" % (n, k)
+            assert err <= ATOL, "%s step %d: obs differ by %g" % (n, k, err) + CAVEAT
+            assert r == z[n + "/reward"][k] and d == bool(z[n + "/done"][k]), "%s step %d" % (n, k) + CAVEAT
             assert env.game.colliding == bool(z[n + "/colliding"][k]) and env.game.goal_reached == bool(z[n + "/goal_reached"][k])
             worst = max(worst, err)
             n_steps += 1

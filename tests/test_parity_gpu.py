@@ -266,7 +266,8 @@ def test_trajectory_buffer_set_reused(torch_cuda, native):
         to, tr, td, tf = b.rollout_tensor(acts[k0: k0 + K], trajectory=True, out=out)
         assert to.shape[0] == K and to.data_ptr() == out[0].data_ptr()
         if i >= 1:
-            assert id(out) in b._traj_plans and b._traj_plans[id(out)][0] is out
+            plan = b._traj_plans[out[0].data_ptr()]
+            assert not any(isinstance(v, torch.Tensor) for v in plan)  # pointers and shapes only: a caller's `del` frees its buffers
         for k in range(K):
             o, r, d, f = a.step_tensor(acts[k0 + k])
             assert torch.equal(o, to[k]) and torch.equal(r, tr[k]) and torch.equal(d, td[k]) and torch.equal(f, tf[k]), (i, k)
@@ -274,6 +275,13 @@ def test_trajectory_buffer_set_reused(torch_cuda, native):
     assert torch.equal(a.state, b.state)
     with pytest.raises(AssertionError):
         b.rollout_tensor(acts[:41], trajectory=True, out=out)
+    # a different reward buffer beside the known obs buffer is not mistaken for the cached set
+    out2 = (out[0], torch.full((cap, n), 5.0, dtype=torch.float64, device=a.device), out[2], out[3])
+    keep = out[1].clone()
+    b.rollout_tensor(acts[:3], trajectory=True, out=out2)
+    assert torch.equal(out[1], keep) and not bool((out2[1][:3] == 5.0).any())
+    b.clear_traj_cache()
+    assert "_traj_plans" not in b.__dict__
     b.close()
     assert "_traj_plans" not in b.__dict__
 

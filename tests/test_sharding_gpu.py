@@ -38,6 +38,12 @@ def test_two_process_sharded_env_equals_unsharded(tmp_path, native, n_ships, tot
     import torch
     from ship_sim_gym_amd.vec_env import ShipVecEnv
     r = _run_ranks(tmp_path, 2, total, K, n_ships)
+    # with >= 2 devices the ranks MUST have taken the RCCL branch (one process per GPU), and every rank must have seen the
+    # same world: a rank that fell back, or a group of the wrong size, fails here rather than passing on the gloo proxy
+    want_backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    for rk in r:
+        assert int(rk["seen_world"][0]) == 2 and str(rk["seen_backend"]) == want_backend and int(rk["backend"][0]) == (want_backend == "nccl"), \
+            (int(rk["seen_world"][0]), str(rk["seen_backend"]), int(rk["n_dev"][0]))
     assert (int(r[0]["lo"]), int(r[0]["hi"]), int(r[1]["lo"]), int(r[1]["hi"])) == (0, total // 2, total // 2, total)
     full = ShipVecEnv(total, n_maps=16, map_seed=1000, n_ships=n_ships)
     np.testing.assert_array_equal(r[1]["bank"], full.bank.cpu().numpy())  # the broadcast delivered rank 0's bank

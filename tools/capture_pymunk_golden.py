@@ -80,10 +80,21 @@ def run(ref_env_cls, game_cfg_cls, env_cfg_cls, name, opts, actions, traffic):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("SHIP_SIM_GYM", "/root/reference"))
-    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
-                                                  "pymunk_streams.npz"))
+    default_out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "pymunk_streams.npz")
+    ap.add_argument("--out", default=default_out)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise THIS SCRIPT, not the reference's physics: run every scenario (first --dry-steps actions) under the "
+                         "test-only stand-in pymunk / pygame / gym of tests/golden/shims (physics = the CPU oracle) and write to "
+                         "--out, which must not be the golden path.  The output is NOT a capture and pins nothing.")
+    ap.add_argument("--dry-steps", type=int, default=40)
     args = ap.parse_args()
     os.environ.setdefault("SDL_VIDEODRIVER", "dummy")
+    if args.dry_run:
+        if os.path.abspath(args.out) == os.path.abspath(default_out):
+            sys.exit("--dry-run never writes the golden file: pass --out elsewhere")
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+        sys.path.insert(0, os.path.join(root, "tests", "golden", "shims"))
+        sys.path.insert(0, root)
     try:
         import pymunk  # noqa: F401
         import pygame  # noqa: F401
@@ -94,12 +105,18 @@ def main():
     from ship_gym.ship_env import ShipEnv
     from ship_gym.config import EnvConfig, GameConfig
     import pymunk as pm
-    data = {"meta/pymunk_version": np.asarray(pm.version), "meta/chipmunk_version": np.asarray(pm.chipmunk_version)}
+    standin = "standin" in str(pm.version)
+    if standin and not args.dry_run:
+        sys.exit("the pymunk on sys.path is the test-only stand-in (physics = the oracle): refusing to write a 'capture' from it")
+    data = {"meta/pymunk_version": np.asarray(pm.version), "meta/chipmunk_version": np.asarray(pm.chipmunk_version),
+            "meta/dry_run": np.asarray(bool(args.dry_run))}
     for traffic in (False, True):
         for name, opts, actions in scenarios():
+            if args.dry_run:
+                actions = actions[:max(1, args.dry_steps)]
             data.update(run(ShipEnv, GameConfig, EnvConfig, name, opts, actions, traffic))
     np.savez_compressed(args.out, **data)
-    print("wrote", args.out, "with", len(data), "arrays")
+    print("%swrote %s with %d arrays (pymunk %s)" % ("DRY RUN, NOT A CAPTURE: " if args.dry_run else "", args.out, len(data), pm.version))
 
 
 if __name__ == "__main__":
