@@ -138,13 +138,54 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
 }
 
 // Goal g's centre (comp 0 = x, 1 = y).  Configs 1-3: the goal bodies never move, so the map record holds them
-// (goff = the record's goal block).  Config 4 (DYN): goals are dynamic bodies; the dyn kernel has just written this
-// step's positions into the env's goal columns (goff = env index, shipsim_dynamics.hip).
+// (goff = the record's goal block).  Config 4 (DYN): goals are dynamic bodies; the dyn step of this API step has left their
+// positions in this step parity's table (goff = env index; DevCfg::dyn_obs, shipsim_dynamics.hip) — the body columns
+// themselves may already be a step ahead.
 template <bool LDS_BANK, bool DYN>
 __device__ __forceinline__ double goal_at(const DevCfg &c, int goff, int g, int comp)
 {
-    if constexpr (DYN) return c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g + comp) * (size_t)c.n_pad + goff];
+    if constexpr (DYN) return c.dyn_obs[((size_t)(c.dyn_tick & 1u) * kDynObs + (size_t)(kDynObsGoals + 2 * g + comp)) * (size_t)c.n_pad + goff];
     else return bank_at<LDS_BANK>(c, goff + 2 * g + comp);
+}
+
+// collide_ship (game.py:232-241) of the player against traffic ship k (config 4): cpBBIntersects, then "touching counts" SAT
+// over both hulls' edge normals.  Rare (the caller rejects by reach first) and deliberately not inlined: its registers must
+// not weigh on the body role's step loop.
+__device__ __attribute__((noinline)) bool traffic_touch(const DevCfg &c, int k, double x, double y, double ca, double sa, double tx, double ty,
+                                                        double tca, double tsa)
+{
+    double ax[SSG_SHIP_VERTS], ay[SSG_SHIP_VERTS], bx[SSG_SHIP_VERTS], by[SSG_SHIP_VERTS];
+    double al = INFINITY, ar = -INFINITY, ab = INFINITY, at = -INFINITY, bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+        const double hx = c.hull[2 * i], hy = c.hull[2 * i + 1];
+        ax[i] = ca * hx + (-sa) * hy + x; ay[i] = sa * hx + ca * hy + y;
+        al = fmin(al, ax[i]); ar = fmax(ar, ax[i]); ab = fmin(ab, ay[i]); at = fmax(at, ay[i]);
+        const double gx = c.thull[k][2 * i], gy = c.thull[k][2 * i + 1];
+        bx[i] = tca * gx + (-tsa) * gy + tx; by[i] = tsa * gx + tca * gy + ty;
+        bl = fmin(bl, bx[i]); br = fmax(br, bx[i]); bb = fmin(bb, by[i]); bt = fmax(bt, by[i]);
+    }
+    if (!((al <= br) & (bl <= ar) & (ab <= bt) & (bb <= at))) return false;
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) { // the player's edge normals
+        const double nx = ca * c.nrm[2 * i] + (-sa) * c.nrm[2 * i + 1], ny = sa * c.nrm[2 * i] + ca * c.nrm[2 * i + 1];
+        const double off = nx * ax[i] + ny * ay[i];
+        double mn = INFINITY;
+#pragma unroll
+        for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, nx * bx[j] + ny * by[j]);
+        sep |= mn > off;
+    }
+#pragma unroll
+    for (int i = 0; i < SSG_SHIP_VERTS; ++i) { // the traffic ship's
+        const double nx = tca * c.tnrm[k][2 * i] + (-tsa) * c.tnrm[k][2 * i + 1], ny = tsa * c.tnrm[k][2 * i] + tca * c.tnrm[k][2 * i + 1];
+        const double off = nx * bx[i] + ny * by[i];
+        double mn = INFINITY;
+#pragma unroll
+        for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, nx * ax[j] + ny * ay[j]);
+        sep |= mn > off;
+    }
+    return !sep;
 }
 
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
@@ -181,18 +222,7 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
     }
 }
 
-// The bank record an env moves to when ShipGame.reset gives it its next world: the next record of the shared bank, or —
-// map_ring mode — the next record of the env's own ring [base, base + R).
-__device__ __forceinline__ int next_map(const DevCfg &c, int map_id)
-{
-    if (c.map_ring > 0) {
-        const int base = map_id - map_id % c.map_ring;
-        const int nxt = map_id + 1;
-        return (nxt - base >= c.map_ring) ? base : nxt;
-    }
-    const int nxt = map_id + 1;
-    return (nxt >= c.n_maps) ? 0 : nxt;
-}
+__device__ __forceinline__ int next_map(const DevCfg &c, int map_id) { return next_map_of(c, map_id); }
 
 // Beam i of an env whose body rotation is (ca, sa): direction heading + phi_i by the angle-addition identity from
 // host-computed cos/sin(phi_i), endpoint = origin + range * direction.  Owner lanes (culling) and worker lanes
@@ -1006,8 +1036,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             pv[0] = x0; pv[1] = y0; pv[2] = (double)rud0; pv[3] = a0;
             if constexpr (DYN) {
                 // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
-                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el];
-                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el];
+                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * (size_t)c.dyn_np + el];
+                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * (size_t)c.dyn_np + el];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[i])); // (in registers before barrier 0, as role 3's state)
@@ -1113,8 +1143,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             nv[5] = do_reset ? rs_gy : nf_gy;
             if constexpr (DYN) { // the newest frame's goal: the next observation's older frame (goals move: kept in two columns)
                 if (live) {
-                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = nv[4];
-                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = nv[5];
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * (size_t)c.dyn_np + el_] = nv[4];
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * (size_t)c.dyn_np + el_] = nv[5];
                 }
             }
             {
@@ -1275,8 +1305,22 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
+    // config 4: collide_ship against the traffic ships, where this step's cpSpaceStep left them (DevCfg::dyn_obs).  No vertex of
+    // ship k's hull is further than its hull radius from its body position: a player whose world box is further than that from
+    // the position cannot touch it (a conservative pre-reject of cpBBIntersects; the exact test decides).
+    bool hit_traffic = false;
     unsigned dflag = 0;
-    if constexpr (DYN) dflag = c.dyn_flag[el_]; // bit 0: the dyn kernels found the player touching a traffic ship
+    if constexpr (DYN) {
+        dflag = c.dyn_flag[el_];
+        const double *tob = c.dyn_obs + ((size_t)(c.dyn_tick & 1u) * kDynObs + kDynObsTraffic) * np + el_;
+#pragma unroll 1
+        for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) { // (rolled: one call site)
+            const double tx = tob[(size_t)(4 * kk) * np], ty = tob[(size_t)(4 * kk + 1) * np];
+            const double dx = dmax(dmax(sbl - tx, tx - sbr), 0.0), dy = dmax(dmax(sbb - ty, ty - sbt), 0.0);
+            if (live & ((dx * dx + dy * dy) <= c.dyn_reach2[kk]))
+                hit_traffic |= traffic_touch(c, kk, x, y, ca, sa, tx, ty, tob[(size_t)(4 * kk + 2) * np], tob[(size_t)(4 * kk + 3) * np]);
+        }
+    }
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -1349,7 +1393,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
     // (the observer, role 2, finds the new frame's nearest goal among the goals this leaves listed)
-    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
+    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | (hit_traffic ? 2u : 0u) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
                                 ((steps_after >= c.max_steps) ? 16u : 0u) | ((alive == 0u) ? 32u : 0u) | (alive << 8);
     if (k + 1 < K) act_next = actions_kn[(size_t)(k + 1) * c.n_envs + el];
 
@@ -1358,10 +1402,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     SSG_STAMP_K(4);
 
     bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
-    if constexpr (DYN) {
-        colliding |= (dflag & 1u) != 0; // ... and against the traffic ships (dyn kernels)
-        if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
-    }
+    if constexpr (DYN) colliding |= hit_traffic; // ... and against the traffic ships
 
     // ---- determine_reward (ship_env.py:62-77) ----
     double rew = goal_reached ? 1.0 : ((oob_x | oob_y) ? -1.0 : -0.01);
@@ -1390,65 +1431,24 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // the new world's goal centres (only these lanes gather)
     }
     if constexpr (DYN) {
-        if (live) {
-            // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
-            c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
-        }
-        // Which envs need the full cpSpaceStep of their other bodies NEXT step (shipsim_dynamics.hip)?  Everything that decides
-        // it is in this role's registers now: a reset env (fresh bodies), an env whose bodies are not at rest, one that lost a
-        // goal holding a cached arbiter this step.  A resting env whose player will be within reach of a parked
-        // traffic ship after its next cpBodyUpdatePosition is queued for collide_ship's exact test only (dyn_sort_kernel runs it).
-        // The others keep their rest bit, traffic bit clear.  Queue = one segment per tile:
-        // no atomics to append; the entry carries its sort bucket (steps since the reset, bank record).
-        bool need_full = false, sat_only = false;
-        if (live) {
-            bool resting = !do_reset & ((dflag & 4u) != 0u);
-            if (resting & goal_reached) {
-                // the goal(s) reached this step leave the space: the rest state survives unless one of them had a cached arbiter
-                // (pair ids of shipsim_dynamics.hip: goal g x bank s = 9 + 2g + s, goal g x ship k = 21 + 3g + k, goals h < g = 39 + g(g-1)/2 + h)
-                const unsigned long long lv = c.dyn_live[el_];
-                unsigned long long gone = 0ull;
-                const unsigned removed = ~gm & ((1u << c.n_goals) - 1u);
-                for (int g = 0; g < c.n_goals; ++g) {
-                    if (!((removed >> g) & 1u)) continue;
-                    gone |= 3ull << (9 + 2 * g);
-                    gone |= 7ull << (21 + 3 * g);
-                    for (int h = 0; h < c.n_goals; ++h)
-                        if (h != g) gone |= 1ull << (h < g ? 39 + g * (g - 1) / 2 + h : 39 + h * (h - 1) / 2 + g);
-                }
-                resting = (lv & gone) == 0ull;
-            }
+        // What the dyn kernels need from this step (shipsim_dynamics.hip): an auto-reset env adopts its next episode's space
+        // before the next step (DR_RESET -> dyn_adopt_kernel).  A space that is stepped queues itself; one at REST must be woken
+        // if the player is about to remove a goal from it (the removed goal's cached arbiters leave with it): whether the
+        // player's hull can reach a goal after its next cpBodyUpdatePosition is decided here, conservatively — every hull
+        // vertex moves by at most |v dt| + (hull radius) |w dt| per axis, and a resting space's goals stay where this step's
+        // table has them — and the env is queued for the cpSpaceStep after the next one, which evaluates collide_goal exactly.
+        if (live && do_reset) c.dyn_req[el_] = (uint8_t)DR_RESET;
+        // (only a resting space with cached arbiters on goals can be disturbed — dyn_flag bits 2, 3; the flag of a space the
+        // concurrent dyn step is stepping may be read old or new: old = "not at rest" is the safe side, new is exact)
+        if (live && !do_reset && ((dflag & 12u) != 4u)) {
+            const double wr = c.dyn_hull_r * fabs(w * c.dt);
+            const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr, r = c.goal_r;
             bool reach = false;
-            if (resting) {
-                // Can the player's hull touch a parked ship after its next cpBodyUpdatePosition?  Every hull vertex moves by at
-                // most |v dt| + (hull radius) |w dt| per axis, so the next hull lies inside this step's world box widened by that;
-                // a parked ship's hull lies inside the circle of its hull radius about its body position.  (A conservative
-                // pre-reject of cpBBIntersects: the exact test decides; tighter than the two hull-radius circles, which put a
-                // quarter of all envs "in reach" of the ship parked in mid-river.)
-                const double wr = c.dyn_hull_r * fabs(w * c.dt);
-                const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr;
-#pragma unroll
-                for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
-                    const double tx = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk) * np + el_], ty = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk + 1) * np + el_];
-                    const double dx = dmax(dmax((sbl - mx) - tx, tx - (sbr + mx)), 0.0), dy = dmax(dmax((sbb - my) - ty, ty - (sbt + my)), 0.0);
-                    reach |= (dx * dx + dy * dy) <= c.dyn_reach2[kk];
-                }
+            for (int g = 0; g < c.n_goals; ++g) {
+                const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0), gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
+                reach |= (bool)((gm >> g) & 1u) & ((gx - r) <= (sbr + mx)) & ((sbl - mx) <= (gx + r)) & ((gy - r) <= (sbt + my)) & ((sbb - my) <= (gy + r));
             }
-            need_full = !resting;
-            sat_only = resting & reach;
-        }
-        const unsigned long long qm = __ballot(need_full | sat_only);
-        const int seg = (blockIdx.x * EPW + tl) >> 6; // this tile's segment (wave-uniform)
-        if (lane == 0) c.dyn_segcnt[seg] = (unsigned)__popcll(qm);
-        if (need_full | sat_only) {
-            const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(qm & ((1ull << lane) - 1ull));
-            unsigned long long key = kDynSatOnly; // a resting env within reach of a parked ship: collide_ship's exact test only
-            if (need_full) {
-                const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
-                key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
-            }
-            c.dyn_queue[slot] = el_;
-            c.dyn_qkey[slot] = key;
+            if (reach) dyn_enqueue(c, c.dyn_tick + 2u, el_, DQ_STEP, dyn_bucket_of(kDynAgeBuckets - 1, map_id));
         }
     }
     if (do_reset) {
@@ -1457,6 +1457,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         gm = (1u << c.n_goals) - 1u;
         // the pre-step rotation the next step's thrust will read: cpvforangle(0)
         pose[2 * EPW + tl] = 1.0; pose[3 * EPW + tl] = 0.0;
+    }
+    if constexpr (DYN) {
+        // the player state the cpSpaceStep after the next one predicts the next step's goal removals from (post-reset)
+        if (live) {
+            double *ps = c.dyn_ps + (size_t)(c.dyn_tick & 1u) * kDynPs * np + el_;
+            st_out(&ps[0 * np], x); st_out(&ps[1 * np], y); st_out(&ps[2 * np], vx); st_out(&ps[3 * np], vy); st_out(&ps[4 * np], ang); st_out(&ps[5 * np], w);
+            st_out(&c.dyn_psgm[(size_t)(c.dyn_tick & 1u) * np + el_], (uint8_t)(gm & ((1u << c.n_goals) - 1u)));
+        }
     }
     if (k == K - 1 && live && !SSG_ABL(9)) { // the state goes back to its columns with the last step of the launch
         st_out(&colX[el], x); st_out(&colY[el], y); st_out(&colVX[el], vx); st_out(&colVY[el], vy); st_out(&colA[el], ang);
