@@ -20,8 +20,8 @@ struct ssg_handle {
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     // config 4 only (shipsim_internal.h DevCfg::dyn_*)
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0, off_dyn_hash = 0, off_dyn_row = 0;
-    size_t off_dyn_gen = 0, off_dyn_age = 0, off_dyn_vmap = 0, off_dyn_qstamp = 0, off_dyn_req = 0, off_dyn_nvalid = 0, off_dyn_nmap = 0,
-           off_dyn_ntag = 0, off_dyn_obs = 0, off_dyn_ps = 0, off_dyn_psgm = 0, off_dyn_region = 0, off_dyn_count = 0, off_dyn_err = 0;
+    size_t off_dyn_gen = 0, off_dyn_age = 0, off_dyn_vmap = 0, off_dyn_req = 0, off_dyn_nvalid = 0, off_dyn_nmap = 0,
+           off_dyn_ntag = 0, off_dyn_obs = 0, off_dyn_ps = 0, off_dyn_region = 0, off_dyn_count = 0, off_dyn_err = 0;
     bool dyn_queue_valid = false; // the queues of the coming steps are what the kernels left (nothing host-side touched the envs since)
     unsigned dyn_tick = 1;        // the next API step (its parity selects the per-step buffers of the dyn pipeline)
     ssg::DynCfg dyn{};
@@ -355,14 +355,12 @@ void refresh_dev(ssg_handle *h)
     d.dyn_gen = reinterpret_cast<uint8_t *>(at(h->off_dyn_gen));
     d.dyn_age = reinterpret_cast<uint8_t *>(at(h->off_dyn_age));
     d.dyn_vmap = reinterpret_cast<int32_t *>(at(h->off_dyn_vmap));
-    d.dyn_qstamp = reinterpret_cast<unsigned *>(at(h->off_dyn_qstamp));
     d.dyn_req = reinterpret_cast<uint8_t *>(at(h->off_dyn_req));
     d.dyn_nvalid = reinterpret_cast<unsigned long long *>(at(h->off_dyn_nvalid));
     d.dyn_nmap = reinterpret_cast<int32_t *>(at(h->off_dyn_nmap));
     d.dyn_ntag = reinterpret_cast<int32_t *>(at(h->off_dyn_ntag));
     d.dyn_obs = reinterpret_cast<double *>(at(h->off_dyn_obs));
     d.dyn_ps = reinterpret_cast<double *>(at(h->off_dyn_ps));
-    d.dyn_psgm = reinterpret_cast<uint8_t *>(at(h->off_dyn_psgm));
     d.dyn_region = reinterpret_cast<int32_t *>(at(h->off_dyn_region));
     d.dyn_count = reinterpret_cast<unsigned *>(at(h->off_dyn_count));
     d.dyn_err = reinterpret_cast<unsigned *>(at(h->off_dyn_err));
@@ -532,14 +530,12 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         take(h->off_dyn_gen, dnp);
         take(h->off_dyn_age, dnp);
         take(h->off_dyn_vmap, dnp * sizeof(int32_t));
-        take(h->off_dyn_qstamp, dnp * sizeof(unsigned));
         take(h->off_dyn_req, np);
         take(h->off_dyn_nvalid, np * sizeof(unsigned long long));
         take(h->off_dyn_nmap, np * sizeof(int32_t));
         take(h->off_dyn_ntag, np * sizeof(int32_t));
         take(h->off_dyn_obs, 2 * (size_t)ssg::kDynObs * np * sizeof(double));
-        take(h->off_dyn_ps, 2 * (size_t)ssg::kDynPs * np * sizeof(double));
-        take(h->off_dyn_psgm, 2 * np);
+        take(h->off_dyn_ps, 2 * (size_t)ssg::kDynPsRow * np * sizeof(double));
         take(h->off_dyn_count, 2 * (size_t)ssg::kDynCountWords * sizeof(unsigned));
         take(h->off_dyn_err, 256);
         // the bucketed queues of the full dyn step (two, by step parity): every (bank record, age) bucket owns 2 * n_pad slots (a
@@ -832,31 +828,41 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                     if (h->dyn_stream) { (void)hipStreamDestroy(h->dyn_stream); h->dyn_stream = nullptr; }
                     int lo = 0, hi = 0;
                     (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // the chain that bounds the step is the dyn step's: give it the CUs first
-                    e = hipStreamCreateWithPriority(&h->dyn_stream, hipStreamNonBlocking, hi);
+                    static const bool kPrio = [] { const char *sv = std::getenv("SSG_DYN_PRIO"); return !sv || std::atoi(sv) != 0; }(); // (experiments)
+                    e = hipStreamCreateWithPriority(&h->dyn_stream, hipStreamNonBlocking, kPrio ? hi : lo);
                     if (e == hipSuccess && !h->ev_adopt) e = hipEventCreateWithFlags(&h->ev_adopt, hipEventDisableTiming);
                     if (e == hipSuccess && !h->ev_dyn) e = hipEventCreateWithFlags(&h->ev_dyn, hipEventDisableTiming);
                     if (e != hipSuccess) return bail("second stream: ", e);
                     h->dyn_stream_device = h->cfg.device_id;
                 }
                 hipStream_t sb = h->dyn_stream;
+                static const int kNoSync = [] { const char *sv = std::getenv("SSG_DYN_NOSYNC"); return sv ? std::atoi(sv) : 0; }(); // (timing experiments only: wrong results)
+                // Stream B carries the chain that bounds the step — dyn(t+1), adopt(t), dyn(t+2), ... in order, no cross-stream
+                // hand-over on it except the wait for step kernel t, long finished by then; stream A runs the step kernels, each
+                // after the adopt pass before it.
                 e = hipEventRecord(h->ev_adopt, sa);
+                if (e == hipSuccess) e = hipStreamWaitEvent(sb, h->ev_adopt, 0);
                 for (int j = 0; j < kk && e == hipSuccess; ++j) {
                     const bool more = j + 1 < kk;
                     if (more) { // the dyn step of the NEXT step, beside this step's kernel
-                        e = hipStreamWaitEvent(sb, h->ev_adopt, 0);
                         h->dev.dyn_tick = h->dyn_tick + 1;
-                        if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, sb);
-                        if (e == hipSuccess) e = hipEventRecord(h->ev_dyn, sb);
+                        e = ssg::launch_dyn_step(h->dev, h->dyn, sb);
                         if (e != hipSuccess) break;
                     }
                     h->dev.dyn_tick = h->dyn_tick;
                     e = step_launch(k + j);
                     h->dyn_tick += 1;
                     if (e == hipSuccess && more) {
-                        e = hipStreamWaitEvent(sa, h->ev_dyn, 0);
+                        if (!(kNoSync & 1)) {
+                            e = hipEventRecord(h->ev_dyn, sa); // (step kernel t done)
+                            if (e == hipSuccess) e = hipStreamWaitEvent(sb, h->ev_dyn, 0);
+                        }
                         h->dev.dyn_tick = h->dyn_tick;
-                        if (e == hipSuccess) e = ssg::launch_dyn_adopt(h->dev, h->dyn, true, sa);
-                        if (e == hipSuccess) e = hipEventRecord(h->ev_adopt, sa);
+                        if (e == hipSuccess) e = ssg::launch_dyn_adopt(h->dev, h->dyn, true, sb);
+                        if (!(kNoSync & 2)) {
+                            if (e == hipSuccess) e = hipEventRecord(h->ev_adopt, sb);
+                            if (e == hipSuccess) e = hipStreamWaitEvent(sa, h->ev_adopt, 0);
+                        }
                     }
                 }
                 if (e != hipSuccess) return bail("pipelined config-4 rollout: ", e);

@@ -60,13 +60,22 @@
 namespace ssg {
 namespace {
 
-extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-uniform hull constants
+// Per wave: [field][kGrp lanes] columns, then the wave-uniform hull constants (and, UNI, the wave's bank planes).  A workgroup of
+// the UNI kernel has TWO waves, each with its own region (kWaveLds doubles apart; they share nothing): two waves are what a CU's
+// LDS holds, and as ONE workgroup they fill whole CUs — the CUs the queue does not need stay entirely free for the step kernel
+// running beside this one (a 1 024-thread workgroup of it needs a whole CU's LDS and never found one when these waves were
+// spread one or two per CU over the chip).
+extern __shared__ double lds_all[];
+#define lds (lds_all + (threadIdx.x >> 6) * kWaveLds)
 
 // Envs per workgroup of the full step (lanes kGrp..63 of its one wave idle: a lone wave's FP64 chain takes the same time
 // whatever its width).  Measured at 65 536 envs, planes once per wave: 48 (76 KB of LDS, two waves per CU) -> 62.5 us in
 // steady state and 135 us with every env queued; 32 (51 KB, three per CU) -> 63.9 / 132; 64 with per-lane planes (158 KB,
 // one per CU; round 2 and the first half of round 3) -> 60.9 / 165, and 100 whenever the queue outgrew 16 384 envs.
 constexpr int kGrp = kDynGrp;
+// (B_STRIDE * (goals + ships + static) + X_STRIDE * ships + A_STRIDE * kLdsArb + kEpaDoubles) * kGrp + hull constants + both banks'
+// planes, for SSG_MAX_GOALS goals: the UNI kernel's per-wave LDS in doubles (static_assert below)
+constexpr int kWaveLds = (8 * (SSG_MAX_GOALS + SSG_N_TRAFFIC + 1) + 3 * SSG_N_TRAFFIC + 25 * 2 + 56) * kDynGrp + 4 * SSG_SHIP_VERTS * (1 + SSG_N_TRAFFIC) + 2 * 4 * SSG_MAX_HULL;
 static_assert(kGrp == 32 || kGrp == 48 || kGrp == 64, "lds[field * kGrp + lane]: at 32 / 64 a lane keeps its LDS banks whatever the field; 48 pays an occasional 2-way conflict on the solver's per-lane body slots");
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
@@ -515,6 +524,7 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
         for (int f = 2; f < DC_GOAL_COLS; ++f) row[DC_GOAL_COLS * g + f] = 0.0;
     }
     col.live[v] = 0ull;
+    row[kDynRowLive] = __longlong_as_double(0ll);
 }
 
 // The step kernel's view of env e's other bodies (both step parities): from the columns of space v.
@@ -563,9 +573,11 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
     col.f64[(size_t)(DC_PREV_GOAL + 1) * col.np + e] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
     col.flag[e] = 0;
     c.dyn_req[e] = 0;
-    c.dyn_gen[e] = (uint8_t)(c.dyn_gen[e] + 1u);
+    const unsigned gen_new = ((unsigned)c.dyn_gen[e] + 1u) & 255u;
+    c.dyn_gen[e] = (uint8_t)gen_new;
     c.dyn_age[e] = 0;
     c.dyn_vmap[e] = m;
+    c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, 0u, gen_new));
     dyn_publish_obs(c, e, e);
 }
 // 64-bit mixing for the "did this step change anything" test of the full step (inputs vs outputs, no re-reads).
@@ -632,50 +644,142 @@ __global__ __launch_bounds__(256) void dyn_adopt_kernel(const DevCfg c, const Dy
     if (e >= c.n_envs) return;
     const unsigned req = c.dyn_req[e];
     if (!(req & DR_RESET)) return;
+    // (this pass sits between two dyn steps of a pipelined rollout: its dependent memory round trips are the step's time.
+    // Everything is requested in one go; the stores and the two queue atomics follow.)
     const size_t dnp = (size_t)c.dyn_np, np = (size_t)c.n_pad;
     const int vn = c.n_pad + e;
-    const int map_now = c.i32cols[(size_t)ICOL_MAP * np + e];          // the record the step kernel moved the env to
-    const int episode = c.i32cols[(size_t)ICOL_EPISODE * np + e];      // ... and the episode it started there
-    const bool usable = c.dyn_nvalid[e] == (((unsigned long long)d.bank_epoch << 32) | (unsigned)episode) && c.dyn_vmap[vn] == map_now;
-    c.dyn_gen[e] = (uint8_t)(c.dyn_gen[e] + 1u); // whatever was queued for the old space is stale
+    int map_now = c.i32cols[(size_t)ICOL_MAP * np + e];          // the record the step kernel moved the env to
+    int episode = c.i32cols[(size_t)ICOL_EPISODE * np + e];      // ... and the episode it started there
+    unsigned long long nvalid = c.dyn_nvalid[e];
+    int vmap_n = c.dyn_vmap[vn];
+    unsigned gen_e = c.dyn_gen[e];
+    unsigned long long live = c.dyn_live[vn];
+    unsigned flag_n = c.dyn_flag[vn];
+    unsigned long long hash_n = c.dyn_hash[vn];
+    unsigned long long pend_c = (unsigned long long)__double_as_longlong(c.dyn_row[(size_t)e * kDynRow + kDynRowPend]); // the old space's queue entry
+    // Body fields: N's row shadow holds them all (80 contiguous doubles: independent loads, one round trip), then the stores —
+    // C's columns, C's row, the step kernel's table.  (Column by column, 81 dependent load / store pairs per env made this pass
+    // 65 us long.)
+    double rw[kDynRow], rot[2 * SSG_N_TRAFFIC];
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)vn * kDynRow);
+#pragma unroll
+        for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = src[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
+#pragma unroll
+        for (int f = 0; f < 2 * SSG_N_TRAFFIC; ++f) rot[f] = c.dyn_f64[(size_t)(DC_TROT + f) * dnp + vn];
+    }
+    asm volatile("" : "+v"(map_now), "+v"(episode), "+v"(nvalid), "+v"(vmap_n), "+v"(gen_e), "+v"(live), "+v"(flag_n), "+v"(hash_n), "+v"(pend_c));
+#pragma unroll
+    for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
+    const bool usable = nvalid == (((unsigned long long)d.bank_epoch << 32) | (unsigned)episode) && vmap_n == map_now;
+    const unsigned gen_new = (gen_e + 1u) & 0xFFu;
+    c.dyn_gen[e] = (uint8_t)gen_new; // whatever was queued for the old space is stale ...
+    // ... and must not take the claim on the space from the entry queued below: the slot the old space's last dyn step
+    // reserved in the queue of step k+1 is voided
+    if ((unsigned)(pend_c >> 40) == ((c.dyn_tick + 1u) & 0xFFFFFFu)) {
+        const unsigned pb = (unsigned)(pend_c >> 28) & (unsigned)(kDynBuckets - 1), psl = (unsigned)pend_c & kDynVMaskU;
+        if (psl < (unsigned)c.dyn_np) c.dyn_region[((size_t)((c.dyn_tick + 1u) & 1u) * kDynBuckets + pb) * dnp + psl] = (int32_t)0xFFFFFFFFu;
+    }
     if (!usable) {
         c.dyn_req[e] = (uint8_t)DR_FRESH;
         if (enqueue) atomicAdd(c.dyn_err + 0, 1u); // (a pipelined rollout has no dyn step left in front of the next step kernel)
         return;
     }
-    // body columns + row shadow
-    for (int f = 0; f < 9 * SSG_N_TRAFFIC; ++f) c.dyn_f64[(size_t)(DC_TRAFFIC + f) * dnp + e] = c.dyn_f64[(size_t)(DC_TRAFFIC + f) * dnp + vn];
-    for (int f = 0; f < DC_GOAL_COLS * SSG_MAX_GOALS; ++f) c.dyn_f64[(size_t)(DC_GOALS + f) * dnp + e] = c.dyn_f64[(size_t)(DC_GOALS + f) * dnp + vn];
-    for (int f = 0; f < 2 * SSG_N_TRAFFIC; ++f) c.dyn_f64[(size_t)(DC_TROT + f) * dnp + e] = c.dyn_f64[(size_t)(DC_TROT + f) * dnp + vn];
+    // queue slots: C for the step after the coming one (unless it is at rest already), the N of the episode after this one
+    const unsigned tq = c.dyn_tick + 1u, qq = tq & 1u;
+    const bool want_c = enqueue && !(flag_n & 4u), want_n = enqueue && (c.flags & SSG_FLAG_AUTO_RESET);
+    const int nm = next_map_of(c, map_now);
+    const unsigned bc = dyn_bucket_of(1, map_now), bn = dyn_bucket_of(0, nm);
+    unsigned slot_c = 0u, slot_n = 0u;
+    if (want_c) slot_c = atomicAdd(c.dyn_count + (size_t)qq * kDynCountWords + kDynBucket0 + bc * kDynBucketStride, 1u);
+    if (want_n) slot_n = atomicAdd(c.dyn_count + (size_t)qq * kDynCountWords + kDynBucket0 + bn * kDynBucketStride, 1u);
+    // cached arbiters (a handful at most): loads first
+    constexpr int kMaxCopy = 8;
+    int apid[kMaxCopy];
+    unsigned ameta[kMaxCopy], ahash[kMaxCopy];
+    double aacc[kMaxCopy][4];
+    int n_arb = 0;
     {
-        const double2 *src = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)vn * kDynRow);
+        unsigned long long lv = live;
+#pragma unroll
+        for (int i = 0; i < kMaxCopy; ++i) {
+            apid[i] = -1; ameta[i] = 0u; ahash[i] = 0u;
+            if (lv) {
+                const int pid = __ffsll((long long)lv) - 1;
+                lv &= lv - 1ull;
+                apid[i] = pid;
+                ameta[i] = c.dyn_u32[(size_t)(DU_META + pid) * dnp + vn];
+                if (pid < kPolyPairs) ahash[i] = c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + vn];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) aacc[i][f] = c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + vn];
+                n_arb = i + 1;
+            }
+        }
+        while (lv) { // (more than eight cached arbiters after one step of a fresh world: never seen; kept correct)
+            const int pid = __ffsll((long long)lv) - 1;
+            lv &= lv - 1ull;
+            c.dyn_u32[(size_t)(DU_META + pid) * dnp + e] = c.dyn_u32[(size_t)(DU_META + pid) * dnp + vn];
+            if (pid < kPolyPairs) c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + e] = c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + vn];
+            for (int f = 0; f < 4; ++f) c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + e] = c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + vn];
+        }
+    }
+    {
+        rw[kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(map_now, 1u, gen_new)); // (the live mask at [75] is N's)
+        rw[kDynRowPend] = 0.0;
+        rw[kDynRowSelf] = __longlong_as_double((long long)(want_c ? tq : 0u));
         double2 *dst = reinterpret_cast<double2 *>(c.dyn_row + (size_t)e * kDynRow);
-        for (int i = 0; i < kDynRow / 2; ++i) dst[i] = src[i];
+#pragma unroll
+        for (int i = 0; i < kDynRow / 2; ++i) { double2 rv; rv.x = rw[2 * i]; rv.y = rw[2 * i + 1]; dst[i] = rv; }
+#pragma unroll
+        for (int f = 0; f < DC_GOAL_COLS * SSG_MAX_GOALS; ++f) c.dyn_f64[(size_t)(DC_GOALS + f) * dnp + e] = rw[f];
+#pragma unroll
+        for (int f = 0; f < 9 * SSG_N_TRAFFIC; ++f) c.dyn_f64[(size_t)(DC_TRAFFIC + f) * dnp + e] = rw[kDynRowTraffic + f];
+#pragma unroll
+        for (int f = 0; f < 2 * SSG_N_TRAFFIC; ++f) c.dyn_f64[(size_t)(DC_TROT + f) * dnp + e] = rot[f];
+        for (int par = 0; par < 2; ++par) {
+            double *o = c.dyn_obs + (size_t)par * kDynObs * np + e;
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+                o[(size_t)(kDynObsGoals + 2 * g) * np] = rw[DC_GOAL_COLS * g];
+                o[(size_t)(kDynObsGoals + 2 * g + 1) * np] = rw[DC_GOAL_COLS * g + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                o[(size_t)(kDynObsTraffic + 4 * k) * np] = rw[kDynRowTraffic + 9 * k];
+                o[(size_t)(kDynObsTraffic + 4 * k + 1) * np] = rw[kDynRowTraffic + 9 * k + 1];
+                o[(size_t)(kDynObsTraffic + 4 * k + 2) * np] = rot[2 * k];
+                o[(size_t)(kDynObsTraffic + 4 * k + 3) * np] = rot[2 * k + 1];
+            }
+        }
     }
-    // cached arbiters
-    unsigned long long live = c.dyn_live[vn];
     c.dyn_live[e] = live;
-    while (live) {
-        const int pid = __ffsll((long long)live) - 1;
-        live &= live - 1ull;
-        c.dyn_u32[(size_t)(DU_META + pid) * dnp + e] = c.dyn_u32[(size_t)(DU_META + pid) * dnp + vn];
-        if (pid < kPolyPairs) c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + e] = c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + vn];
-        for (int f = 0; f < 4; ++f) c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + e] = c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + vn];
+#pragma unroll
+    for (int i = 0; i < kMaxCopy; ++i) {
+        if (i < n_arb) {
+            const int pid = apid[i];
+            c.dyn_u32[(size_t)(DU_META + pid) * dnp + e] = ameta[i];
+            if (pid < kPolyPairs) c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + e] = ahash[i];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + e] = aacc[i][f];
+        }
     }
-    const unsigned flag_n = c.dyn_flag[vn];
     c.dyn_flag[e] = (uint8_t)(flag_n & 12u);
-    c.dyn_hash[e] = c.dyn_hash[vn];
+    c.dyn_hash[e] = hash_n;
     c.dyn_age[e] = 1;
     c.dyn_vmap[e] = map_now;
-    dyn_publish_obs(c, e, e);
     if (enqueue) {
         c.dyn_req[e] = 0;
-        if (!(flag_n & 4u)) dyn_enqueue(c, c.dyn_tick + 1u, e, DQ_STEP, dyn_bucket_of(1, map_now), true);
-        if (c.flags & SSG_FLAG_AUTO_RESET) { // the world after this one
-            const int nm = next_map_of(c, map_now);
+        int32_t *region = c.dyn_region + (size_t)qq * kDynBuckets * dnp;
+        if (want_c) {
+            if (slot_c < (unsigned)c.dyn_np) region[(size_t)bc * dnp + slot_c] = (int32_t)((unsigned)e | ((unsigned)DQ_STEP << 28) | ((gen_new & 3u) << 30));
+            else atomicAdd(c.dyn_err + 1, 1u);
+        }
+        if (want_n) { // the world after this one
             c.dyn_nmap[e] = nm;
             c.dyn_ntag[e] = episode + 1;
-            dyn_enqueue(c, c.dyn_tick + 1u, vn, DQ_NJOB, dyn_bucket_of(0, nm), true);
+            c.dyn_row[(size_t)vn * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episode + 1) << 32)));
+            if (slot_n < (unsigned)c.dyn_np) region[(size_t)bn * dnp + slot_n] = (int32_t)((unsigned)vn | ((unsigned)DQ_NJOB << 28) | (((unsigned)c.dyn_gen[vn] & 3u) << 30));
+            else atomicAdd(c.dyn_err + 1, 1u);
         }
     } else {
         c.dyn_req[e] = (uint8_t)DR_AHEAD; // the classify pass queues it for step k+1, not k
@@ -715,26 +819,32 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
     const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
     // the player-state records: step k's dyn step reads parity k (nothing to predict), step k+1's reads parity k+1
     for (int par = 0; par < 2; ++par) {
+        double *ps = c.dyn_ps + ((size_t)par * np + e) * kDynPsRow;
 #pragma unroll
-        for (int f = 0; f < kDynPs; ++f) c.dyn_ps[((size_t)par * kDynPs + f) * np + e] = st[f];
-        c.dyn_psgm[(size_t)par * np + e] = (uint8_t)(gmask | (par == (int)(tick & 1u) ? kDynPsSkip : 0u));
+        for (int f = 0; f < kDynPs; ++f) ps[f] = st[f];
+        ps[kDynPs] = __longlong_as_double((long long)(gmask | (par == (int)(tick & 1u) ? kDynPsSkip : 0u)));
     }
+    const unsigned gen_e = c.dyn_gen[e];
+    auto set_vmap = [&](int m) { // the record of the current space, and its mirror in the row
+        c.dyn_vmap[e] = m;
+        c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, (unsigned)age, gen_e));
+    };
     if (req & DR_FRESH) { // an auto-reset env without a usable N: rebuilt from its record by the dyn step of step k
-        c.dyn_vmap[e] = map_id;
+        set_vmap(map_id);
         c.dyn_req[e] = 0;
-        dyn_enqueue(c, tick, e, DQ_FRESH, dyn_bucket_of(0, map_id), true);
+        dyn_enqueue(c, tick, e, DQ_FRESH, dyn_bucket_of(0, map_id));
     } else if (req & DR_AHEAD) { // adopted just now: already holds step k's state
         c.dyn_req[e] = 0;
-        if (!(flag & 4u)) dyn_enqueue(c, tick + 1u, e, DQ_STEP, dyn_bucket_of(age, map_id), true);
+        if (!(flag & 4u)) dyn_enqueue(c, tick + 1u, e, DQ_STEP, dyn_bucket_of(age, map_id));
     } else {
         // rest bit still valid?  It was established for this bank generation; callers that write the body columns
         // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).  A cached arbiter that left with its goal
         // was part of the fixed point: the bodies it touched are stepped again.
         const bool rest = ((flag & 4u) != 0u) && (hash0 == (unsigned long long)d.bank_epoch) &&
                           (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
-        c.dyn_vmap[e] = map_id;
+        set_vmap(map_id);
         if (rest) c.dyn_flag[e] = (uint8_t)(flag & 12u);
-        else dyn_enqueue(c, tick, e, DQ_STEP, dyn_bucket_of(age, map_id), true);
+        else dyn_enqueue(c, tick, e, DQ_STEP, dyn_bucket_of(age, map_id));
     }
     // the next episode's space
     if (c.flags & SSG_FLAG_AUTO_RESET) {
@@ -743,7 +853,8 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         if (!have) {
             c.dyn_nmap[e] = nm;
             c.dyn_ntag[e] = episode + 1;
-            dyn_enqueue(c, tick, c.n_pad + e, DQ_NJOB, dyn_bucket_of(0, nm), true);
+            c.dyn_row[(size_t)(c.n_pad + e) * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episode + 1) << 32)));
+            dyn_enqueue(c, tick, c.n_pad + e, DQ_NJOB, dyn_bucket_of(0, nm));
         }
     }
 }
@@ -758,9 +869,12 @@ __host__ __device__ constexpr int dyn_lane_doubles(int n_goals, bool uni)
 }
 
 template <bool UNI>
-__global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
+__global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
-    const int lane = threadIdx.x;
+    constexpr int kWpg = UNI ? 2 : 1; // waves per workgroup (see lds_all)
+    static_assert(dyn_lane_doubles(SSG_MAX_GOALS, true) * kGrp + kHullDoubles * (1 + SSG_N_TRAFFIC) + 2 * kBankDoubles == kWaveLds, "kWaveLds");
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(); // (development aid, see stamp())
     const unsigned tick = c.dyn_tick, qi = tick & 1u;
     unsigned *const qcount = c.dyn_count + (size_t)qi * kDynCountWords;
     // The last workgroup to leave zeroes the queue's counters for its next use, two steps from now (every workgroup has read
@@ -769,7 +883,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         unsigned old = 0;
         if (lane == 0) old = atomicAdd(qcount, 1u);
         old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        if (old == gridDim.x - 1u) {
+        if (old == gridDim.x * (unsigned)kWpg - 1u) {
             for (int i = lane; i < kDynBuckets; i += 64) qcount[kDynBucket0 + i * kDynBucketStride] = 0u;
             if (lane == 0) qcount[0] = 0u;
         }
@@ -783,6 +897,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     unsigned n_map = 0;
 #pragma unroll
     for (int j = 0; j < kDynAgeBuckets; ++j) n_map += cnt[j];
+    const unsigned long long t_cnt = __builtin_amdgcn_s_memtime(); // (development aid)
     const unsigned r_map = (n_map + (unsigned)(kGrp - 1)) / (unsigned)kGrp * (unsigned)kGrp;
     unsigned incl = r_map;
 #pragma unroll
@@ -790,9 +905,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const unsigned vsh = __shfl_up(incl, o);
         incl += (lane >= o) ? vsh : 0u;
     }
-    const unsigned s0 = (unsigned)blockIdx.x * (unsigned)kGrp;
+    // A resident set of workgroups walks the queue (the grid is what the chip holds at once, not the worst-case queue: thousands
+    // of workgroups that only find out that they are past the queue's end kept the dispatcher — and, on a high-priority stream,
+    // the step kernel running beside this one — waiting).  In steady state every workgroup finds at most one wave of work.
+    const unsigned q_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    for (unsigned wslot = blockIdx.x * (unsigned)kWpg + (threadIdx.x >> 6); wslot * (unsigned)kGrp < q_total; wslot += gridDim.x * (unsigned)kWpg) {
+    const unsigned s0 = wslot * (unsigned)kGrp;
     const unsigned long long mine = __ballot((incl - r_map <= s0) & (s0 < incl));
-    if (mine == 0ull) { leave(); return; } // past the queue's end
+    if (mine == 0ull) break; // (cannot happen below q_total)
     const int wm = __ffsll((long long)mine) - 1; // this wave's map bucket (wave-uniform)
     const unsigned o_in_map = s0 - (unsigned)__builtin_amdgcn_readlane((int)(incl - r_map), wm) + (unsigned)lane;
     unsigned entry = 0u;
@@ -811,41 +931,93 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
     }
     const unsigned etype = (entry >> 28) & 3u;
+    const unsigned long long t_ent = __builtin_amdgcn_s_memtime(); // (development aid)
+    queued = queued && (int)(entry & kDynVMask) < c.dyn_np;
     const int v = queued ? (int)(entry & kDynVMask) : 0;          // the space this lane steps
-    queued = queued && v < c.dyn_np && ((unsigned)c.dyn_gen[v] & 3u) == (entry >> 30); // (an entry of a space the env has left is stale)
-    const bool is_n = queued & (etype == DQ_NJOB);                 // the next episode's space: nothing of the player is read
-    const int e = queued ? (v >= c.n_pad ? v - c.n_pad : v) : 0;  // its env
-    const bool fresh = queued & (etype != DQ_STEP);                // rebuilt from the record: nothing of the space's old state is read
-    if (!__any(queued)) { leave(); return; }
+    const int e = v >= c.n_pad ? v - c.n_pad : v;                 // its env
     const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
     const int cbase = kGrp * lane_doubles;
     const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
-    stage_hulls(c, d, cbase, lane);
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.dyn_np};
     const size_t np = col.np;               // stride of the dyn columns (vspaces)
     const size_t enp = (size_t)c.n_pad;     // stride of the per-env tables
-    int map_id = queued ? (is_n ? c.dyn_nmap[e] : c.dyn_vmap[v]) : 0;
-    if (UNI) {
-        const unsigned long long qm = __ballot(queued);
-        map_id = __builtin_amdgcn_readlane(map_id, __ffsll((long long)qm) - 1);
-        const double *rec_u = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
+    // Everything the step reads from memory about this space is requested NOW, in one go, from SIX cache lines of the lane: the
+    // space's row (body fields, live-arbiter mask, record / age / generation, an N job's order) and the env's player-state
+    // record.  (Requested where they were used — and from a table each — these were five more dependent round trips of
+    // 48 scattered lines at the head of every wave's chain: 12 k cycles.)
+    double rw[kDynRow], ps[kDynPsRow];
+    {
+        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)v * kDynRow);
+#pragma unroll
+        for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
+        const double2 *ps2 = reinterpret_cast<const double2 *>(c.dyn_ps + ((size_t)qi * enp + e) * kDynPsRow);
+#pragma unroll
+        for (int i = 0; i < kDynPsRow / 2; ++i) { const double2 rv = ps2[i]; ps[2 * i] = rv.x; ps[2 * i + 1] = rv.y; }
+    }
+    stage_hulls(c, d, cbase, lane);
+    if (UNI) { // banks of at most 64 records: the bucket's map index IS the record (all lanes of the wave sit on it)
+        const double *rec_u = c.bank + (size_t)wm * SSG_MAP_STRIDE;
         for (int q = lane; q < 2 * kBankDoubles; q += 64) {
             const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
             lds[sbank + q] = rec_u[SSG_MAP_OFF_PLANES + sd * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
         }
     }
+#pragma unroll
+    for (int f = 0; f < kDynPsRow; ++f) asm volatile("" : "+v"(ps[f]));
+#pragma unroll
+    for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
+    const unsigned long long live_in = (unsigned long long)__double_as_longlong(rw[kDynRowLive]);
+    const unsigned long long meta_in = (unsigned long long)__double_as_longlong(rw[kDynRowMeta]);
+    const unsigned long long order_in = (unsigned long long)__double_as_longlong(rw[kDynRowOrder]);
+    const unsigned pgm_in = (unsigned)__double_as_longlong(ps[kDynPs]);
+    const int vmap_in = (int)(unsigned)meta_in, age_in0 = (int)((meta_in >> 32) & 255ull);
+    const unsigned gen_now = (unsigned)((meta_in >> 40) & 255ull);
+    const int nmap_in = (int)(unsigned)order_in, ntag_in = (int)(unsigned)(order_in >> 32);
+    // (an entry of a space the env has left is stale; a space the step kernel woke that had queued itself has its own entry)
+    queued = queued && (gen_now & 3u) == (entry >> 30) &&
+             !(etype == DQ_WAKE && (unsigned)__double_as_longlong(rw[kDynRowSelf]) == tick);
+    const bool is_n = queued & (etype == DQ_NJOB);      // the next episode's space: nothing of the player is read
+    const bool fresh = queued & ((etype == DQ_FRESH) | (etype == DQ_NJOB)); // rebuilt from the record: nothing of the space's old state is read
+    const int map_id = UNI ? wm : (is_n ? nmap_in : vmap_in);
+    // The slot of the NEXT step's queue this space takes if this step changes anything: reserved now — at the end it would be one
+    // more dependent round trip on every wave's chain — one atomic per distinct bucket of the wave (its lanes sit on one
+    // record and on one or two ages); a space that comes to rest leaves a null entry in its slot.
+    const int age_next = (fresh ? 0 : age_in0) < 255 ? (fresh ? 0 : age_in0) + 1 : 255;
+    const unsigned bnext = dyn_bucket_of(age_next, map_id);
+    unsigned slot_base = 0u;  // (in the leader lane of my bucket: the atomic's result is not waited for here, see the write-back)
+    int slot_leader = 0, slot_rank = 0;
+    {
+        unsigned long long todo = __ballot(queued & !is_n);
+        while (todo) {
+            const int ld = __ffsll((long long)todo) - 1;
+            const unsigned bb = (unsigned)__builtin_amdgcn_readlane((int)bnext, ld);
+            const unsigned long long same = __ballot(queued & !is_n & (bnext == bb)) & todo;
+            if (lane == ld) slot_base = atomicAdd(c.dyn_count + (size_t)(qi ^ 1u) * kDynCountWords + kDynBucket0 + bb * kDynBucketStride, (unsigned)__popcll(same));
+            if ((same >> lane) & 1ull) { slot_leader = ld; slot_rank = __popcll(same & ((1ull << lane) - 1ull)); }
+            todo &= ~same;
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave per workgroup: the LDS writes above are visible to its lanes
     __builtin_amdgcn_wave_barrier();
+    if (!__any(queued)) continue;
+    {   // (development aid: how full are the waves?)
+        const unsigned long long qb = __ballot(queued);
+        if (d.stop_after == -1 && lane == 0) { atomicAdd(c.dyn_err + 2, (unsigned)__popcll(qb)); atomicAdd(c.dyn_err + 3, 1u); }
+    }
     if (queued) {
     const double dt = c.dt;
     const int ng = c.n_goals;
     const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
     // development aid (SSG_DYN_STOP=-1): phase stamps of this lane's wave into the unused arbiter rows of pair 50..53
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     auto stamp = [&](int i) {
         if (d.stop_after == -1)
             col.f64[(size_t)(DC_ARB + 4 * 50 + i) * np + v] = (double)(__builtin_amdgcn_s_memtime() - t_start);
     };
+    stamp(0);
+    if (d.stop_after == -1) {
+        col.f64[(size_t)(DC_ARB + 4 * 53 + 0) * np + v] = (double)(t_cnt - t_start);
+        col.f64[(size_t)(DC_ARB + 4 * 53 + 1) * np + v] = (double)(t_ent - t_start);
+    }
     // goals still in the space for this cpSpaceStep, and the cached arbiters that survive (set below, once the row is in)
     unsigned gmask = (1u << ng) - 1u;
     unsigned long long live = 0ull, live0 = 0ull;
@@ -876,13 +1048,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
     double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
     {
-        // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
-        // gathers over 75 x 64 lines per wave (the sorted queue scatters a wave's envs over the whole batch)
         static_assert(DC_GOAL_COLS * SSG_MAX_GOALS == kDynRowTraffic && kDynRowTraffic + 9 * SSG_N_TRAFFIC <= kDynRow && kDynRow % 2 == 0, "row layout");
-        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)v * kDynRow);
-        double rw[kDynRow];
-#pragma unroll
-        for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
 #pragma unroll
         for (int g = 0; g < SSG_MAX_GOALS; ++g)
 #pragma unroll
@@ -915,12 +1081,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         // player state the step before THAT left behind (dyn_ps: its cpBodyUpdatePosition is pose = p + v dt, a + w dt whatever
         // the action), the goal mask of that moment, and the goal centres this space holds (= where they were after the last
         // cpSpaceStep).  Same expressions as the step kernel's body role: ship_world(), the box reject, cpPolyShapePointQuery.
-        const unsigned pgm = c.dyn_psgm[(size_t)qi * enp + e];
+        const unsigned pgm = pgm_in;
         unsigned gm = pgm & ((1u << ng) - 1u);
         if (!(pgm & kDynPsSkip)) {
-            double ps[kDynPs];
-#pragma unroll
-            for (int f = 0; f < kDynPs; ++f) ps[f] = c.dyn_ps[((size_t)qi * kDynPs + f) * enp + e];
             const double px = ps[0] + ps[2] * dt, py = ps[1] + ps[3] * dt, pa = ps[4] + ps[5] * dt;
             double psa, pca;
             sincos_body(pa, &psa, &pca);
@@ -963,7 +1126,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             }
         }
         gmask = gm;
-        live = drop_removed_goal_arbiters(col.live[v], gmask, ng);
+        live = drop_removed_goal_arbiters(live_in, gmask, ng);
     }
     live0 = live;
 #pragma unroll
@@ -1056,7 +1219,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     };
     auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
 
-    stamp(0);
     stamp(1);
     prof_last = __builtin_amdgcn_s_memtime();
     // ---- (3) collide, canonical order ---------------------------------------------------------------------------
@@ -1545,28 +1707,47 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         col.f64[(size_t)(DC_ARB + 4 * 50 + 8) * np + v] = (double)dbg_cnt[1];
         col.f64[(size_t)(DC_ARB + 4 * 50 + 9) * np + v] = (double)dbg_cnt[2];
     }
+    const unsigned slot_next = (unsigned)__shfl((int)slot_base, slot_leader) + (unsigned)slot_rank; // the slot reserved at the head
     col.live[v] = live;
     c.dyn_hash[v] = (unsigned long long)d.bank_epoch; // the bank generation this (possible) rest state belongs to
     // unchanged = a fixed point of cpSpaceStep: at rest (bit 2); bit 3: ... with cached arbiters on goals (pair ids 9 ..): the one
     // kind of resting space the player can disturb, by removing such a goal (the step kernel wakes it, shipsim_kernels.hip)
     col.flag[v] = (uint8_t)(changed ? 0u : (4u | ((live >> 9) ? 8u : 0u)));
-    const int age_in = fresh ? 0 : (int)c.dyn_age[v];
-    const int age_out = age_in < 255 ? age_in + 1 : 255;
-    c.dyn_age[v] = (uint8_t)age_out;
+    c.dyn_age[v] = (uint8_t)age_next;
+    {   // the row's mirrors of the live mask and of record / age / generation
+        double2 m;
+        m.x = __longlong_as_double((long long)dyn_meta_pack(map_id, (unsigned)age_next, gen_now));
+        m.y = rw[kDynRowOrder];
+        c.dyn_row[(size_t)v * kDynRow + kDynRowLive] = __longlong_as_double((long long)live);
+        *reinterpret_cast<double2 *>(c.dyn_row + (size_t)v * kDynRow + kDynRowMeta) = m;
+        if (!is_n) {
+            double2 pz;
+            pz.x = __longlong_as_double((long long)dyn_pend_pack(tick + 1u, bnext, slot_next));
+            pz.y = __longlong_as_double((long long)(changed ? tick + 1u : 0u)); // kDynRowSelf
+            *reinterpret_cast<double2 *>(c.dyn_row + (size_t)v * kDynRow + kDynRowPend) = pz;
+        }
+    }
     if (is_n) {
         // the next episode's space has had its first step: it waits for the env to get there (dyn_adopt_kernel)
         c.dyn_vmap[v] = map_id;
-        c.dyn_nvalid[e] = ((unsigned long long)d.bank_epoch << 32) | (unsigned)c.dyn_ntag[e];
-    } else if (changed) {
-        dyn_enqueue(c, tick + 1u, v, DQ_STEP, dyn_bucket_of(age_out, map_id)); // stepped again next step
+        c.dyn_nvalid[e] = ((unsigned long long)d.bank_epoch << 32) | (unsigned)ntag_in;
+    } else {
+        // the slot reserved at the head: stepped again next step if anything changed, a null entry otherwise
+        const unsigned ent = changed ? ((unsigned)v | ((unsigned)DQ_STEP << 28) | ((gen_now & 3u) << 30)) : 0xFFFFFFFFu;
+        if (slot_next < (unsigned)c.dyn_np) c.dyn_region[((size_t)(qi ^ 1u) * kDynBuckets + bnext) * (size_t)c.dyn_np + slot_next] = (int32_t)ent;
+        else atomicAdd(c.dyn_err + 1, 1u);
     }
     } // queued
+    __builtin_amdgcn_s_waitcnt(0xC07F); // (the next wave of work reuses the LDS columns)
+    __builtin_amdgcn_wave_barrier();
+    } // wslot
     leave();
 }
 
 size_t dyn_lds_bytes(int n_goals, bool uni)
 {
-    return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) + (uni ? 2 * kBankDoubles : 0)) * sizeof(double);
+    if (uni) return 2 * (size_t)kWaveLds * sizeof(double); // two waves per workgroup, each with the region of a six-goal space
+    return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
 }
 
 // Raise the dynamic-LDS cap of the full-step kernel (once per handle, like prepare_step).
@@ -1590,9 +1771,15 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
     // one bank record per wave: the buckets tell records apart only when the bank holds at most kDynMapBuckets of them
     // (a per-env ring of worlds never does)
     const bool uni = c.map_ring == 0 && c.n_maps <= kDynMapBuckets;
-    const dim3 grid((unsigned)((c.dyn_np + kDynSortedPad + kGrp - 1) / kGrp));
-    if (uni) hipLaunchKernelGGL(dyn_step_kernel<true>, grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
-    else hipLaunchKernelGGL(dyn_step_kernel<false>, grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+    // the resident set: two workgroups (76 KB of LDS each, one wave alone on its SIMD) per CU; each walks the queue with the grid's stride
+    static const unsigned n_cu = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(cu > 0 ? cu : 256); }();
+    const unsigned worst = (unsigned)((c.dyn_np + kDynSortedPad + kGrp - 1) / kGrp);
+    if (uni) { // one two-wave workgroup per CU
+        const unsigned wg = (worst + 1u) / 2u;
+        hipLaunchKernelGGL(dyn_step_kernel<true>, dim3(wg < n_cu ? wg : n_cu), dim3(128), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
+    } else {
+        hipLaunchKernelGGL(dyn_step_kernel<false>, dim3(worst < n_cu ? worst : n_cu), dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+    }
     return hipGetLastError();
 }
 

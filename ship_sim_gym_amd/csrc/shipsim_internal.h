@@ -60,12 +60,14 @@ constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics o
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride; // per queue
 // queue entry: vspace | type << 28 | (generation & 3) << 30
 enum { DQ_STEP = 0 /* cpSpaceStep of a current space */, DQ_FRESH = 1 /* rebuild the current space from its record, then step */,
-       DQ_NJOB = 2 /* build the next episode's space (N) from its record and step it once */ };
+       DQ_NJOB = 2 /* build the next episode's space (N) from its record and step it once */,
+       DQ_WAKE = 3 /* cpSpaceStep of a current space the step kernel woke: void if the space queued itself for the same step */ };
 constexpr unsigned kDynVMask = (1u << 28) - 1u;
 // what the step kernel reads of the other bodies, per env and step parity: goal g centre at 2g, 2g+1; traffic ship k
 // (x, y, cos a, sin a) at 12 + 4k ..
 constexpr int kDynObsGoals = 0, kDynObsTraffic = 2 * SSG_MAX_GOALS, kDynObs = 2 * SSG_MAX_GOALS + 4 * SSG_N_TRAFFIC;
 constexpr int kDynPs = 6;         // the player state the dyn step predicts the goal removals from: x, y, vx, vy, angle, w
+constexpr int kDynPsRow = 8;      // ... one 64-byte record per env and step parity: the six, [6] the goal mask (bits 0-5; kDynPsSkip), [7] spare
 constexpr unsigned kDynPsSkip = 0x40u; // bit of the ps goal mask: this record predicts nothing (the mask is already current)
 // bits of dyn_req (step kernel -> adopt pass)
 enum { DR_RESET = 2 /* auto-reset this step: adopt N */, DR_FRESH = 4 /* ... but N was not usable: rebuild from the record */,
@@ -81,7 +83,28 @@ __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 // lines per env: [0, 48) goal g field f at 8g + f, [48, 75) traffic ship k field f at 48 + 9k + f.  Written by everything that
 // writes the columns (dyn_init, the full step's write-back, ssg_dyn_invalidate after a caller's own writes); read by the full
 // step only.  The columns stay the interface of everything else (classify pass, step kernel, ssg_state_field).
+constexpr unsigned kDynVMaskU = (1u << 28) - 1u;
 constexpr int kDynRow = 80, kDynRowTraffic = 48;
+// ... and what else the full step needs of the space, so that ONE batch of loads on five lines of the lane brings it all
+// (every separately indexed table was another set of 48 scattered lines — and TLB entries — per wave): [75] the live-arbiter mask,
+// [76] bank record | age << 32 | generation << 40, [77] (N spaces) the N job's order: bank record | episode index << 32.
+// Mirrors of DevCfg::dyn_live / dyn_vmap / dyn_age / dyn_gen / dyn_nmap / dyn_ntag, kept by whoever writes those.
+constexpr int kDynRowLive = 75, kDynRowMeta = 76, kDynRowOrder = 77;
+// [78] where the space's pending queue entry sits — the slot its last dyn step reserved in the next step's queue: slot | bucket << 28 |
+// (tick of that queue & 0xFFFFFF) << 40 — so that the adopt pass can void the entry of a space the env has left (a stale entry
+// must not take the claim on the space from the adopted one's entry).
+constexpr int kDynRowPend = 78;
+// [79] the step the space has queued ITSELF for (its last dyn step changed something; or the adopt pass queued it), 0 = none: a DQ_WAKE
+// entry for that step is a duplicate.
+constexpr int kDynRowSelf = 79;
+__host__ __device__ __forceinline__ unsigned long long dyn_pend_pack(unsigned tick, unsigned bucket, unsigned slot)
+{
+    return (unsigned long long)(slot & kDynVMaskU) | ((unsigned long long)bucket << 28) | ((unsigned long long)(tick & 0xFFFFFFu) << 40);
+}
+__host__ __device__ __forceinline__ unsigned long long dyn_meta_pack(int vmap, unsigned age, unsigned gen)
+{
+    return (unsigned long long)(unsigned)vmap | ((unsigned long long)(age & 255u) << 32) | ((unsigned long long)(gen & 255u) << 40);
+}
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
 constexpr int kStatsDoubles = 4 * kStatsSlots;
@@ -121,13 +144,11 @@ struct DevCfg {
     uint8_t *dyn_gen;             // [dyn_np] generation of the space: queue entries of an older one are stale (the env was reset meanwhile)
     uint8_t *dyn_age;             // [dyn_np] cpSpaceSteps this space has had (saturating): its sort bucket
     int32_t *dyn_vmap;            // [dyn_np] bank record the space was built from
-    unsigned *dyn_qstamp;         // [dyn_np] the tick the space was last queued for (a space is queued once per step)
     uint8_t *dyn_req;             // [n_pad] DR_* bits: step kernel -> adopt pass -> classify pass
     unsigned long long *dyn_nvalid; // [n_pad] bank generation << 32 | episode index the N space was built for
     int32_t *dyn_nmap, *dyn_ntag; // [n_pad] the N job's order: bank record and episode index
     double *dyn_obs;              // [2][kDynObs][n_pad] by step parity: what the step kernel reads of the other bodies
-    double *dyn_ps;               // [2][kDynPs][n_pad] by step parity: the player state after the step (post-reset), step kernel -> dyn step
-    uint8_t *dyn_psgm;            // [2][n_pad] ... its goal mask (bits 0-5; kDynPsSkip)
+    double *dyn_ps;               // [2][n_pad][kDynPsRow] by step parity: the player state after the step (post-reset) and its goal mask, step kernel -> dyn step
     int32_t *dyn_region;          // [2][kDynBuckets][dyn_np] queue entries, bucket b of queue q at [(q * kDynBuckets + b) * dyn_np ..)
     unsigned *dyn_count;          // [2][kDynCountWords] per queue: [0] exit ticket of the consuming kernel; [kDynBucket0 + b * kDynBucketStride] bucket counters
     unsigned *dyn_err;            // [4] should-never-happen counters: [0] adoption without a usable N inside a pipelined rollout, [1] queue overflow
@@ -194,11 +215,10 @@ __device__ __forceinline__ int next_map_of(const DevCfg &c, int map_id)
     return (nxt >= c.n_maps) ? 0 : nxt;
 }
 
-// Append an entry to the queue of step `tick` (at most once per space and step: dyn_qstamp).
-__device__ __forceinline__ void dyn_enqueue(const DevCfg &c, unsigned tick, int v, unsigned type, unsigned bucket, bool force = false)
+// Append an entry to the queue of step `tick`.  (A space may be queued twice for one step — by the dyn step that stepped it and, as
+// DQ_WAKE, by the step kernel: the consumer drops a DQ_WAKE entry of a space that queued itself, kDynRowSelf.)
+__device__ __forceinline__ void dyn_enqueue(const DevCfg &c, unsigned tick, int v, unsigned type, unsigned bucket)
 {
-    if (!force && atomicMax(c.dyn_qstamp + v, tick) >= tick) return; // already queued for this step
-    if (force) c.dyn_qstamp[v] = tick;
     const unsigned q = tick & 1u;
     const unsigned slot = atomicAdd(c.dyn_count + (size_t)q * kDynCountWords + kDynBucket0 + bucket * kDynBucketStride, 1u);
     if (slot >= (unsigned)c.dyn_np) { atomicAdd(c.dyn_err + 1, 1u); return; }

@@ -148,46 +148,6 @@ __device__ __forceinline__ double goal_at(const DevCfg &c, int goff, int g, int 
     else return bank_at<LDS_BANK>(c, goff + 2 * g + comp);
 }
 
-// collide_ship (game.py:232-241) of the player against traffic ship k (config 4): cpBBIntersects, then "touching counts" SAT
-// over both hulls' edge normals.  Rare (the caller rejects by reach first) and deliberately not inlined: its registers must
-// not weigh on the body role's step loop.
-__device__ __attribute__((noinline)) bool traffic_touch(const DevCfg &c, int k, double x, double y, double ca, double sa, double tx, double ty,
-                                                        double tca, double tsa)
-{
-    double ax[SSG_SHIP_VERTS], ay[SSG_SHIP_VERTS], bx[SSG_SHIP_VERTS], by[SSG_SHIP_VERTS];
-    double al = INFINITY, ar = -INFINITY, ab = INFINITY, at = -INFINITY, bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-        const double hx = c.hull[2 * i], hy = c.hull[2 * i + 1];
-        ax[i] = ca * hx + (-sa) * hy + x; ay[i] = sa * hx + ca * hy + y;
-        al = fmin(al, ax[i]); ar = fmax(ar, ax[i]); ab = fmin(ab, ay[i]); at = fmax(at, ay[i]);
-        const double gx = c.thull[k][2 * i], gy = c.thull[k][2 * i + 1];
-        bx[i] = tca * gx + (-tsa) * gy + tx; by[i] = tsa * gx + tca * gy + ty;
-        bl = fmin(bl, bx[i]); br = fmax(br, bx[i]); bb = fmin(bb, by[i]); bt = fmax(bt, by[i]);
-    }
-    if (!((al <= br) & (bl <= ar) & (ab <= bt) & (bb <= at))) return false;
-    bool sep = false;
-#pragma unroll
-    for (int i = 0; i < SSG_SHIP_VERTS; ++i) { // the player's edge normals
-        const double nx = ca * c.nrm[2 * i] + (-sa) * c.nrm[2 * i + 1], ny = sa * c.nrm[2 * i] + ca * c.nrm[2 * i + 1];
-        const double off = nx * ax[i] + ny * ay[i];
-        double mn = INFINITY;
-#pragma unroll
-        for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, nx * bx[j] + ny * by[j]);
-        sep |= mn > off;
-    }
-#pragma unroll
-    for (int i = 0; i < SSG_SHIP_VERTS; ++i) { // the traffic ship's
-        const double nx = tca * c.tnrm[k][2 * i] + (-tsa) * c.tnrm[k][2 * i + 1], ny = tsa * c.tnrm[k][2 * i] + tca * c.tnrm[k][2 * i + 1];
-        const double off = nx * bx[i] + ny * by[i];
-        double mn = INFINITY;
-#pragma unroll
-        for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, nx * ax[j] + ny * ay[j]);
-        sep |= mn > off;
-    }
-    return !sep;
-}
-
 // ShipGame.closest_goal (game.py:333-349): strict '<', first listed goal wins ties; (-1,-1) when none left.
 template <bool LDS_BANK, bool DYN>
 __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned gm, double x, double y, double &gx,
@@ -260,11 +220,12 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 __host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
+constexpr int kTrafficTabBytes = SSG_N_TRAFFIC * 4 * 8 * 8; // config 4: per traffic ship k, [k][0..3][i] = local vertex x, y, plane normal x, y
 constexpr int kPoseDoubles = 7;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
-    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 6 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * kGoalScratchBytes;
+    return kBeamTabBytes + kShipTabBytes + kTrafficTabBytes + kPoseDoubles * epw * 8 + 6 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * kGoalScratchBytes;
 }
 __host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
 __host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
@@ -865,7 +826,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [7][EPW]
+    double *traffictab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [3][4][8], config 4
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes + kTrafficTabBytes); // [7][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
     int *poser = posem + EPW;                                                                // [EPW]
     unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
@@ -903,6 +865,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[0 * 8 + i] = c.hull[2 * i];     shiptab[1 * 8 + i] = c.hull[2 * i + 1];   // vertex i
         shiptab[2 * 8 + i] = c.nrm[2 * i];      shiptab[3 * 8 + i] = c.nrm[2 * i + 1];    // plane normal i
         shiptab[4 * 8 + i] = c.hull[2 * ip];    shiptab[5 * 8 + i] = c.hull[2 * ip + 1];  // vertex i-1 (edge start)
+    }
+    if constexpr (DYN) {
+        if (threadIdx.x >= 160 && threadIdx.x < 160 + SSG_N_TRAFFIC * SSG_SHIP_VERTS) {
+            const int kk = (threadIdx.x - 160) / SSG_SHIP_VERTS, i = (threadIdx.x - 160) % SSG_SHIP_VERTS;
+            traffictab[(kk * 4 + 0) * 8 + i] = c.thull[kk][2 * i]; traffictab[(kk * 4 + 1) * 8 + i] = c.thull[kk][2 * i + 1];
+            traffictab[(kk * 4 + 2) * 8 + i] = c.tnrm[kk][2 * i];  traffictab[(kk * 4 + 3) * 8 + i] = c.tnrm[kk][2 * i + 1];
+        }
     }
     if (threadIdx.x == 128) {
         // lidar origin of a freshly reset ship (angle 0: cpvforangle(0) = (1, 0)): pos + half the world AABB extents,
@@ -1305,21 +1274,86 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
-    // config 4: collide_ship against the traffic ships, where this step's cpSpaceStep left them (DevCfg::dyn_obs).  No vertex of
-    // ship k's hull is further than its hull radius from its body position: a player whose world box is further than that from
-    // the position cannot touch it (a conservative pre-reject of cpBBIntersects; the exact test decides).
+    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep left them
+    // (DevCfg::dyn_obs): cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the rejects
+    // run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world box is
+    // further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass go
+    // into the tile's pair queue (the goal narrowphase's, which runs after this) and are served 12 at a time by the whole wave:
+    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.
     bool hit_traffic = false;
     unsigned dflag = 0;
     if constexpr (DYN) {
         dflag = c.dyn_flag[el_];
         const double *tob = c.dyn_obs + ((size_t)(c.dyn_tick & 1u) * kDynObs + kDynObsTraffic) * np + el_;
-#pragma unroll 1
-        for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) { // (rolled: one call site)
+        unsigned short *tq = reinterpret_cast<unsigned short *>(goal_scratch0 + (tl >> 6) * kGoalScratchBytes);
+        unsigned *tw = reinterpret_cast<unsigned *>(tq + 64 * SSG_MAX_GOALS);
+        static_assert(SSG_N_TRAFFIC <= SSG_MAX_GOALS, "the traffic pairs of a tile fit the goal pair queue");
+        tw[lane] = 0u;
+        int n_tp = 0;
+#pragma unroll
+        for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
             const double tx = tob[(size_t)(4 * kk) * np], ty = tob[(size_t)(4 * kk + 1) * np];
             const double dx = dmax(dmax(sbl - tx, tx - sbr), 0.0), dy = dmax(dmax(sbb - ty, ty - sbt), 0.0);
-            if (live & ((dx * dx + dy * dy) <= c.dyn_reach2[kk]))
-                hit_traffic |= traffic_touch(c, kk, x, y, ca, sa, tx, ty, tob[(size_t)(4 * kk + 2) * np], tob[(size_t)(4 * kk + 3) * np]);
+            bool cand = false;
+            if (live & ((dx * dx + dy * dy) <= c.dyn_reach2[kk])) {
+                const double tca = tob[(size_t)(4 * kk + 2) * np], tsa = tob[(size_t)(4 * kk + 3) * np];
+                double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+                    const double gx = traffictab[(kk * 4 + 0) * 8 + i], gy = traffictab[(kk * 4 + 1) * 8 + i];
+                    const double wx = tca * gx + (-tsa) * gy + tx, wy = tsa * gx + tca * gy + ty;
+                    bl = dmin(bl, wx); br = dmax(br, wx); bb = dmin(bb, wy); bt = dmax(bt, wy);
+                }
+                cand = (sbl <= br) & (bl <= sbr) & (sbb <= bt) & (bb <= sbt); // cpBBIntersects(player, ship k)
+            }
+            const unsigned long long m = __ballot(cand);
+            const int pos = n_tp + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (cand) tq[pos] = (unsigned short)(lane | (kk << 6));
+            n_tp += __popcll(m);
         }
+        for (int base = 0; base < n_tp; base += 12) {
+            const int p = base + wq;
+            const bool valid = (lane < 60) & (p < n_tp);
+            const unsigned code = tq[valid ? p : 0];
+            const int src = code & 63, kk = code >> 6;
+            const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
+            const double *tsrc = tob - el_ + (blockIdx.x * EPW + (tl & ~63) + src); // env `src` of this tile (a live one: it queued the pair)
+            const double tx = tsrc[(size_t)(4 * kk) * np], ty = tsrc[(size_t)(4 * kk + 1) * np];
+            const double tca = tsrc[(size_t)(4 * kk + 2) * np], tsa = tsrc[(size_t)(4 * kk + 3) * np];
+            const double *tt = traffictab + kk * 32;
+            bool sep;
+            {   // axis = the player's edge normal i: every vertex of the ship strictly in front of the player's vertex i?
+                const double nx = bca * w_nx + (-bsa) * w_ny, ny = bsa * w_nx + bca * w_ny;
+                const double vx_ = bca * w_hx + (-bsa) * w_hy + bx, vy_ = bsa * w_hx + bca * w_hy + by;
+                const double off = nx * vx_ + ny * vy_;
+                double mn = INFINITY;
+#pragma unroll
+                for (int j = 0; j < SSG_SHIP_VERTS; ++j) {
+                    const double gx = tt[0 * 8 + j], gy = tt[1 * 8 + j];
+                    const double qx = tca * gx + (-tsa) * gy + tx, qy = tsa * gx + tca * gy + ty;
+                    mn = dmin(mn, nx * qx + ny * qy);
+                }
+                sep = mn > off;
+            }
+            {   // axis = the ship's edge normal i
+                const double lnx = tt[2 * 8 + wi], lny = tt[3 * 8 + wi], lvx = tt[0 * 8 + wi], lvy = tt[1 * 8 + wi];
+                const double nx = tca * lnx + (-tsa) * lny, ny = tsa * lnx + tca * lny;
+                const double vx_ = tca * lvx + (-tsa) * lvy + tx, vy_ = tsa * lvx + tca * lvy + ty;
+                const double off = nx * vx_ + ny * vy_;
+                double mn = INFINITY;
+#pragma unroll
+                for (int j = 0; j < SSG_SHIP_VERTS; ++j) {
+                    const double hx = shiptab[0 * 8 + j], hy = shiptab[1 * 8 + j];
+                    const double qx = bca * hx + (-bsa) * hy + bx, qy = bsa * hx + bca * hy + by;
+                    mn = dmin(mn, nx * qx + ny * qy);
+                }
+                sep |= mn > off;
+            }
+            const unsigned long long ms = __ballot(valid & sep);
+            const bool separated = ((ms >> (5 * wq)) & 31ull) != 0ull;
+            if (valid & (wi == 0) & !separated) atomicOr(&tw[src], 1u);
+        }
+        hit_traffic = tw[lane] != 0u;
     }
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
@@ -1448,7 +1482,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0), gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
                 reach |= (bool)((gm >> g) & 1u) & ((gx - r) <= (sbr + mx)) & ((sbl - mx) <= (gx + r)) & ((gy - r) <= (sbt + my)) & ((sbb - my) <= (gy + r));
             }
-            if (reach) dyn_enqueue(c, c.dyn_tick + 2u, el_, DQ_STEP, dyn_bucket_of(kDynAgeBuckets - 1, map_id));
+            if (reach) dyn_enqueue(c, c.dyn_tick + 2u, el_, DQ_WAKE, dyn_bucket_of(kDynAgeBuckets - 1, map_id));
         }
     }
     if (do_reset) {
@@ -1461,9 +1495,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     if constexpr (DYN) {
         // the player state the cpSpaceStep after the next one predicts the next step's goal removals from (post-reset)
         if (live) {
-            double *ps = c.dyn_ps + (size_t)(c.dyn_tick & 1u) * kDynPs * np + el_;
-            st_out(&ps[0 * np], x); st_out(&ps[1 * np], y); st_out(&ps[2 * np], vx); st_out(&ps[3 * np], vy); st_out(&ps[4 * np], ang); st_out(&ps[5 * np], w);
-            st_out(&c.dyn_psgm[(size_t)(c.dyn_tick & 1u) * np + el_], (uint8_t)(gm & ((1u << c.n_goals) - 1u)));
+            // (one 64-byte record per env: the 64 lanes of the wave write 4 KB in a row)
+            double2 *ps = reinterpret_cast<double2 *>(c.dyn_ps + ((size_t)(c.dyn_tick & 1u) * np + el_) * kDynPsRow);
+            double2 a0, a1, a2, a3;
+            a0.x = x; a0.y = y; a1.x = vx; a1.y = vy; a2.x = ang; a2.y = w;
+            a3.x = __longlong_as_double((long long)(gm & ((1u << c.n_goals) - 1u))); a3.y = 0.0;
+            ps[0] = a0; ps[1] = a1; ps[2] = a2; ps[3] = a3;
         }
     }
     if (k == K - 1 && live && !SSG_ABL(9)) { // the state goes back to its columns with the last step of the launch
