@@ -20,8 +20,7 @@ struct ssg_handle {
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     // config 4 only (shipsim_internal.h DevCfg::dyn_*)
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0, off_dyn_hash = 0, off_dyn_row = 0;
-    size_t off_dyn_gen = 0, off_dyn_age = 0, off_dyn_vmap = 0, off_dyn_req = 0, off_dyn_nvalid = 0, off_dyn_nmap = 0,
-           off_dyn_ntag = 0, off_dyn_obs = 0, off_dyn_ps = 0, off_dyn_region = 0, off_dyn_count = 0, off_dyn_err = 0;
+    size_t off_dyn_gen = 0, off_dyn_age = 0, off_dyn_vmap = 0, off_dyn_req = 0, off_dyn_nvalid = 0, off_dyn_obs = 0, off_dyn_ps = 0, off_dyn_region = 0, off_dyn_count = 0, off_dyn_err = 0;
     bool dyn_queue_valid = false; // the queues of the coming steps are what the kernels left (nothing host-side touched the envs since)
     unsigned dyn_tick = 1;        // the next API step (its parity selects the per-step buffers of the dyn pipeline)
     ssg::DynCfg dyn{};
@@ -343,7 +342,7 @@ void refresh_dev(ssg_handle *h)
     d.bank = h->bank;
     d.n_ships = c.n_ships;
     const bool dyn = base && c.n_ships > 1;
-    d.dyn_np = 2 * h->n_pad;
+    d.dyn_np = 3 * h->n_pad;
     d.dyn_tick = h->dyn_tick;
     auto at = [&](size_t off) -> char * { return dyn ? base + off : nullptr; };
     d.dyn_f64 = reinterpret_cast<double *>(at(h->off_dyn_f64));
@@ -357,8 +356,6 @@ void refresh_dev(ssg_handle *h)
     d.dyn_vmap = reinterpret_cast<int32_t *>(at(h->off_dyn_vmap));
     d.dyn_req = reinterpret_cast<uint8_t *>(at(h->off_dyn_req));
     d.dyn_nvalid = reinterpret_cast<unsigned long long *>(at(h->off_dyn_nvalid));
-    d.dyn_nmap = reinterpret_cast<int32_t *>(at(h->off_dyn_nmap));
-    d.dyn_ntag = reinterpret_cast<int32_t *>(at(h->off_dyn_ntag));
     d.dyn_obs = reinterpret_cast<double *>(at(h->off_dyn_obs));
     d.dyn_ps = reinterpret_cast<double *>(at(h->off_dyn_ps));
     d.dyn_region = reinterpret_cast<int32_t *>(at(h->off_dyn_region));
@@ -518,8 +515,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     }
     if (h->cfg.n_ships > 1) {
         // config 4: columns of the traffic ships, goal bodies and cached arbiters (shipsim_internal.h DC_* / DU_*)
-        // (every per-space column has 2 * n_pad elements: env e's current space e and its next episode's n_pad + e)
-        const size_t dnp = 2 * np;
+        // (every per-space column has 3 * n_pad elements: env e's current space e and its two N slots n_pad + e, 2 n_pad + e)
+        const size_t dnp = 3 * np;
         auto take = [&](size_t &off, size_t bytes) { off = (h->nbytes + 255) & ~(size_t)255; h->nbytes = off + bytes; };
         take(h->off_dyn_f64, (size_t)ssg::DC_COUNT * dnp * sizeof(double));
         take(h->off_dyn_live, dnp * sizeof(unsigned long long));
@@ -531,10 +528,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         take(h->off_dyn_age, dnp);
         take(h->off_dyn_vmap, dnp * sizeof(int32_t));
         take(h->off_dyn_req, np);
-        take(h->off_dyn_nvalid, np * sizeof(unsigned long long));
-        take(h->off_dyn_nmap, np * sizeof(int32_t));
-        take(h->off_dyn_ntag, np * sizeof(int32_t));
-        take(h->off_dyn_obs, 2 * (size_t)ssg::kDynObs * np * sizeof(double));
+        take(h->off_dyn_nvalid, 2 * np * sizeof(unsigned long long));
+        take(h->off_dyn_obs, (size_t)ssg::kDynObsPlanes * ssg::kDynObs * np * sizeof(double));
         take(h->off_dyn_ps, 2 * (size_t)ssg::kDynPsRow * np * sizeof(double));
         take(h->off_dyn_count, 2 * (size_t)ssg::kDynCountWords * sizeof(unsigned));
         take(h->off_dyn_err, 256);
@@ -582,10 +577,10 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
     } else if (field == SSG_F_TRAFFIC || field == SSG_F_GOAL_BODIES) {
         if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
         const int c0 = field == SSG_F_TRAFFIC ? ssg::DC_TRAFFIC : ssg::DC_GOALS;
-        // (a dyn column has 2 * n_pad elements — the envs' current spaces, then their next episodes': the stride says so)
-        off = h->off_dyn_f64 + (size_t)c0 * 2 * np * 8; es = 8;
+        // (a dyn column has 3 * n_pad elements — the envs' current spaces, then their coming episodes': the stride says so)
+        off = h->off_dyn_f64 + (size_t)c0 * 3 * np * 8; es = 8;
         nc = field == SSG_F_TRAFFIC ? 9 * SSG_N_TRAFFIC : ssg::DC_GOAL_COLS * SSG_MAX_GOALS;
-        *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = 2 * np * 8;
+        *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = 3 * np * 8;
         return SSG_OK;
     } else if (field == SSG_F_EPISODES) {
         off = h->off_i32 + (size_t)ssg::ICOL_EPISODE * np * 4; es = 4; nc = 1;
@@ -767,10 +762,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
     auto flags_at = [&](int k) { return dev_flags ? dev_flags + (size_t)k * (size_t)traj : nullptr; };
     const bool dyn = h->cfg.n_ships > 1;
     if (dyn) {
-        // Config 4.  Per step: the adopt pass (envs the last step auto-reset take over their next episode's space), the full
-        // dyn step of the queued spaces, the step kernel.  Inside a rollout of several steps the dyn step of step k+1 runs
-        // beside the step kernel of step k on the handle's second stream (shipsim_dynamics.hip header: it needs nothing that
-        // step kernel produces); the first dyn step of the call has nothing to run beside.
+        // Config 4.  Per step: the full dyn step of the queued spaces, then the step kernel — two launches.  Inside a rollout of
+        // several steps the dyn step of step k+1 runs beside the step kernel of step k on the handle's second stream
+        // (shipsim_dynamics.hip header: it needs nothing that step kernel produces); the first dyn step of the call has nothing
+        // to run beside.
         const bool shift = h->cfg.history > 2;
         hipStream_t sa = static_cast<hipStream_t>(stream);
         if (h->cfg.map_ring > 0 && !h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds first");
@@ -782,9 +777,8 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
         // what must precede the dyn step of step `tick` on stream sa: adoptions, and the queues rebuilt if the host touched the envs
         auto prologue = [&]() -> hipError_t {
             h->dev.dyn_tick = h->dyn_tick;
-            hipError_t e = ssg::launch_dyn_adopt(h->dev, h->dyn, h->dyn_queue_valid, sa);
-            if (e != hipSuccess || h->dyn_queue_valid) return e;
-            e = hipMemsetAsync(h->dev.dyn_count, 0, 2 * (size_t)ssg::kDynCountWords * sizeof(unsigned), sa);
+            if (h->dyn_queue_valid) return hipSuccess;
+            hipError_t e = hipMemsetAsync(h->dev.dyn_count, 0, 2 * (size_t)ssg::kDynCountWords * sizeof(unsigned), sa);
             if (e == hipSuccess) e = ssg::launch_dyn_classify(h->dev, h->dyn, sa);
             return e;
         };
@@ -807,7 +801,7 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 h->ring_credit -= kk;
             }
             hipError_t e = prologue();
-            if (e != hipSuccess) return bail("dyn adopt / classify launch: ", e);
+            if (e != hipSuccess) return bail("dyn classify launch: ", e);
             h->dyn_queue_valid = true;
             e = ssg::launch_dyn_step(h->dev, h->dyn, sa);
             if (e != hipSuccess) return bail("dyn step launch: ", e);
@@ -815,8 +809,8 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
             if (!pipelined) {
                 for (int j = 0; j < kk; ++j) {
                     if (j > 0) {
-                        e = prologue();
-                        if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, sa);
+                        h->dev.dyn_tick = h->dyn_tick;
+                        e = ssg::launch_dyn_step(h->dev, h->dyn, sa);
                         if (e != hipSuccess) return bail("dyn step launch: ", e);
                     }
                     e = step_launch(k + j);
@@ -837,16 +831,17 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 }
                 hipStream_t sb = h->dyn_stream;
                 static const int kNoSync = [] { const char *sv = std::getenv("SSG_DYN_NOSYNC"); return sv ? std::atoi(sv) : 0; }(); // (timing experiments only: wrong results)
-                // Stream B carries the chain that bounds the step — dyn(t+1), adopt(t), dyn(t+2), ... in order, no cross-stream
-                // hand-over on it except the wait for step kernel t, long finished by then; stream A runs the step kernels, each
-                // after the adopt pass before it.
-                e = hipEventRecord(h->ev_adopt, sa);
+                // Stream B carries the chain that bounds the step — dyn(t+1), dyn(t+2), ... in order; each waits for the step
+                // kernel two steps back (the player state it predicts from; long finished as a rule).  Stream A runs the step
+                // kernels, each after the dyn step of its own step.
+                e = hipEventRecord(h->ev_adopt, sa); // (the call's first dyn step, on A)
                 if (e == hipSuccess) e = hipStreamWaitEvent(sb, h->ev_adopt, 0);
                 for (int j = 0; j < kk && e == hipSuccess; ++j) {
                     const bool more = j + 1 < kk;
                     if (more) { // the dyn step of the NEXT step, beside this step's kernel
                         h->dev.dyn_tick = h->dyn_tick + 1;
                         e = ssg::launch_dyn_step(h->dev, h->dyn, sb);
+                        if (e == hipSuccess) e = hipEventRecord(h->ev_adopt, sb);
                         if (e != hipSuccess) break;
                     }
                     h->dev.dyn_tick = h->dyn_tick;
@@ -854,15 +849,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                     h->dyn_tick += 1;
                     if (e == hipSuccess && more) {
                         if (!(kNoSync & 1)) {
-                            e = hipEventRecord(h->ev_dyn, sa); // (step kernel t done)
+                            e = hipEventRecord(h->ev_dyn, sa); // (step kernel t done: dyn(t+2) reads what it left)
                             if (e == hipSuccess) e = hipStreamWaitEvent(sb, h->ev_dyn, 0);
                         }
-                        h->dev.dyn_tick = h->dyn_tick;
-                        if (e == hipSuccess) e = ssg::launch_dyn_adopt(h->dev, h->dyn, true, sb);
-                        if (!(kNoSync & 2)) {
-                            if (e == hipSuccess) e = hipEventRecord(h->ev_adopt, sb);
-                            if (e == hipSuccess) e = hipStreamWaitEvent(sa, h->ev_adopt, 0);
-                        }
+                        if (!(kNoSync & 2) && e == hipSuccess) e = hipStreamWaitEvent(sa, h->ev_adopt, 0); // (step kernel t+1 reads what dyn(t+1) leaves)
                     }
                 }
                 if (e != hipSuccess) return bail("pipelined config-4 rollout: ", e);

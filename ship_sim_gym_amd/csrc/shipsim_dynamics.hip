@@ -40,12 +40,15 @@
 //     stream A:  step(k)   | adopt(k)            | step(k+1) | ...
 //     stream B:  dyn(k+1)  |          dyn(k+2)                | ...
 // (b): an env the step kernel auto-resets needs its NEW world's first cpSpaceStep before the next step kernel — a fresh
-// world's hardest step (ship 1 spawns inside the left bank).  Every env therefore keeps the space of its NEXT episode ready,
-// built from its record and stepped once ("N", vspace n_pad + e; nothing in it depends on the player): dyn_adopt_kernel copies
-// N over the current space (C) for the envs that were reset and orders the N of the episode after.  The step kernel reads the
-// other bodies from a per-parity table (DevCfg::dyn_obs) while the next dyn step already rewrites the columns, and runs
-// collide_ship against the traffic ships itself.
-// Per step: dyn_adopt_kernel (small), dyn_step_kernel, the step kernel — the last two side by side inside ssg_rollout*.
+// world's hardest step (ship 1 spawns inside the left bank).  Every env therefore keeps the spaces of its coming episodes
+// ready, built from their records and stepped once ("N" slots, vspace (1 + s) * n_pad + e, episode q in slot q & 1; nothing in
+// them depends on the player): an N job publishes what the step kernel needs of it in its own plane of DevCfg::dyn_obs.  On
+// a reset at step t the step kernel (i) reads step t+1's bodies from that plane, (ii) queues, for the dyn step of step t+2,
+// an ADOPT entry — cpSpaceStep FROM the N slot INTO the current space (C) — and the N job of the episode after.  The
+// step kernel otherwise reads the other bodies from the per-parity planes of dyn_obs while the next dyn step already rewrites
+// the columns, and runs collide_ship against the traffic ships itself.  So the body columns (SSG_F_TRAFFIC,
+// SSG_F_GOAL_BODIES) of an env lag its auto-reset by two steps.
+// Per step: dyn_step_kernel and the step kernel — two launches, side by side inside ssg_rollout*.
 //
 // The canonical pair order, the cold GJK start and the unsolved player arbiters are the named assumptions of the
 // oracle (oracle/ssg_dynamics.c header); this file follows the same ones.
@@ -65,6 +68,8 @@ namespace {
 // LDS holds, and as ONE workgroup they fill whole CUs — the CUs the queue does not need stay entirely free for the step kernel
 // running beside this one (a 1 024-thread workgroup of it needs a whole CU's LDS and never found one when these waves were
 // spread one or two per CU over the chip).
+// (kUniWpg = 1: measured — two waves of one workgroup on a CU run 74 -> 87 us, and the free CUs bought the step kernel nothing)
+constexpr int kUniWpg = 1;
 extern __shared__ double lds_all[];
 #define lds (lds_all + (threadIdx.x >> 6) * kWaveLds)
 
@@ -577,7 +582,7 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
     c.dyn_gen[e] = (uint8_t)gen_new;
     c.dyn_age[e] = 0;
     c.dyn_vmap[e] = m;
-    c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, 0u, gen_new));
+    c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, 0u, 0u));
     dyn_publish_obs(c, e, e);
 }
 // 64-bit mixing for the "did this step change anything" test of the full step (inputs vs outputs, no re-reads).
@@ -630,163 +635,6 @@ __device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigne
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// dyn_adopt_kernel (c.dyn_tick = k: step k is the next one).  An env the step kernel auto-reset in step k-1 (DR_RESET) starts
-// step k on its next world, whose other bodies must then have had their first cpSpaceStep: that is what its N space holds
-// (built and stepped by an earlier dyn step, from the record the env has just moved to).  N is copied over C — body columns,
-// row shadow, live arbiters — and published to the step kernel; C is queued for step k+1 unless it is already at rest, and the N
-// of the episode after this one is ordered (enqueue = true; the classify pass does both otherwise).  Without a usable N
-// (never inside a pipelined rollout: a new bank, the first step of a handle) the env is marked DR_FRESH: the dyn step of
-// step k rebuilds C from the record.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dyn_adopt_kernel(const DevCfg c, const DynCfg d, const int enqueue)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= c.n_envs) return;
-    const unsigned req = c.dyn_req[e];
-    if (!(req & DR_RESET)) return;
-    // (this pass sits between two dyn steps of a pipelined rollout: its dependent memory round trips are the step's time.
-    // Everything is requested in one go; the stores and the two queue atomics follow.)
-    const size_t dnp = (size_t)c.dyn_np, np = (size_t)c.n_pad;
-    const int vn = c.n_pad + e;
-    int map_now = c.i32cols[(size_t)ICOL_MAP * np + e];          // the record the step kernel moved the env to
-    int episode = c.i32cols[(size_t)ICOL_EPISODE * np + e];      // ... and the episode it started there
-    unsigned long long nvalid = c.dyn_nvalid[e];
-    int vmap_n = c.dyn_vmap[vn];
-    unsigned gen_e = c.dyn_gen[e];
-    unsigned long long live = c.dyn_live[vn];
-    unsigned flag_n = c.dyn_flag[vn];
-    unsigned long long hash_n = c.dyn_hash[vn];
-    unsigned long long pend_c = (unsigned long long)__double_as_longlong(c.dyn_row[(size_t)e * kDynRow + kDynRowPend]); // the old space's queue entry
-    // Body fields: N's row shadow holds them all (80 contiguous doubles: independent loads, one round trip), then the stores —
-    // C's columns, C's row, the step kernel's table.  (Column by column, 81 dependent load / store pairs per env made this pass
-    // 65 us long.)
-    double rw[kDynRow], rot[2 * SSG_N_TRAFFIC];
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)vn * kDynRow);
-#pragma unroll
-        for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = src[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
-#pragma unroll
-        for (int f = 0; f < 2 * SSG_N_TRAFFIC; ++f) rot[f] = c.dyn_f64[(size_t)(DC_TROT + f) * dnp + vn];
-    }
-    asm volatile("" : "+v"(map_now), "+v"(episode), "+v"(nvalid), "+v"(vmap_n), "+v"(gen_e), "+v"(live), "+v"(flag_n), "+v"(hash_n), "+v"(pend_c));
-#pragma unroll
-    for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
-    const bool usable = nvalid == (((unsigned long long)d.bank_epoch << 32) | (unsigned)episode) && vmap_n == map_now;
-    const unsigned gen_new = (gen_e + 1u) & 0xFFu;
-    c.dyn_gen[e] = (uint8_t)gen_new; // whatever was queued for the old space is stale ...
-    // ... and must not take the claim on the space from the entry queued below: the slot the old space's last dyn step
-    // reserved in the queue of step k+1 is voided
-    if ((unsigned)(pend_c >> 40) == ((c.dyn_tick + 1u) & 0xFFFFFFu)) {
-        const unsigned pb = (unsigned)(pend_c >> 28) & (unsigned)(kDynBuckets - 1), psl = (unsigned)pend_c & kDynVMaskU;
-        if (psl < (unsigned)c.dyn_np) c.dyn_region[((size_t)((c.dyn_tick + 1u) & 1u) * kDynBuckets + pb) * dnp + psl] = (int32_t)0xFFFFFFFFu;
-    }
-    if (!usable) {
-        c.dyn_req[e] = (uint8_t)DR_FRESH;
-        if (enqueue) atomicAdd(c.dyn_err + 0, 1u); // (a pipelined rollout has no dyn step left in front of the next step kernel)
-        return;
-    }
-    // queue slots: C for the step after the coming one (unless it is at rest already), the N of the episode after this one
-    const unsigned tq = c.dyn_tick + 1u, qq = tq & 1u;
-    const bool want_c = enqueue && !(flag_n & 4u), want_n = enqueue && (c.flags & SSG_FLAG_AUTO_RESET);
-    const int nm = next_map_of(c, map_now);
-    const unsigned bc = dyn_bucket_of(1, map_now), bn = dyn_bucket_of(0, nm);
-    unsigned slot_c = 0u, slot_n = 0u;
-    if (want_c) slot_c = atomicAdd(c.dyn_count + (size_t)qq * kDynCountWords + kDynBucket0 + bc * kDynBucketStride, 1u);
-    if (want_n) slot_n = atomicAdd(c.dyn_count + (size_t)qq * kDynCountWords + kDynBucket0 + bn * kDynBucketStride, 1u);
-    // cached arbiters (a handful at most): loads first
-    constexpr int kMaxCopy = 8;
-    int apid[kMaxCopy];
-    unsigned ameta[kMaxCopy], ahash[kMaxCopy];
-    double aacc[kMaxCopy][4];
-    int n_arb = 0;
-    {
-        unsigned long long lv = live;
-#pragma unroll
-        for (int i = 0; i < kMaxCopy; ++i) {
-            apid[i] = -1; ameta[i] = 0u; ahash[i] = 0u;
-            if (lv) {
-                const int pid = __ffsll((long long)lv) - 1;
-                lv &= lv - 1ull;
-                apid[i] = pid;
-                ameta[i] = c.dyn_u32[(size_t)(DU_META + pid) * dnp + vn];
-                if (pid < kPolyPairs) ahash[i] = c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + vn];
-#pragma unroll
-                for (int f = 0; f < 4; ++f) aacc[i][f] = c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + vn];
-                n_arb = i + 1;
-            }
-        }
-        while (lv) { // (more than eight cached arbiters after one step of a fresh world: never seen; kept correct)
-            const int pid = __ffsll((long long)lv) - 1;
-            lv &= lv - 1ull;
-            c.dyn_u32[(size_t)(DU_META + pid) * dnp + e] = c.dyn_u32[(size_t)(DU_META + pid) * dnp + vn];
-            if (pid < kPolyPairs) c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + e] = c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + vn];
-            for (int f = 0; f < 4; ++f) c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + e] = c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + vn];
-        }
-    }
-    {
-        rw[kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(map_now, 1u, gen_new)); // (the live mask at [75] is N's)
-        rw[kDynRowPend] = 0.0;
-        rw[kDynRowSelf] = __longlong_as_double((long long)(want_c ? tq : 0u));
-        double2 *dst = reinterpret_cast<double2 *>(c.dyn_row + (size_t)e * kDynRow);
-#pragma unroll
-        for (int i = 0; i < kDynRow / 2; ++i) { double2 rv; rv.x = rw[2 * i]; rv.y = rw[2 * i + 1]; dst[i] = rv; }
-#pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS * SSG_MAX_GOALS; ++f) c.dyn_f64[(size_t)(DC_GOALS + f) * dnp + e] = rw[f];
-#pragma unroll
-        for (int f = 0; f < 9 * SSG_N_TRAFFIC; ++f) c.dyn_f64[(size_t)(DC_TRAFFIC + f) * dnp + e] = rw[kDynRowTraffic + f];
-#pragma unroll
-        for (int f = 0; f < 2 * SSG_N_TRAFFIC; ++f) c.dyn_f64[(size_t)(DC_TROT + f) * dnp + e] = rot[f];
-        for (int par = 0; par < 2; ++par) {
-            double *o = c.dyn_obs + (size_t)par * kDynObs * np + e;
-#pragma unroll
-            for (int g = 0; g < SSG_MAX_GOALS; ++g) {
-                o[(size_t)(kDynObsGoals + 2 * g) * np] = rw[DC_GOAL_COLS * g];
-                o[(size_t)(kDynObsGoals + 2 * g + 1) * np] = rw[DC_GOAL_COLS * g + 1];
-            }
-#pragma unroll
-            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-                o[(size_t)(kDynObsTraffic + 4 * k) * np] = rw[kDynRowTraffic + 9 * k];
-                o[(size_t)(kDynObsTraffic + 4 * k + 1) * np] = rw[kDynRowTraffic + 9 * k + 1];
-                o[(size_t)(kDynObsTraffic + 4 * k + 2) * np] = rot[2 * k];
-                o[(size_t)(kDynObsTraffic + 4 * k + 3) * np] = rot[2 * k + 1];
-            }
-        }
-    }
-    c.dyn_live[e] = live;
-#pragma unroll
-    for (int i = 0; i < kMaxCopy; ++i) {
-        if (i < n_arb) {
-            const int pid = apid[i];
-            c.dyn_u32[(size_t)(DU_META + pid) * dnp + e] = ameta[i];
-            if (pid < kPolyPairs) c.dyn_u32[(size_t)(DU_HASH + pid) * dnp + e] = ahash[i];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) c.dyn_f64[(size_t)(DC_ARB + 4 * pid + f) * dnp + e] = aacc[i][f];
-        }
-    }
-    c.dyn_flag[e] = (uint8_t)(flag_n & 12u);
-    c.dyn_hash[e] = hash_n;
-    c.dyn_age[e] = 1;
-    c.dyn_vmap[e] = map_now;
-    if (enqueue) {
-        c.dyn_req[e] = 0;
-        int32_t *region = c.dyn_region + (size_t)qq * kDynBuckets * dnp;
-        if (want_c) {
-            if (slot_c < (unsigned)c.dyn_np) region[(size_t)bc * dnp + slot_c] = (int32_t)((unsigned)e | ((unsigned)DQ_STEP << 28) | ((gen_new & 3u) << 30));
-            else atomicAdd(c.dyn_err + 1, 1u);
-        }
-        if (want_n) { // the world after this one
-            c.dyn_nmap[e] = nm;
-            c.dyn_ntag[e] = episode + 1;
-            c.dyn_row[(size_t)vn * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episode + 1) << 32)));
-            if (slot_n < (unsigned)c.dyn_np) region[(size_t)bn * dnp + slot_n] = (int32_t)((unsigned)vn | ((unsigned)DQ_NJOB << 28) | (((unsigned)c.dyn_gen[vn] & 3u) << 30));
-            else atomicAdd(c.dyn_err + 1, 1u);
-        }
-    } else {
-        c.dyn_req[e] = (uint8_t)DR_AHEAD; // the classify pass queues it for step k+1, not k
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // dyn_classify_kernel (c.dyn_tick = k: step k is the next one).  In steady state the queues maintain themselves (a stepped
 // space that changed queues itself, the step kernel wakes resting spaces whose goals the player is about to reach, the
 // adopt pass queues what it adopted) and this kernel does not run.  It runs when the host touched the envs in between —
@@ -809,13 +657,14 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
     unsigned gm_raw = c.mask[e];
     unsigned long long live0 = c.dyn_live[e];
     unsigned long long hash0 = c.dyn_hash[e];
-    unsigned long long nvalid = c.dyn_nvalid[e];
+    unsigned long long nvalid0 = c.dyn_nvalid[e], nvalid1 = c.dyn_nvalid[np + e];
+    int vmap0 = c.dyn_vmap[c.n_pad + e], vmap1 = c.dyn_vmap[2 * c.n_pad + e];
     int age = c.dyn_age[e];
     double st[kDynPs];
 #pragma unroll
     for (int f = 0; f < kDynPs; ++f) st[f] = c.f64cols[(size_t)(COL_X + f) * np + e];
     static_assert(COL_X == 0 && COL_W == 5 && kDynPs == 6, "x, y, vx, vy, angle, w are the first six state columns");
-    asm volatile("" : "+v"(map_id), "+v"(episode), "+v"(flag), "+v"(req), "+v"(gm_raw), "+v"(live0), "+v"(hash0), "+v"(nvalid), "+v"(age));
+    asm volatile("" : "+v"(map_id), "+v"(episode), "+v"(flag), "+v"(req), "+v"(gm_raw), "+v"(live0), "+v"(hash0), "+v"(nvalid0), "+v"(nvalid1), "+v"(vmap0), "+v"(vmap1), "+v"(age));
     const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
     // the player-state records: step k's dyn step reads parity k (nothing to predict), step k+1's reads parity k+1
     for (int par = 0; par < 2; ++par) {
@@ -824,37 +673,48 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         for (int f = 0; f < kDynPs; ++f) ps[f] = st[f];
         ps[kDynPs] = __longlong_as_double((long long)(gmask | (par == (int)(tick & 1u) ? kDynPsSkip : 0u)));
     }
-    const unsigned gen_e = c.dyn_gen[e];
-    auto set_vmap = [&](int m) { // the record of the current space, and its mirror in the row
+    auto set_vmap = [&](int m, int a) { // the record and age of the current space, and their mirror in the row
         c.dyn_vmap[e] = m;
-        c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, (unsigned)age, gen_e));
+        c.dyn_age[e] = (uint8_t)a;
+        c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, (unsigned)a, 0u));
     };
-    if (req & DR_FRESH) { // an auto-reset env without a usable N: rebuilt from its record by the dyn step of step k
-        set_vmap(map_id);
-        c.dyn_req[e] = 0;
-        dyn_enqueue(c, tick, e, DQ_FRESH, dyn_bucket_of(0, map_id));
-    } else if (req & DR_AHEAD) { // adopted just now: already holds step k's state
-        c.dyn_req[e] = 0;
-        if (!(flag & 4u)) dyn_enqueue(c, tick + 1u, e, DQ_STEP, dyn_bucket_of(age, map_id));
+    // is N slot s usable as episode q on record m?
+    auto n_usable = [&](int q, int m) -> bool {
+        const unsigned long long want = ((unsigned long long)d.bank_epoch << 32) | (unsigned)q;
+        return (q & 1) ? (nvalid1 == want && vmap1 == m) : (nvalid0 == want && vmap0 == m);
+    };
+    c.dyn_row[(size_t)e * kDynRow + kDynRowSelf] = 0.0; // (no DQ_WAKE entry survives the rebuild)
+    if (req & (DR_RESET | DR_ADOPTING)) {
+        // the env was auto-reset one (DR_RESET) or two (DR_ADOPTING) steps ago and its current space still holds the old episode:
+        // the ADOPT entry the step kernel queued is gone with the old queues.  From a usable N slot it is queued again — for
+        // the step it is due in —; without one (a new bank) the space is rebuilt from the record in step k's dyn step, and
+        // the step kernel reads it like any other (an env two steps past its reset cannot be helped: never seen, counted).
+        const bool ok = n_usable(episode, map_id);
+        if (ok) {
+            dyn_enqueue(c, (req & DR_RESET) ? tick + 1u : tick, e, (episode & 1) ? DQ_ADOPT1 : DQ_ADOPT0, dyn_bucket_of(1, map_id));
+        } else {
+            if (req & DR_ADOPTING) atomicAdd(c.dyn_err + 0, 1u);
+            set_vmap(map_id, 0);
+            c.dyn_req[e] = 0;
+            dyn_enqueue(c, tick, e, DQ_FRESH, dyn_bucket_of(0, map_id));
+        }
     } else {
         // rest bit still valid?  It was established for this bank generation; callers that write the body columns
         // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).  A cached arbiter that left with its goal
         // was part of the fixed point: the bodies it touched are stepped again.
         const bool rest = ((flag & 4u) != 0u) && (hash0 == (unsigned long long)d.bank_epoch) &&
                           (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
-        set_vmap(map_id);
+        set_vmap(map_id, age);
         if (rest) c.dyn_flag[e] = (uint8_t)(flag & 12u);
         else dyn_enqueue(c, tick, e, DQ_STEP, dyn_bucket_of(age, map_id));
     }
     // the next episode's space
     if (c.flags & SSG_FLAG_AUTO_RESET) {
         const int nm = next_map_of(c, map_id);
-        const bool have = nvalid == (((unsigned long long)d.bank_epoch << 32) | (unsigned)(episode + 1)) && c.dyn_vmap[c.n_pad + e] == nm;
-        if (!have) {
-            c.dyn_nmap[e] = nm;
-            c.dyn_ntag[e] = episode + 1;
-            c.dyn_row[(size_t)(c.n_pad + e) * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episode + 1) << 32)));
-            dyn_enqueue(c, tick, c.n_pad + e, DQ_NJOB, dyn_bucket_of(0, nm));
+        if (!n_usable(episode + 1, nm)) {
+            const int vn = (1 + ((episode + 1) & 1)) * c.n_pad + e;
+            c.dyn_row[(size_t)vn * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episode + 1) << 32)));
+            dyn_enqueue(c, tick, vn, DQ_NJOB, dyn_bucket_of(0, nm));
         }
     }
 }
@@ -869,9 +729,9 @@ __host__ __device__ constexpr int dyn_lane_doubles(int n_goals, bool uni)
 }
 
 template <bool UNI>
-__global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
+__global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
-    constexpr int kWpg = UNI ? 2 : 1; // waves per workgroup (see lds_all)
+    constexpr int kWpg = UNI ? kUniWpg : 1; // waves per workgroup (see lds_all)
     static_assert(dyn_lane_doubles(SSG_MAX_GOALS, true) * kGrp + kHullDoubles * (1 + SSG_N_TRAFFIC) + 2 * kBankDoubles == kWaveLds, "kWaveLds");
     const int lane = threadIdx.x & 63;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime(); // (development aid, see stamp())
@@ -905,11 +765,15 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
         const unsigned vsh = __shfl_up(incl, o);
         incl += (lane >= o) ? vsh : 0u;
     }
-    // A resident set of workgroups walks the queue (the grid is what the chip holds at once, not the worst-case queue: thousands
-    // of workgroups that only find out that they are past the queue's end kept the dispatcher — and, on a high-priority stream,
-    // the step kernel running beside this one — waiting).  In steady state every workgroup finds at most one wave of work.
+    // One workgroup per wave of the queue (the grid covers the worst case — every space queued —; the workgroups past the
+    // queue's end leave here).  (kPersistent, measured and not kept: a resident set of 2 x CUs workgroups walking the queue with
+    // the grid's stride — the loop-carried counters cost the kernel 47 spilled VGPRs, 74 -> 80 us, and the step kernel beside
+    // it gained nothing.)
+    constexpr bool kPersistent = false;
     const unsigned q_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    for (unsigned wslot = blockIdx.x * (unsigned)kWpg + (threadIdx.x >> 6); wslot * (unsigned)kGrp < q_total; wslot += gridDim.x * (unsigned)kWpg) {
+    unsigned wslot = blockIdx.x * (unsigned)kWpg + (threadIdx.x >> 6);
+    do {
+    if (!(wslot * (unsigned)kGrp < q_total)) break;
     const unsigned s0 = wslot * (unsigned)kGrp;
     const unsigned long long mine = __ballot((incl - r_map <= s0) & (s0 < incl));
     if (mine == 0ull) break; // (cannot happen below q_total)
@@ -930,11 +794,15 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
             before += cj;
         }
     }
-    const unsigned etype = (entry >> 28) & 3u;
+    const unsigned etype = (entry >> 27) & 7u;
     const unsigned long long t_ent = __builtin_amdgcn_s_memtime(); // (development aid)
     queued = queued && (int)(entry & kDynVMask) < c.dyn_np;
-    const int v = queued ? (int)(entry & kDynVMask) : 0;          // the space this lane steps
-    const int e = v >= c.n_pad ? v - c.n_pad : v;                 // its env
+    const int v = queued ? (int)(entry & kDynVMask) : 0;          // the space this lane steps (writes)
+    const int e = v % c.n_pad;                                    // its env
+    // an ADOPT entry steps FROM the env's N slot INTO its current space (the env was auto-reset: shipsim_kernels.hip, role 3)
+    const bool adopt_e = (etype == DQ_ADOPT0) | (etype == DQ_ADOPT1);
+    const int nslot = adopt_e ? (int)(etype - DQ_ADOPT0) : (v >= c.n_pad ? v / c.n_pad - 1 : 0);
+    const int vin = adopt_e ? (1 + nslot) * c.n_pad + e : v;      // the space this lane reads
     const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
     const int cbase = kGrp * lane_doubles;
     const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
@@ -945,9 +813,11 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
     // space's row (body fields, live-arbiter mask, record / age / generation, an N job's order) and the env's player-state
     // record.  (Requested where they were used — and from a table each — these were five more dependent round trips of
     // 48 scattered lines at the head of every wave's chain: 12 k cycles.)
+    unsigned gen_now = c.dyn_gen[v];
+    unsigned long long nvalid_in = c.dyn_nvalid[(size_t)nslot * enp + e];
     double rw[kDynRow], ps[kDynPsRow];
     {
-        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)v * kDynRow);
+        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)vin * kDynRow);
 #pragma unroll
         for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
         const double2 *ps2 = reinterpret_cast<const double2 *>(c.dyn_ps + ((size_t)qi * enp + e) * kDynPsRow);
@@ -970,14 +840,17 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
     const unsigned long long meta_in = (unsigned long long)__double_as_longlong(rw[kDynRowMeta]);
     const unsigned long long order_in = (unsigned long long)__double_as_longlong(rw[kDynRowOrder]);
     const unsigned pgm_in = (unsigned)__double_as_longlong(ps[kDynPs]);
+    asm volatile("" : "+v"(gen_now), "+v"(nvalid_in));
     const int vmap_in = (int)(unsigned)meta_in, age_in0 = (int)((meta_in >> 32) & 255ull);
-    const unsigned gen_now = (unsigned)((meta_in >> 40) & 255ull);
     const int nmap_in = (int)(unsigned)order_in, ntag_in = (int)(unsigned)(order_in >> 32);
     // (an entry of a space the env has left is stale; a space the step kernel woke that had queued itself has its own entry)
     queued = queued && (gen_now & 3u) == (entry >> 30) &&
              !(etype == DQ_WAKE && (unsigned)__double_as_longlong(rw[kDynRowSelf]) == tick);
-    const bool is_n = queued & (etype == DQ_NJOB);      // the next episode's space: nothing of the player is read
+    const bool is_n = queued & (etype == DQ_NJOB);      // a coming episode's space: nothing of the player is read
     const bool fresh = queued & ((etype == DQ_FRESH) | (etype == DQ_NJOB)); // rebuilt from the record: nothing of the space's old state is read
+    const bool adopting = queued & adopt_e;             // reads the N slot, writes every field of the current space
+    if (adopting && !(nvalid_in == (((unsigned long long)d.bank_epoch << 32) | (unsigned)ntag_in) && nmap_in == vmap_in))
+        atomicAdd(c.dyn_err + 0, 1u); // (the slot's N job has not run on this bank: cannot happen — the job is ordered an episode ahead)
     const int map_id = UNI ? wm : (is_n ? nmap_in : vmap_in);
     // The slot of the NEXT step's queue this space takes if this step changes anything: reserved now — at the end it would be one
     // more dependent round trip on every wave's chain — one atomic per distinct bucket of the wave (its lanes sit on one
@@ -1240,14 +1113,14 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
         unsigned old_hash[2] = {0u, 0u};
         double old_jn[2] = {0.0, 0.0}, old_jt[2] = {0.0, 0.0};
         if ((live >> pid) & 1ull) {
-            const unsigned meta = col.u32[(size_t)(DU_META + pid) * np + v];
+            const unsigned meta = col.u32[(size_t)(DU_META + pid) * np + vin];
             state = meta & 7u;
             old_count = (meta >> 5) & 3u;
             if (pid < kPolyPairs) {
-                const unsigned hh = col.u32[(size_t)(DU_HASH + pid) * np + v];
+                const unsigned hh = col.u32[(size_t)(DU_HASH + pid) * np + vin];
                 old_hash[0] = hh & 0xFFFFu; old_hash[1] = hh >> 16;
             }
-            const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + v;
+            const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + vin;
             old_jn[0] = acc[0 * np]; old_jn[1] = acc[1 * np]; old_jt[0] = acc[2 * np]; old_jt[1] = acc[3 * np];
             ain ^= arb_hash(pid, meta & ~0x18u, (pid < kPolyPairs) ? (old_hash[0] | old_hash[1] << 16) : 0u, old_jn[0], old_jn[1],
                             old_jt[0], old_jt[1]); // (age bits are 0 for an arbiter touched every step; a cached one changes anyway)
@@ -1409,7 +1282,7 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
         while (rest) {
             const int pid = __ffsll((long long)rest) - 1;
             rest &= rest - 1ull;
-            unsigned meta = col.u32[(size_t)(DU_META + pid) * np + v];
+            unsigned meta = col.u32[(size_t)(DU_META + pid) * np + vin];
             unsigned age = (meta >> 3) & 3u;
             age += 1u; // ticks >= 1: the arbiter is (now) "cached"
             changed = true; // an ageing arbiter is a state change by itself
@@ -1418,6 +1291,10 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
             } else {
                 meta = (meta & ~0x1Fu) | (unsigned)ST_CACHED | (age << 3);
                 col.u32[(size_t)(DU_META + pid) * np + v] = meta;
+                if (adopting) { // the record moves from the N slot to the current space with the rest
+                    if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + v] = col.u32[(size_t)(DU_HASH + pid) * np + vin];
+                    for (int f = 0; f < 4; ++f) col.f64[(size_t)(DC_ARB + 4 * pid + f) * np + v] = col.f64[(size_t)(DC_ARB + 4 * pid + f) * np + vin];
+                }
             }
         }
     }
@@ -1648,7 +1525,9 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
     // what the step kernel reads of this env's other bodies, in this step's parity (an N space has no reader yet: the adopt
     // pass publishes it); a rebuilt space publishes both parities (it may come to rest at once, and nobody rewrites a resting
     // space's table)
-    double *const obs_p = c.dyn_obs + (size_t)qi * kDynObs * enp + e, *const obs_q = c.dyn_obs + (size_t)(qi ^ 1u) * kDynObs * enp + e;
+    // (an N job publishes to its slot's plane: what the step kernel reads in the step after the env's auto-reset)
+    double *const obs_p = c.dyn_obs + (size_t)(is_n ? 2u + (unsigned)nslot : qi) * kDynObs * enp + e, *const obs_q = c.dyn_obs + (size_t)(qi ^ 1u) * kDynObs * enp + e;
+    const bool both = (fresh | adopting) & !is_n; // nobody rewrites a resting space's planes: a rebuilt / adopted one fills both
 #pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + v;
@@ -1663,16 +1542,16 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
         bool dfb = false;
 #pragma unroll
         for (int f = 0; f < 9; ++f) dfb |= differs(val[f], tin[k][f]);
-        if (dfb | fresh) {
+        if (dfb | fresh | adopting) {
 #pragma unroll
             for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = val[f]; row[f] = val[f]; }
             col.f64[(size_t)(DC_TROT + 2 * k) * np + v] = rca; // the rotation of the angle column, for collide_ship in the step kernel
             col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + v] = rsa;
         }
-        if (!is_n) {
+        {
             obs_p[(size_t)(kDynObsTraffic + 4 * k) * enp] = val[0]; obs_p[(size_t)(kDynObsTraffic + 4 * k + 1) * enp] = val[1];
             obs_p[(size_t)(kDynObsTraffic + 4 * k + 2) * enp] = rca; obs_p[(size_t)(kDynObsTraffic + 4 * k + 3) * enp] = rsa;
-            if (fresh) {
+            if (both) {
                 obs_q[(size_t)(kDynObsTraffic + 4 * k) * enp] = val[0]; obs_q[(size_t)(kDynObsTraffic + 4 * k + 1) * enp] = val[1];
                 obs_q[(size_t)(kDynObsTraffic + 4 * k + 2) * enp] = rca; obs_q[(size_t)(kDynObsTraffic + 4 * k + 3) * enp] = rsa;
             }
@@ -1689,13 +1568,13 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
         bool dfb = false;
 #pragma unroll
         for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= differs(val[f], gin[g][f]);
-        if (dfb | fresh) {
+        if (dfb | fresh | adopting) {
 #pragma unroll
             for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = val[f]; row[f] = val[f]; }
         }
-        if (!is_n) {
+        {
             obs_p[(size_t)(kDynObsGoals + 2 * g) * enp] = val[0]; obs_p[(size_t)(kDynObsGoals + 2 * g + 1) * enp] = val[1];
-            if (fresh) { obs_q[(size_t)(kDynObsGoals + 2 * g) * enp] = val[0]; obs_q[(size_t)(kDynObsGoals + 2 * g + 1) * enp] = val[1]; }
+            if (both) { obs_q[(size_t)(kDynObsGoals + 2 * g) * enp] = val[0]; obs_q[(size_t)(kDynObsGoals + 2 * g + 1) * enp] = val[1]; }
         }
         changed |= dfb;
     }
@@ -1714,39 +1593,36 @@ __global__ __launch_bounds__(UNI ? 128 : 64) void dyn_step_kernel(const DevCfg c
     // kind of resting space the player can disturb, by removing such a goal (the step kernel wakes it, shipsim_kernels.hip)
     col.flag[v] = (uint8_t)(changed ? 0u : (4u | ((live >> 9) ? 8u : 0u)));
     c.dyn_age[v] = (uint8_t)age_next;
-    {   // the row's mirrors of the live mask and of record / age / generation
+    {   // the row's mirrors of the live mask and of record / age; the step this space has queued itself for
         double2 m;
-        m.x = __longlong_as_double((long long)dyn_meta_pack(map_id, (unsigned)age_next, gen_now));
+        m.x = __longlong_as_double((long long)dyn_meta_pack(map_id, (unsigned)age_next, 0u));
         m.y = rw[kDynRowOrder];
         c.dyn_row[(size_t)v * kDynRow + kDynRowLive] = __longlong_as_double((long long)live);
         *reinterpret_cast<double2 *>(c.dyn_row + (size_t)v * kDynRow + kDynRowMeta) = m;
-        if (!is_n) {
-            double2 pz;
-            pz.x = __longlong_as_double((long long)dyn_pend_pack(tick + 1u, bnext, slot_next));
-            pz.y = __longlong_as_double((long long)(changed ? tick + 1u : 0u)); // kDynRowSelf
-            *reinterpret_cast<double2 *>(c.dyn_row + (size_t)v * kDynRow + kDynRowPend) = pz;
-        }
+        if (!is_n) c.dyn_row[(size_t)v * kDynRow + kDynRowSelf] = __longlong_as_double((long long)(changed ? tick + 1u : 0u));
     }
+    if (fresh | adopting) c.dyn_vmap[v] = map_id;
     if (is_n) {
-        // the next episode's space has had its first step: it waits for the env to get there (dyn_adopt_kernel)
-        c.dyn_vmap[v] = map_id;
-        c.dyn_nvalid[e] = ((unsigned long long)d.bank_epoch << 32) | (unsigned)ntag_in;
+        // the coming episode's space has had its first step: it waits for the env to get there
+        c.dyn_nvalid[(size_t)nslot * enp + e] = ((unsigned long long)d.bank_epoch << 32) | (unsigned)ntag_in;
     } else {
         // the slot reserved at the head: stepped again next step if anything changed, a null entry otherwise
-        const unsigned ent = changed ? ((unsigned)v | ((unsigned)DQ_STEP << 28) | ((gen_now & 3u) << 30)) : 0xFFFFFFFFu;
+        const unsigned ent = changed ? dyn_entry((unsigned)v, DQ_STEP, gen_now) : kDynNullEntry;
         if (slot_next < (unsigned)c.dyn_np) c.dyn_region[((size_t)(qi ^ 1u) * kDynBuckets + bnext) * (size_t)c.dyn_np + slot_next] = (int32_t)ent;
         else atomicAdd(c.dyn_err + 1, 1u);
     }
     } // queued
-    __builtin_amdgcn_s_waitcnt(0xC07F); // (the next wave of work reuses the LDS columns)
-    __builtin_amdgcn_wave_barrier();
-    } // wslot
+    if (kPersistent) {
+        __builtin_amdgcn_s_waitcnt(0xC07F); // (the next wave of work reuses the LDS columns)
+        __builtin_amdgcn_wave_barrier();
+    }
+    } while (kPersistent && ((wslot += gridDim.x * (unsigned)kWpg), true));
     leave();
 }
 
 size_t dyn_lds_bytes(int n_goals, bool uni)
 {
-    if (uni) return 2 * (size_t)kWaveLds * sizeof(double); // two waves per workgroup, each with the region of a six-goal space
+    if (uni) return (size_t)kUniWpg * kWaveLds * sizeof(double); // kUniWpg waves per workgroup, each with the region of a six-goal space
     return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
 }
 
@@ -1774,18 +1650,13 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
     // the resident set: two workgroups (76 KB of LDS each, one wave alone on its SIMD) per CU; each walks the queue with the grid's stride
     static const unsigned n_cu = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(cu > 0 ? cu : 256); }();
     const unsigned worst = (unsigned)((c.dyn_np + kDynSortedPad + kGrp - 1) / kGrp);
-    if (uni) { // one two-wave workgroup per CU
-        const unsigned wg = (worst + 1u) / 2u;
-        hipLaunchKernelGGL(dyn_step_kernel<true>, dim3(wg < n_cu ? wg : n_cu), dim3(128), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
+    if (uni) { // two waves per CU
+        const unsigned wg = (worst + (unsigned)kUniWpg - 1u) / (unsigned)kUniWpg;
+        hipLaunchKernelGGL(dyn_step_kernel<true>, dim3(wg), dim3(64 * kUniWpg), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
     } else {
-        hipLaunchKernelGGL(dyn_step_kernel<false>, dim3(worst < n_cu ? worst : n_cu), dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+        hipLaunchKernelGGL(dyn_step_kernel<false>, dim3(worst), dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_dyn_adopt(const DevCfg &c, const DynCfg &d, bool enqueue, hipStream_t stream)
-{
-    hipLaunchKernelGGL(dyn_adopt_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256), 0, stream, c, d, enqueue ? 1 : 0);
+    (void)n_cu;
     return hipGetLastError();
 }
 

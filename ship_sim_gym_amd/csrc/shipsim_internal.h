@@ -40,9 +40,10 @@ enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* c
 // and both are decided by the player's pose after cpBodyUpdatePosition — which step k-1's velocities fix exactly.  So the
 // full dyn step of API step k+1 needs nothing from the step kernel of step k: it runs BESIDE it, on a second stream.
 //
-// "vspace" = one Chipmunk space of non-player bodies: env e's current one (C, index e) and the one of its NEXT episode,
-// already built and stepped once (N, index n_pad + e): an auto-reset adopts N instead of putting a fresh world's first —
-// and hardest — cpSpaceStep on the critical path.  Every dyn column has 2 * n_pad elements.
+// "vspace" = one Chipmunk space of non-player bodies: env e's current one (C, index e) and two slots for the ones of its coming
+// episodes, built ahead and stepped once (N slot s, index (1 + s) * n_pad + e; episode q uses slot q & 1): an auto-reset continues
+// from N instead of putting a fresh world's first — and hardest — cpSpaceStep on the critical path.  Every dyn column has
+// 3 * n_pad elements.
 //
 // The queue of the full dyn step is BUCKETED by (bank record, steps since the reset): after a reset the traffic ships and goal
 // bodies of an env replay a transient that depends on its world and age only (the player pushes nothing), so envs of one
@@ -58,20 +59,25 @@ constexpr int kDynSortedPad = kDynMapBuckets * kDynGrp; // wave slots beyond the
 constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after word 0 (the consumers' exit ticket)
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride; // per queue
-// queue entry: vspace | type << 28 | (generation & 3) << 30
+// queue entry: vspace | type << 27 | (generation & 3) << 30
 enum { DQ_STEP = 0 /* cpSpaceStep of a current space */, DQ_FRESH = 1 /* rebuild the current space from its record, then step */,
-       DQ_NJOB = 2 /* build the next episode's space (N) from its record and step it once */,
-       DQ_WAKE = 3 /* cpSpaceStep of a current space the step kernel woke: void if the space queued itself for the same step */ };
-constexpr unsigned kDynVMask = (1u << 28) - 1u;
+       DQ_NJOB = 2 /* build a next-episode space (the entry's vspace: N slot 0 or 1) from its record and step it once */,
+       DQ_WAKE = 3 /* cpSpaceStep of a current space the step kernel woke: void if the space queued itself for the same step */,
+       DQ_ADOPT0 = 4, DQ_ADOPT1 = 5 /* the env was auto-reset: cpSpaceStep FROM its N slot 0 / 1 INTO its current space */ };
+constexpr unsigned kDynVMask = (1u << 27) - 1u;
+__host__ __device__ __forceinline__ unsigned dyn_entry(unsigned v, unsigned type, unsigned gen) { return v | (type << 27) | ((gen & 3u) << 30); }
+constexpr unsigned kDynNullEntry = 0xFFFFFFFFu; // (vspace out of range: ignored)
 // what the step kernel reads of the other bodies, per env and step parity: goal g centre at 2g, 2g+1; traffic ship k
 // (x, y, cos a, sin a) at 12 + 4k ..
 constexpr int kDynObsGoals = 0, kDynObsTraffic = 2 * SSG_MAX_GOALS, kDynObs = 2 * SSG_MAX_GOALS + 4 * SSG_N_TRAFFIC;
+constexpr int kDynObsPlanes = 4;  // planes 0, 1: the current space by step parity; 2, 3: N slot 0 / 1 after its one step (what an env sees in the
+                                  // step after its auto-reset, before its current space has taken the N slot over)
 constexpr int kDynPs = 6;         // the player state the dyn step predicts the goal removals from: x, y, vx, vy, angle, w
 constexpr int kDynPsRow = 8;      // ... one 64-byte record per env and step parity: the six, [6] the goal mask (bits 0-5; kDynPsSkip), [7] spare
 constexpr unsigned kDynPsSkip = 0x40u; // bit of the ps goal mask: this record predicts nothing (the mask is already current)
 // bits of dyn_req (step kernel -> adopt pass)
-enum { DR_RESET = 2 /* auto-reset this step: adopt N */, DR_FRESH = 4 /* ... but N was not usable: rebuild from the record */,
-       DR_AHEAD = 8 /* adopted just now: the space already holds the coming step's state */ };
+enum { DR_RESET = 2 /* auto-reset in the last step: the coming step reads the N slot's table; an ADOPT entry waits in the queue of the step after */,
+       DR_ADOPTING = 4 /* auto-reset two steps ago: the ADOPT entry is due in the coming step's dyn step */ };
 // sort bucket of a space that is `age` steps into its episode on bank record `map_id`
 __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 {
@@ -83,24 +89,16 @@ __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 // lines per env: [0, 48) goal g field f at 8g + f, [48, 75) traffic ship k field f at 48 + 9k + f.  Written by everything that
 // writes the columns (dyn_init, the full step's write-back, ssg_dyn_invalidate after a caller's own writes); read by the full
 // step only.  The columns stay the interface of everything else (classify pass, step kernel, ssg_state_field).
-constexpr unsigned kDynVMaskU = (1u << 28) - 1u;
 constexpr int kDynRow = 80, kDynRowTraffic = 48;
 // ... and what else the full step needs of the space, so that ONE batch of loads on five lines of the lane brings it all
 // (every separately indexed table was another set of 48 scattered lines — and TLB entries — per wave): [75] the live-arbiter mask,
-// [76] bank record | age << 32 | generation << 40, [77] (N spaces) the N job's order: bank record | episode index << 32.
-// Mirrors of DevCfg::dyn_live / dyn_vmap / dyn_age / dyn_gen / dyn_nmap / dyn_ntag, kept by whoever writes those.
+// [76] bank record | age << 32, [77] (N spaces) the N job's order: bank record | episode index << 32.
+// [75], [76] mirror DevCfg::dyn_live / dyn_vmap / dyn_age, kept by whoever writes those (the generation is read from DevCfg::dyn_gen:
+// the step kernel bumps it while a dyn step may be rewriting the row).
 constexpr int kDynRowLive = 75, kDynRowMeta = 76, kDynRowOrder = 77;
-// [78] where the space's pending queue entry sits — the slot its last dyn step reserved in the next step's queue: slot | bucket << 28 |
-// (tick of that queue & 0xFFFFFF) << 40 — so that the adopt pass can void the entry of a space the env has left (a stale entry
-// must not take the claim on the space from the adopted one's entry).
-constexpr int kDynRowPend = 78;
-// [79] the step the space has queued ITSELF for (its last dyn step changed something; or the adopt pass queued it), 0 = none: a DQ_WAKE
-// entry for that step is a duplicate.
+// [79] the step the space has queued ITSELF for (its last dyn step changed something), 0 = none: a DQ_WAKE entry for that step is a
+// duplicate.
 constexpr int kDynRowSelf = 79;
-__host__ __device__ __forceinline__ unsigned long long dyn_pend_pack(unsigned tick, unsigned bucket, unsigned slot)
-{
-    return (unsigned long long)(slot & kDynVMaskU) | ((unsigned long long)bucket << 28) | ((unsigned long long)(tick & 0xFFFFFFu) << 40);
-}
 __host__ __device__ __forceinline__ unsigned long long dyn_meta_pack(int vmap, unsigned age, unsigned gen)
 {
     return (unsigned long long)(unsigned)vmap | ((unsigned long long)(age & 255u) << 32) | ((unsigned long long)(gen & 255u) << 40);
@@ -132,7 +130,7 @@ struct DevCfg {
     const double *bank;
     unsigned long long *dbg; // diagnostic builds only (-DSSG_STAMPS): per-wave s_memtime stamps
     // config 4 (n_ships == 4): columns of the non-player bodies (shipsim_dynamics.hip); null otherwise.  Every dyn column has
-    // dyn_np = 2 * n_pad elements: vspace v = e (env e's current space) or n_pad + e (its next episode's, stepped once).
+    // dyn_np = 3 * n_pad elements: vspace v = e (env e's current space) or (1 + s) * n_pad + e (N slot s).
     int n_ships;
     int dyn_np;
     unsigned dyn_tick;            // the API step this launch belongs to (k >= 1): its parity selects obs / ps / queue buffers
@@ -144,14 +142,13 @@ struct DevCfg {
     uint8_t *dyn_gen;             // [dyn_np] generation of the space: queue entries of an older one are stale (the env was reset meanwhile)
     uint8_t *dyn_age;             // [dyn_np] cpSpaceSteps this space has had (saturating): its sort bucket
     int32_t *dyn_vmap;            // [dyn_np] bank record the space was built from
-    uint8_t *dyn_req;             // [n_pad] DR_* bits: step kernel -> adopt pass -> classify pass
-    unsigned long long *dyn_nvalid; // [n_pad] bank generation << 32 | episode index the N space was built for
-    int32_t *dyn_nmap, *dyn_ntag; // [n_pad] the N job's order: bank record and episode index
-    double *dyn_obs;              // [2][kDynObs][n_pad] by step parity: what the step kernel reads of the other bodies
+    uint8_t *dyn_req;             // [n_pad] DR_* bits, written by the step kernel (and cleared by a host-side reset)
+    unsigned long long *dyn_nvalid; // [2][n_pad] per N slot: bank generation << 32 | episode index the slot was built for
+    double *dyn_obs;              // [kDynObsPlanes][kDynObs][n_pad] what the step kernel reads of the other bodies
     double *dyn_ps;               // [2][n_pad][kDynPsRow] by step parity: the player state after the step (post-reset) and its goal mask, step kernel -> dyn step
     int32_t *dyn_region;          // [2][kDynBuckets][dyn_np] queue entries, bucket b of queue q at [(q * kDynBuckets + b) * dyn_np ..)
     unsigned *dyn_count;          // [2][kDynCountWords] per queue: [0] exit ticket of the consuming kernel; [kDynBucket0 + b * kDynBucketStride] bucket counters
-    unsigned *dyn_err;            // [4] should-never-happen counters: [0] adoption without a usable N inside a pipelined rollout, [1] queue overflow
+    unsigned *dyn_err;            // [4] should-never-happen counters: [0] an ADOPT entry whose N slot was not usable, [1] queue overflow
     double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS]; // traffic hulls (local), for collide_ship
     double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2: the step kernel's reject in front of collide_ship's exact test
     double dyn_hull_r;                // the player's hull radius about its body position
@@ -178,9 +175,6 @@ hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map
 // Config 4, all with c.dyn_tick = k, the API step being prepared (shipsim_dynamics.hip):
 // the cpSpaceStep of step k for the spaces queued for it (queue k & 1)
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream);
-// envs the step kernel auto-reset in step k-1 take over their N space (= their new world after ITS step k); enqueue: queue them
-// for step k+1 and order the next N (false when the classify pass follows, which does both)
-hipError_t launch_dyn_adopt(const DevCfg &c, const DynCfg &d, bool enqueue, hipStream_t stream);
 // rebuild the queues of steps k and k+1 and the player-state records from the columns (after the host touched the envs: ssg_reset,
 // a new bank, ssg_dyn_invalidate, a fresh handle); the caller has zeroed both queues' counters on the stream
 hipError_t launch_dyn_classify(const DevCfg &c, const DynCfg &d, hipStream_t stream);
@@ -223,7 +217,7 @@ __device__ __forceinline__ void dyn_enqueue(const DevCfg &c, unsigned tick, int 
     const unsigned slot = atomicAdd(c.dyn_count + (size_t)q * kDynCountWords + kDynBucket0 + bucket * kDynBucketStride, 1u);
     if (slot >= (unsigned)c.dyn_np) { atomicAdd(c.dyn_err + 1, 1u); return; }
     c.dyn_region[((size_t)q * kDynBuckets + bucket) * (size_t)c.dyn_np + slot] =
-            (int32_t)((unsigned)v | (type << 28) | (((unsigned)c.dyn_gen[v] & 3u) << 30));
+            (int32_t)dyn_entry((unsigned)v, type, (unsigned)c.dyn_gen[v]);
 }
 
 // sin / cos of a body angle (cpvforangle).  The library's sincos is ~190 instructions of full-range machinery; body

@@ -140,11 +140,17 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
 // Goal g's centre (comp 0 = x, 1 = y).  Configs 1-3: the goal bodies never move, so the map record holds them
 // (goff = the record's goal block).  Config 4 (DYN): goals are dynamic bodies; the dyn step of this API step has left their
 // positions in this step parity's table (goff = env index; DevCfg::dyn_obs, shipsim_dynamics.hip) — the body columns
-// themselves may already be a step ahead.
+// themselves may already be a step ahead.  In the step after an env's auto-reset the table is the one its N slot published
+// (DR_RESET, shipsim_internal.h).
+__device__ __forceinline__ int dyn_goff(const DevCfg &c, int e, unsigned req, int episodes)
+{
+    const unsigned plane = (req & DR_RESET) ? 2u + ((unsigned)episodes & 1u) : (c.dyn_tick & 1u);
+    return (int)(plane * (unsigned)(kDynObs * c.n_pad)) + e;
+}
 template <bool LDS_BANK, bool DYN>
 __device__ __forceinline__ double goal_at(const DevCfg &c, int goff, int g, int comp)
 {
-    if constexpr (DYN) return c.dyn_obs[((size_t)(c.dyn_tick & 1u) * kDynObs + (size_t)(kDynObsGoals + 2 * g + comp)) * (size_t)c.n_pad + goff];
+    if constexpr (DYN) return c.dyn_obs[(size_t)(kDynObsGoals + 2 * g + comp) * (size_t)c.n_pad + (size_t)goff]; // (goff: plane * kDynObs * n_pad + env, dyn_goff())
     else return bank_at<LDS_BANK>(c, goff + 2 * g + comp);
 }
 
@@ -995,11 +1001,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
         constexpr int F = 6 + NB;
         double pv[F];
+        int obs_goff = 0; // config 4: where this step's goal centres are (dyn_goff)
         {
             const int el = el_;
             const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
             const int rud0 = colRud[el], map0 = colMap[el];
             const unsigned gm0 = c.mask[el];
+            if constexpr (DYN) obs_goff = dyn_goff(c, el, c.dyn_req[el], c.i32cols[(size_t)ICOL_EPISODE * np + el]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) pv[6 + i] = colLid[(size_t)i * np + el];
             pv[0] = x0; pv[1] = y0; pv[2] = (double)rud0; pv[3] = a0;
@@ -1091,7 +1099,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(4);
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
             double nf_gx = 0, nf_gy = 0;
-            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
+            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? obs_goff : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
             SSG_STAMP_K(5);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
@@ -1173,6 +1181,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // =========================================================================================================
     double x, y, vx, vy, ang, w, cum;
     unsigned gm;
+    unsigned req0 = 0; // config 4: DR_* bits the previous step left for this env
     int map_id, rudder, steps, episodes;
     {
         const int el = el_;
@@ -1182,6 +1191,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         rudder = colRud[el];
         steps = colStep[el];
         episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
+        if constexpr (DYN) req0 = c.dyn_req[el];
     }
     if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // (gathered bank: this env's goal centres -> LDS, before barrier 0)
     int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
@@ -1213,7 +1223,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     asm volatile("" : "+v"(el));
     const int act = act_next;
     const int rec_off = map_id * SSG_MAP_STRIDE;
-    const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
+    const int goff = DYN ? dyn_goff(c, el_, req0, episodes) : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
 
     // ---- handle_discrete_action (game.py:140-153) on the pre-step pose --------------------------------------------
     double fx = 0.0, fy = 0.0, tq = 0.0;
@@ -1284,7 +1294,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     unsigned dflag = 0;
     if constexpr (DYN) {
         dflag = c.dyn_flag[el_];
-        const double *tob = c.dyn_obs + ((size_t)(c.dyn_tick & 1u) * kDynObs + kDynObsTraffic) * np + el_;
+        const double *tob = c.dyn_obs + (size_t)kDynObsTraffic * np + (size_t)goff; // (this env's plane of the table, traffic block)
         unsigned short *tq = reinterpret_cast<unsigned short *>(goal_scratch0 + (tl >> 6) * kGoalScratchBytes);
         unsigned *tw = reinterpret_cast<unsigned *>(tq + 64 * SSG_MAX_GOALS);
         static_assert(SSG_N_TRAFFIC <= SSG_MAX_GOALS, "the traffic pairs of a tile fit the goal pair queue");
@@ -1317,7 +1327,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const unsigned code = tq[valid ? p : 0];
             const int src = code & 63, kk = code >> 6;
             const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
-            const double *tsrc = tob - el_ + (blockIdx.x * EPW + (tl & ~63) + src); // env `src` of this tile (a live one: it queued the pair)
+            const double *tsrc = c.dyn_obs + (size_t)kDynObsTraffic * np + (size_t)__shfl(goff, src); // env `src` of this tile (a live one: it queued the pair), in ITS plane
             const double tx = tsrc[(size_t)(4 * kk) * np], ty = tsrc[(size_t)(4 * kk + 1) * np];
             const double tca = tsrc[(size_t)(4 * kk + 2) * np], tsa = tsrc[(size_t)(4 * kk + 3) * np];
             const double *tt = traffictab + kk * 32;
@@ -1465,16 +1475,41 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // the new world's goal centres (only these lanes gather)
     }
     if constexpr (DYN) {
-        // What the dyn kernels need from this step (shipsim_dynamics.hip): an auto-reset env adopts its next episode's space
-        // before the next step (DR_RESET -> dyn_adopt_kernel).  A space that is stepped queues itself; one at REST must be woken
+        // What the dyn kernels need from this step (shipsim_dynamics.hip): an auto-reset env continues on the space of its new
+        // episode (below).  A space that is stepped queues itself; one at REST must be woken
         // if the player is about to remove a goal from it (the removed goal's cached arbiters leave with it): whether the
         // player's hull can reach a goal after its next cpBodyUpdatePosition is decided here, conservatively — every hull
         // vertex moves by at most |v dt| + (hull radius) |w dt| per axis, and a resting space's goals stay where this step's
         // table has them — and the env is queued for the cpSpaceStep after the next one, which evaluates collide_goal exactly.
-        if (live && do_reset) c.dyn_req[el_] = (uint8_t)DR_RESET;
+        if (live) {
+            const unsigned req_new = do_reset ? (unsigned)DR_RESET : ((req0 & DR_RESET) ? (unsigned)DR_ADOPTING : 0u);
+            if (req_new != req0) c.dyn_req[el_] = (uint8_t)req_new;
+        }
+        if (live && do_reset) {
+            // ShipGame.reset + add_default_traffic for the other bodies: the world of the episode that starts now sits in the env's
+            // N slot (episodes & 1; `episodes`, `map_id` are already the new episode's), built and stepped once by an N job an
+            // episode ago.  The NEXT step reads its table (DR_RESET); the dyn step of the step after continues from the slot into
+            // the current space (ADOPT) — and the N job of the episode after this one is ordered into the other slot.  Whatever
+            // the old space still has in the queues is void from here on (generation).
+            const unsigned gen_new = ((unsigned)c.dyn_gen[el_] + 1u) & 255u;
+            c.dyn_gen[el_] = (uint8_t)gen_new;
+            const unsigned tq = c.dyn_tick + 2u, qq = tq & 1u;
+            const int nm = next_map(c, map_id);
+            const int vn = (1 + ((episodes + 1) & 1)) * c.n_pad + el_;
+            const unsigned ba = dyn_bucket_of(1, map_id), bn = dyn_bucket_of(0, nm);
+            unsigned *cnt = c.dyn_count + (size_t)qq * kDynCountWords + kDynBucket0;
+            const unsigned slot_a = atomicAdd(cnt + ba * kDynBucketStride, 1u), slot_n = atomicAdd(cnt + bn * kDynBucketStride, 1u);
+            c.dyn_row[(size_t)vn * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episodes + 1) << 32)));
+            int32_t *region = c.dyn_region + (size_t)qq * kDynBuckets * (size_t)c.dyn_np;
+            if (slot_a < (unsigned)c.dyn_np) region[(size_t)ba * c.dyn_np + slot_a] = (int32_t)dyn_entry((unsigned)el_, (episodes & 1) ? DQ_ADOPT1 : DQ_ADOPT0, gen_new);
+            else atomicAdd(c.dyn_err + 1, 1u);
+            if (slot_n < (unsigned)c.dyn_np) region[(size_t)bn * c.dyn_np + slot_n] = (int32_t)dyn_entry((unsigned)vn, DQ_NJOB, (unsigned)c.dyn_gen[vn]);
+            else atomicAdd(c.dyn_err + 1, 1u);
+        }
         // (only a resting space with cached arbiters on goals can be disturbed — dyn_flag bits 2, 3; the flag of a space the
-        // concurrent dyn step is stepping may be read old or new: old = "not at rest" is the safe side, new is exact)
-        if (live && !do_reset && ((dflag & 12u) != 4u)) {
+        // concurrent dyn step is stepping may be read old or new: old = "not at rest" is the safe side, new is exact; the flag
+        // of a space that is still being taken over from its N slot says nothing)
+        if (live && !do_reset && (((dflag & 12u) != 4u) | (req0 != 0u))) {
             const double wr = c.dyn_hull_r * fabs(w * c.dt);
             const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr, r = c.goal_r;
             bool reach = false;

@@ -33,9 +33,10 @@ def _oracle_dyn(ob, idx):
 
 
 def _compare_dyn(N, vec, ob, just_reset=None, atol=1e-9):
-    """Traffic / goal body columns against the oracle's bodies.  The HIP path rebuilds the bodies of an auto-reset
-    env at the start of that env's next step (the dyn kernel sees the step kernel's reset bit), so envs that were
-    reset by the step just taken are compared one step later."""
+    """Traffic / goal body columns against the oracle's bodies.  The body COLUMNS of an auto-reset env lag its reset by two
+    steps (include/shipsim.h, SSG_F_TRAFFIC: in the step after the reset the step kernel reads the new world from the table
+    its N slot published; the dyn step after that continues from the slot into the columns): `just_reset` = the envs that
+    were reset by one of the last two steps are left out."""
     idx = np.arange(vec.num_envs)
     keep = np.ones(vec.num_envs, dtype=bool) if just_reset is None else ~just_reset.astype(bool)
     t_g, g_g = _dyn_state(N, vec)
@@ -59,8 +60,10 @@ def test_config4_parity(n, nb, K, n_maps):
     acts = vec.random_actions(4242, 0, K)
     acts_h = acts.cpu().numpy()
     max_err, n_done, n_col = 0.0, 0, 0
+    r_done = np.zeros(n, dtype=np.uint8)
     for k in range(K):
         obs, rew, done, flags = vec.step_tensor(acts[k])
+        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
         np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
         np.testing.assert_array_equal(rew.cpu().numpy(), r_rew, err_msg="reward differs at step %d" % k)
@@ -70,7 +73,7 @@ def test_config4_parity(n, nb, K, n_maps):
         n_done += int(r_done.sum())
         n_col += int(((flags.cpu().numpy() & N.EV_COLLIDING) != 0).sum())
         if k in (0, 1, 2, 7, 40, K - 1):
-            _compare_dyn(N, vec, ob, just_reset=r_done)
+            _compare_dyn(N, vec, ob, just_reset=r_done | p_done)
     assert n_done > n // 4 and n_col > 0
     assert max_err <= 1e-9
     vec.close()
@@ -102,7 +105,9 @@ def test_config4_pipelined_rollout_matches_oracle_every_step(n, nb, K, n_maps):
     parts[1] = [t.clone() for t in vec.rollout_tensor(acts[K1:], trajectory=True)]
     g_obs, g_rew, g_done, g_flags = [torch.cat([a, b]).cpu().numpy() for a, b in zip(*parts)]
     worst, n_done, n_goal = 0.0, 0, 0
+    r_done = np.zeros(n, dtype=np.uint8)
     for k in range(K):
+        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
         np.testing.assert_array_equal(g_done[k], r_done, err_msg="done differs at pipelined step %d" % k)
         np.testing.assert_array_equal(g_rew[k], r_rew, err_msg="reward differs at pipelined step %d" % k)
@@ -111,7 +116,7 @@ def test_config4_pipelined_rollout_matches_oracle_every_step(n, nb, K, n_maps):
         worst = max(worst, err)
         n_done += int(r_done.sum()); n_goal += int((r_rew == 1.0).sum())
     assert worst <= 1e-9 and n_done > n // 4 and n_goal > 0
-    _compare_dyn(N, vec, ob, just_reset=r_done)
+    _compare_dyn(N, vec, ob, just_reset=r_done | p_done)
     assert _dyn_errors(N, vec) == [0, 0, 0, 0]
     # the same steps, one launch sequence per step
     b = ShipVecEnv(n, n_beams=nb, n_maps=n_maps, n_ships=4)
@@ -120,7 +125,7 @@ def test_config4_pipelined_rollout_matches_oracle_every_step(n, nb, K, n_maps):
         o, r, d, f = b.step_tensor(acts[k])
         assert torch.equal(o, torch.from_numpy(g_obs[k]).to(o.device)), "step %d" % k
         assert torch.equal(d, torch.from_numpy(g_done[k]).to(d.device)) and torch.equal(f, torch.from_numpy(g_flags[k]).to(f.device))
-    keep = torch.from_numpy(~r_done.astype(bool)).to(b.device)
+    keep = torch.from_numpy(~(r_done | p_done).astype(bool)).to(b.device)
     assert torch.equal(b.field(N.F_TRAFFIC)[:, keep], vec.field(N.F_TRAFFIC)[:, keep])
     assert torch.equal(b.field(N.F_X), vec.field(N.F_X)) and torch.equal(b.field(N.F_GOAL_MASK), vec.field(N.F_GOAL_MASK))
     assert _dyn_errors(N, b) == [0, 0, 0, 0]
@@ -168,14 +173,16 @@ def test_config4_solver_scenarios():
     acts = acts.astype(np.int32)                          # kind 3 drives forward, the others only move the rudder
     n_col = 0
     struck = np.zeros(n, dtype=bool)
+    r_done = np.zeros(n, dtype=np.uint8)
     for k in range(K):
         a = torch.from_numpy(acts[k]).to(vec.device)
         obs, rew, done, flags = vec.step_tensor(a)
+        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts[k], auto_reset=True)
         np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
         np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
         assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
-        _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
+        _compare_dyn(N, vec, ob, just_reset=r_done | p_done, atol=1e-8)
         n_col += int(((flags.cpu().numpy() & N.EV_COLLIDING) != 0)[3::4].sum())
         struck |= np.abs(_dyn_state(N, vec)[0][:, 2, 3:]).max(axis=1) > 0      # ship 3 acquired a real velocity
     assert n_col >= n // 8                                # the player did run into the parked ships
@@ -231,12 +238,14 @@ def test_config4_rest_bit_and_poke_at_rest():
     for e in idx:
         cur = ob.peek_dyn(int(e))["traffic"][1]
         ob.poke_traffic(int(e), 1, 372.0, 360.0, cur[2], 11.0, cur[4], 0.03)
+    r_done = np.zeros(n, dtype=np.uint8)
     for k in range(25):
         obs, rew, done, flags = vec.step_tensor(ones)
+        p_done = r_done
         r_obs, r_rew, r_done = ob.step(np.ones(n, dtype=np.int32))
         np.testing.assert_array_equal(done.cpu().numpy(), r_done)
         assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
-        _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
+        _compare_dyn(N, vec, ob, just_reset=r_done | p_done, atol=1e-8)
     t, _ = _dyn_state(N, vec)
     assert (np.abs(t[idx, 2, 0] - 400.0) > 1e-3).mean() > 0.9     # ship 3 was really pushed in the poked envs
     vec.close()
@@ -308,14 +317,16 @@ def test_config4_curriculum_maps():
     np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
     acts_h = acts.cpu().numpy()
     moved3 = False
+    r_done = np.zeros(n, dtype=np.uint8)
     for k in range(12, 130):
         obs, rew, done, flags = vec.step_tensor(acts[k])
+        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
         np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
         np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
         assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
         if k % 10 == 0:
-            _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
+            _compare_dyn(N, vec, ob, just_reset=r_done | p_done, atol=1e-8)
             moved3 |= bool((_dyn_state(N, vec)[0][:, 0, 0] > 170.0).any())
     assert moved3                                                 # ship 1 is pushed out of a left bank wider than lesson 0's 150
     vec.close()
