@@ -290,12 +290,6 @@ int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev
  * (0 = gathered from L2 / HBM) and the dynamic LDS bytes per workgroup. */
 int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int *bank_in_lds, size_t *lds_bytes);
 
-/* Inspection aid, config 4 (no reference counterpart): the pipeline's should-never-happen counters since the state blob was
- * zeroed, read back synchronously on `stream`: out[0] = auto-reset envs that found no usable next-episode space inside a
- * pipelined rollout, out[1] = queue entries dropped because a bucket was full, out[2..3] reserved.  All zero in a correct run
- * (tests assert it). */
-int ssg_debug_dyn_errors(ssg_handle *h, uint32_t out[4], void *stream);
-
 /* Measurement aid (no reference counterpart): coalesced 8-byte-per-lane device copy of n_doubles doubles, the
  * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);

@@ -25,7 +25,7 @@ EXPORTS = (
     "ssg_config_set_ship", "ssg_state_nbytes", "ssg_state_field", "ssg_bind_state", "ssg_set_map_bank", "ssg_reset",
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
-    "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_debug_dyn_errors", "ssg_rollout_traj",
+    "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_rollout_traj",
 )
 
 
@@ -94,7 +94,6 @@ def lib():
     L.ssg_debug_copy8.argtypes = [vp, vp, C.c_size_t, vp]
     L.ssg_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp]
     L.ssg_dyn_invalidate.argtypes = [vp, vp, vp]
-    L.ssg_debug_dyn_errors.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.ssg_host_convex_hull.argtypes = [C.c_int, dp, dp, ip]
     L.ssg_host_moment_for_poly.argtypes = [C.c_double, C.c_int, dp, dp]
     L.ssg_host_goal_x_range.argtypes = [dp, C.c_double, C.c_double, dp, dp, ip]

@@ -18,21 +18,10 @@ struct ssg_handle {
     ssg::DevCfg dev{};
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
-    // config 4 only (shipsim_internal.h DevCfg::dyn_*)
-    size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0, off_dyn_hash = 0, off_dyn_row = 0;
-    size_t off_dyn_gen = 0, off_dyn_age = 0, off_dyn_vmap = 0, off_dyn_req = 0, off_dyn_nvalid = 0, off_dyn_obs = 0, off_dyn_ps = 0, off_dyn_region = 0, off_dyn_count = 0, off_dyn_err = 0;
-    bool dyn_queue_valid = false; // the queues of the coming steps are what the kernels left (nothing host-side touched the envs since)
-    unsigned dyn_tick = 1;        // the next API step (its parity selects the per-step buffers of the dyn pipeline)
+    size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
+    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0, off_dyn_row = 0, off_dyn_segcnt = 0;
+    bool dyn_queue_valid = false; // the step kernel's last launch left the next step's dyn queue (nothing host-side touched the envs since)
     ssg::DynCfg dyn{};
-    hipStream_t dyn_stream = nullptr;   // the pipelined rollout's second stream (the dyn step of step k+1 beside the step kernel of step k)
-    hipEvent_t ev_adopt = nullptr, ev_dyn = nullptr;
-    int dyn_stream_device = -1;
-    ~ssg_handle()
-    {
-        if (ev_adopt) (void)hipEventDestroy(ev_adopt);
-        if (ev_dyn) (void)hipEventDestroy(ev_dyn);
-        if (dyn_stream) (void)hipStreamDestroy(dyn_stream);
-    }
     void *state = nullptr;
     const double *bank = nullptr;
     int n_maps = 0;
@@ -278,6 +267,16 @@ int set_traffic(ssg_handle *h)
         d.tx[k] = kTraffic[k][0];
         d.ty[k] = kTraffic[k][1];
     }
+    // furthest hull vertex from the body position, for the conservative reach test of the player x traffic pairs
+    auto hull_radius = [](const double *hull) {
+        double r2 = 0.0;
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) r2 = std::max(r2, hull[2 * i] * hull[2 * i] + hull[2 * i + 1] * hull[2 * i + 1]);
+        return std::sqrt(r2);
+    };
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        const double r = (hull_radius(h->cfg.ship_hull) + hull_radius(d.thull[k])) * 1.001 + 1.0;
+        d.reach2[k] = r * r;
+    }
     d.t_m_inv = h->cfg.ship_m_inv;
     // add_goal (game.py:77-95): mass 1, pm.moment_for_circle(1, 0, radius) = m * 0.5 * (r1^2 + r2^2)
     d.goal_m_inv = 1.0 / 1.0;
@@ -342,29 +341,18 @@ void refresh_dev(ssg_handle *h)
     d.bank = h->bank;
     d.n_ships = c.n_ships;
     const bool dyn = base && c.n_ships > 1;
-    d.dyn_np = 3 * h->n_pad;
-    d.dyn_tick = h->dyn_tick;
-    auto at = [&](size_t off) -> char * { return dyn ? base + off : nullptr; };
-    d.dyn_f64 = reinterpret_cast<double *>(at(h->off_dyn_f64));
-    d.dyn_live = reinterpret_cast<unsigned long long *>(at(h->off_dyn_live));
-    d.dyn_u32 = reinterpret_cast<uint32_t *>(at(h->off_dyn_u32));
-    d.dyn_flag = reinterpret_cast<uint8_t *>(at(h->off_dyn_flag));
-    d.dyn_hash = reinterpret_cast<unsigned long long *>(at(h->off_dyn_hash));
-    d.dyn_row = reinterpret_cast<double *>(at(h->off_dyn_row));
-    d.dyn_gen = reinterpret_cast<uint8_t *>(at(h->off_dyn_gen));
-    d.dyn_age = reinterpret_cast<uint8_t *>(at(h->off_dyn_age));
-    d.dyn_vmap = reinterpret_cast<int32_t *>(at(h->off_dyn_vmap));
-    d.dyn_req = reinterpret_cast<uint8_t *>(at(h->off_dyn_req));
-    d.dyn_nvalid = reinterpret_cast<unsigned long long *>(at(h->off_dyn_nvalid));
-    d.dyn_obs = reinterpret_cast<double *>(at(h->off_dyn_obs));
-    d.dyn_ps = reinterpret_cast<double *>(at(h->off_dyn_ps));
-    d.dyn_region = reinterpret_cast<int32_t *>(at(h->off_dyn_region));
-    d.dyn_count = reinterpret_cast<unsigned *>(at(h->off_dyn_count));
-    d.dyn_err = reinterpret_cast<unsigned *>(at(h->off_dyn_err));
-    std::memcpy(d.thull, h->dyn.thull, sizeof(d.thull));
-    std::memcpy(d.tnrm, h->dyn.tnrm, sizeof(d.tnrm));
-    {   // the step kernel's reject in front of collide_ship's exact player x traffic test: no vertex of ship k's hull is further than
-        // its hull radius from its body position, so a player whose world box is further than that from the position cannot touch it
+    d.dyn_f64 = dyn ? reinterpret_cast<double *>(base + h->off_dyn_f64) : nullptr;
+    d.dyn_live = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_live) : nullptr;
+    d.dyn_u32 = dyn ? reinterpret_cast<uint32_t *>(base + h->off_dyn_u32) : nullptr;
+    d.dyn_flag = dyn ? reinterpret_cast<uint8_t *>(base + h->off_dyn_flag) : nullptr;
+    d.dyn_hash = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_hash) : nullptr;
+    d.dyn_queue = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_queue) : nullptr;
+    d.dyn_count = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_count) : nullptr;
+    d.dyn_qkey = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_qkey) : nullptr;
+    d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
+    d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
+    d.dyn_segcnt = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_segcnt) : nullptr;
+    {   // the step kernel's reach test: (hull radius of traffic ship k, with a margin)^2 and the player's own hull radius
         auto radius = [](const double *hull) {
             double r2 = 0.0;
             for (int i = 0; i < SSG_SHIP_VERTS; ++i) r2 = std::max(r2, hull[2 * i] * hull[2 * i] + hull[2 * i + 1] * hull[2 * i + 1]);
@@ -489,8 +477,6 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring must be 0 or in 2..64");
     if (cfg->map_ring != 0 && cfg->history > 2)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring needs history <= 2");
-    if (cfg->n_ships > 1 && cfg->map_ring != 0 && cfg->map_ring < 3) // (current episode, the next one's space, one unused world)
-        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_ships = 4 needs map_ring >= 3");
     if (cfg->n_ships > 1 && (cfg->flags & SSG_FLAG_EXACT_LIDAR))
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: SSG_FLAG_EXACT_LIDAR is not built for n_ships = 4");
     ssg_handle *h = new (std::nothrow) ssg_handle();
@@ -515,27 +501,18 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     }
     if (h->cfg.n_ships > 1) {
         // config 4: columns of the traffic ships, goal bodies and cached arbiters (shipsim_internal.h DC_* / DU_*)
-        // (every per-space column has 3 * n_pad elements: env e's current space e and its two N slots n_pad + e, 2 n_pad + e)
-        const size_t dnp = 3 * np;
-        auto take = [&](size_t &off, size_t bytes) { off = (h->nbytes + 255) & ~(size_t)255; h->nbytes = off + bytes; };
-        take(h->off_dyn_f64, (size_t)ssg::DC_COUNT * dnp * sizeof(double));
-        take(h->off_dyn_live, dnp * sizeof(unsigned long long));
-        take(h->off_dyn_u32, (size_t)ssg::DU_COUNT * dnp * sizeof(uint32_t));
-        take(h->off_dyn_flag, dnp);
-        take(h->off_dyn_hash, dnp * sizeof(unsigned long long));
-        take(h->off_dyn_row, dnp * (size_t)ssg::kDynRow * sizeof(double));
-        take(h->off_dyn_gen, dnp);
-        take(h->off_dyn_age, dnp);
-        take(h->off_dyn_vmap, dnp * sizeof(int32_t));
-        take(h->off_dyn_req, np);
-        take(h->off_dyn_nvalid, 2 * np * sizeof(unsigned long long));
-        take(h->off_dyn_obs, (size_t)ssg::kDynObsPlanes * ssg::kDynObs * np * sizeof(double));
-        take(h->off_dyn_ps, 2 * (size_t)ssg::kDynPsRow * np * sizeof(double));
-        take(h->off_dyn_count, 2 * (size_t)ssg::kDynCountWords * sizeof(unsigned));
-        take(h->off_dyn_err, 256);
-        // the bucketed queues of the full dyn step (two, by step parity): every (bank record, age) bucket owns 2 * n_pad slots (a
-        // space sits in one bucket, but nothing bounds how the spaces spread over them)
-        take(h->off_dyn_region, 2 * (size_t)ssg::kDynBuckets * dnp * sizeof(int32_t));
+        h->off_dyn_f64 = (h->nbytes + 255) & ~(size_t)255;
+        h->off_dyn_live = h->off_dyn_f64 + (size_t)ssg::DC_COUNT * np * sizeof(double);
+        h->off_dyn_u32 = h->off_dyn_live + np * sizeof(unsigned long long);
+        h->off_dyn_flag = h->off_dyn_u32 + (size_t)ssg::DU_COUNT * np * sizeof(uint32_t);
+        h->off_dyn_hash = h->off_dyn_flag + np;
+        h->off_dyn_queue = h->off_dyn_hash + np * sizeof(unsigned long long);
+        h->off_dyn_count = h->off_dyn_queue + np * sizeof(int32_t);
+        h->off_dyn_qkey = h->off_dyn_count + (((size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
+        h->off_dyn_sorted = h->off_dyn_qkey + np * sizeof(unsigned long long);
+        h->off_dyn_row = (h->off_dyn_sorted + (np + (size_t)ssg::kDynSortedPad) * sizeof(int32_t) + 255) & ~(size_t)255;
+        h->off_dyn_segcnt = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
+        h->nbytes = h->off_dyn_segcnt + ((np / 64 * sizeof(unsigned) + 255) & ~(size_t)255);
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -577,11 +554,8 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
     } else if (field == SSG_F_TRAFFIC || field == SSG_F_GOAL_BODIES) {
         if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
         const int c0 = field == SSG_F_TRAFFIC ? ssg::DC_TRAFFIC : ssg::DC_GOALS;
-        // (a dyn column has 3 * n_pad elements — the envs' current spaces, then their coming episodes': the stride says so)
-        off = h->off_dyn_f64 + (size_t)c0 * 3 * np * 8; es = 8;
+        off = h->off_dyn_f64 + (size_t)c0 * np * 8; es = 8;
         nc = field == SSG_F_TRAFFIC ? 9 * SSG_N_TRAFFIC : ssg::DC_GOAL_COLS * SSG_MAX_GOALS;
-        *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = 3 * np * 8;
-        return SSG_OK;
     } else if (field == SSG_F_EPISODES) {
         off = h->off_i32 + (size_t)ssg::ICOL_EPISODE * np * 4; es = 4; nc = 1;
     } else if (field == SSG_F_DYN_FLAGS) {
@@ -761,113 +735,44 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
     auto done_at = [&](int k) { return dev_done + (size_t)k * (size_t)traj; };
     auto flags_at = [&](int k) { return dev_flags ? dev_flags + (size_t)k * (size_t)traj : nullptr; };
     const bool dyn = h->cfg.n_ships > 1;
-    if (dyn) {
-        // Config 4.  Per step: the full dyn step of the queued spaces, then the step kernel — two launches.  Inside a rollout of
-        // several steps the dyn step of step k+1 runs beside the step kernel of step k on the handle's second stream
-        // (shipsim_dynamics.hip header: it needs nothing that step kernel produces); the first dyn step of the call has nothing
-        // to run beside.
+    if (h->cfg.history > 2 || dyn) {
+        // non-default history: one launch per step into the staging rows, then the frame shift (see the kernel).
+        // config 4: every step is the dyn kernel (traffic ships, goal bodies, contact solver) followed by the step
+        // kernel, which reads this step's goal positions and the traffic-contact bit it left in the dyn columns.
         const bool shift = h->cfg.history > 2;
-        hipStream_t sa = static_cast<hipStream_t>(stream);
         if (h->cfg.map_ring > 0 && !h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds first");
-        static const bool kSerial = [] { const char *sv = std::getenv("SSG_DYN_SERIAL"); return sv && std::atoi(sv) != 0; }();
-        auto bail = [&](const char *what, hipError_t e) {
-            h->dyn_queue_valid = false; // (the next call rebuilds the queues from the columns)
-            return fail(h, SSG_ERR_HIP, std::string(what) + hipGetErrorString(e));
-        };
-        // what must precede the dyn step of step `tick` on stream sa: adoptions, and the queues rebuilt if the host touched the envs
-        auto prologue = [&]() -> hipError_t {
-            h->dev.dyn_tick = h->dyn_tick;
-            if (h->dyn_queue_valid) return hipSuccess;
-            hipError_t e = hipMemsetAsync(h->dev.dyn_count, 0, 2 * (size_t)ssg::kDynCountWords * sizeof(unsigned), sa);
-            if (e == hipSuccess) e = ssg::launch_dyn_classify(h->dev, h->dyn, sa);
-            return e;
-        };
-        auto step_launch = [&](int k) -> hipError_t {
-            hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
-                                            shift ? h->dev.obs2 : obs_at(k), rew_at(k), done_at(k), flags_at(k), 0, sa);
-            if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), sa);
-            return e;
-        };
-        for (int k = 0; k < K;) {
-            int kk = K - k;
-            if (h->cfg.map_ring > 0) {
-                // every step may start one episode per env, and an env's NEXT episode's space is built as soon as it starts
-                // one: keep two unused worlds in every ring
-                if (h->ring_credit < 2) {
+        for (int k = 0; k < K; ++k) {
+            if (h->cfg.map_ring > 0) { // every step may start one episode per env: keep an unused world in every ring
+                if (h->ring_credit < 1) {
                     rc = ring_refill(h, nullptr, stream);
                     if (rc != SSG_OK) return rc;
                 }
-                kk = kk < h->ring_credit - 1 ? kk : h->ring_credit - 1;
-                h->ring_credit -= kk;
+                h->ring_credit -= 1;
             }
-            hipError_t e = prologue();
-            if (e != hipSuccess) return bail("dyn classify launch: ", e);
-            h->dyn_queue_valid = true;
-            e = ssg::launch_dyn_step(h->dev, h->dyn, sa);
-            if (e != hipSuccess) return bail("dyn step launch: ", e);
-            const bool pipelined = kk > 1 && !shift && !kSerial;
-            if (!pipelined) {
-                for (int j = 0; j < kk; ++j) {
-                    if (j > 0) {
-                        h->dev.dyn_tick = h->dyn_tick;
-                        e = ssg::launch_dyn_step(h->dev, h->dyn, sa);
-                        if (e != hipSuccess) return bail("dyn step launch: ", e);
-                    }
-                    e = step_launch(k + j);
-                    if (e != hipSuccess) return bail("step launch: ", e);
-                    h->dyn_tick += 1;
+            if (dyn) {
+                hipError_t e = hipSuccess;
+                if (!h->dyn_queue_valid) { // the classify pass rebuilds the queue: its bucket counters and length start from zero,
+                                           // the sorted queue holds nothing (-1 everywhere: the sort only writes the entries)
+                    e = hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
+                    if (e == hipSuccess)
+                        e = hipMemsetAsync(h->dev.dyn_sorted, 0xFF, ((size_t)h->dev.n_pad + ssg::kDynSortedPad) * sizeof(int32_t),
+                                           static_cast<hipStream_t>(stream));
                 }
-            } else {
-                if (!h->dyn_stream || h->dyn_stream_device != h->cfg.device_id) {
-                    if (h->dyn_stream) { (void)hipStreamDestroy(h->dyn_stream); h->dyn_stream = nullptr; }
-                    int lo = 0, hi = 0;
-                    (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // the chain that bounds the step is the dyn step's: give it the CUs first
-                    static const bool kPrio = [] { const char *sv = std::getenv("SSG_DYN_PRIO"); return !sv || std::atoi(sv) != 0; }(); // (experiments)
-                    e = hipStreamCreateWithPriority(&h->dyn_stream, hipStreamNonBlocking, kPrio ? hi : lo);
-                    if (e == hipSuccess && !h->ev_adopt) e = hipEventCreateWithFlags(&h->ev_adopt, hipEventDisableTiming);
-                    if (e == hipSuccess && !h->ev_dyn) e = hipEventCreateWithFlags(&h->ev_dyn, hipEventDisableTiming);
-                    if (e != hipSuccess) return bail("second stream: ", e);
-                    h->dyn_stream_device = h->cfg.device_id;
+                if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
+                if (e != hipSuccess) {
+                    h->dyn_queue_valid = false; // (a sorted queue the full step never consumed must not survive: the next call starts over)
+                    return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
                 }
-                hipStream_t sb = h->dyn_stream;
-                static const int kNoSync = [] { const char *sv = std::getenv("SSG_DYN_NOSYNC"); return sv ? std::atoi(sv) : 0; }(); // (timing experiments only: wrong results)
-                // Stream B carries the chain that bounds the step — dyn(t+1), dyn(t+2), ... in order; each waits for the step
-                // kernel two steps back (the player state it predicts from; long finished as a rule).  Stream A runs the step
-                // kernels, each after the dyn step of its own step.
-                e = hipEventRecord(h->ev_adopt, sa); // (the call's first dyn step, on A)
-                if (e == hipSuccess) e = hipStreamWaitEvent(sb, h->ev_adopt, 0);
-                for (int j = 0; j < kk && e == hipSuccess; ++j) {
-                    const bool more = j + 1 < kk;
-                    if (more) { // the dyn step of the NEXT step, beside this step's kernel
-                        h->dev.dyn_tick = h->dyn_tick + 1;
-                        e = ssg::launch_dyn_step(h->dev, h->dyn, sb);
-                        if (e == hipSuccess) e = hipEventRecord(h->ev_adopt, sb);
-                        if (e != hipSuccess) break;
-                    }
-                    h->dev.dyn_tick = h->dyn_tick;
-                    e = step_launch(k + j);
-                    h->dyn_tick += 1;
-                    if (e == hipSuccess && more) {
-                        if (!(kNoSync & 1)) {
-                            e = hipEventRecord(h->ev_dyn, sa); // (step kernel t done: dyn(t+2) reads what it left)
-                            if (e == hipSuccess) e = hipStreamWaitEvent(sb, h->ev_dyn, 0);
-                        }
-                        if (!(kNoSync & 2) && e == hipSuccess) e = hipStreamWaitEvent(sa, h->ev_adopt, 0); // (step kernel t+1 reads what dyn(t+1) leaves)
-                    }
-                }
-                if (e != hipSuccess) return bail("pipelined config-4 rollout: ", e);
             }
-            k += kk;
-        }
-        return SSG_OK;
-    }
-    if (h->cfg.history > 2) {
-        // non-default history: one launch per step into the staging rows, then the frame shift (see the kernel).
-        for (int k = 0; k < K; ++k) {
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
-                                            h->dev.obs2, rew_at(k), done_at(k), flags_at(k), 0, static_cast<hipStream_t>(stream));
-            if (e == hipSuccess) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
-            if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+                                            shift ? h->dev.obs2 : obs_at(k), rew_at(k), done_at(k), flags_at(k), 0,
+                                            static_cast<hipStream_t>(stream));
+            if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) {
+                h->dyn_queue_valid = false; // (the next call rebuilds the dyn queue from the flags, counters zeroed)
+                return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+            }
+            if (dyn) h->dyn_queue_valid = true; // the step kernel's body role has queued the envs whose bodies must be stepped next
         }
         return SSG_OK;
     }
@@ -956,19 +861,6 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream)
     h->dyn_queue_valid = false;
     hipError_t e = ssg::launch_dyn_invalidate(h->dev, dev_mask, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn_invalidate launch: ") + hipGetErrorString(e));
-    return SSG_OK;
-}
-
-int ssg_debug_dyn_errors(ssg_handle *h, uint32_t out[4], void *stream)
-{
-    int rc = check_ready(h, false);
-    if (rc != SSG_OK) return rc;
-    if (!out) return fail(h, SSG_ERR_BAD_ARG, "ssg_debug_dyn_errors: NULL argument");
-    out[0] = out[1] = out[2] = out[3] = 0;
-    if (h->cfg.n_ships <= 1) return SSG_OK;
-    hipError_t e = hipMemcpyAsync(out, h->dev.dyn_err, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
-    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_debug_dyn_errors: ") + hipGetErrorString(e));
     return SSG_OK;
 }
 

@@ -25,30 +25,12 @@
 //    EPA's growing hull has seven LDS entries per lane, scratch beyond (practically never).
 //  * Arbiter records (accumulated impulses, contact hashes, state, age) persist in struct-of-arrays columns but are
 //    read or written only for pairs whose bit is set in the env's 64-bit live mask.
-//  * Which spaces are stepped: the ones queued for this step into their (bank record, steps since the reset) bucket
-//    (shipsim_internal.h: one returning atomic per entry, no sort pass), walked map-major so that the lanes of a wave sit on
-//    one bank record and on neighbouring ages and walk the same path, and read through a row-major shadow of the body columns
-//    (DevCfg::dyn_row).  A space that changed queues itself for the next step; one at a fixed point of cpSpaceStep (the rest
-//    bit) is not stepped at all until something wakes it.
-//
-// The pipeline.  The player never pushes anything (PLAYER assumption), so the other bodies of an env evolve on their own
-// except for (a) the goals the player removes (deferred space.remove, game.py:252) and (b) the end of the episode.  Both
-// are decided by the player's pose after cpBodyUpdatePosition, which step k's action cannot change: pose(k) = state(k-1)
-// advanced by state(k-1)'s velocities.  So the cpSpaceStep of API step k+1 needs from the player only the state the step
-// kernel of step k-1 left behind (DevCfg::dyn_ps): it evaluates collide_goal for step k itself (same expressions as the step
-// kernel) and drops the removed goals' arbiters — and therefore runs BESIDE the step kernel of step k, on a second stream:
-//     stream A:  step(k)   | adopt(k)            | step(k+1) | ...
-//     stream B:  dyn(k+1)  |          dyn(k+2)                | ...
-// (b): an env the step kernel auto-resets needs its NEW world's first cpSpaceStep before the next step kernel — a fresh
-// world's hardest step (ship 1 spawns inside the left bank).  Every env therefore keeps the spaces of its coming episodes
-// ready, built from their records and stepped once ("N" slots, vspace (1 + s) * n_pad + e, episode q in slot q & 1; nothing in
-// them depends on the player): an N job publishes what the step kernel needs of it in its own plane of DevCfg::dyn_obs.  On
-// a reset at step t the step kernel (i) reads step t+1's bodies from that plane, (ii) queues, for the dyn step of step t+2,
-// an ADOPT entry — cpSpaceStep FROM the N slot INTO the current space (C) — and the N job of the episode after.  The
-// step kernel otherwise reads the other bodies from the per-parity planes of dyn_obs while the next dyn step already rewrites
-// the columns, and runs collide_ship against the traffic ships itself.  So the body columns (SSG_F_TRAFFIC,
-// SSG_F_GOAL_BODIES) of an env lag its auto-reset by two steps.
-// Per step: dyn_step_kernel and the step kernel — two launches, side by side inside ssg_rollout*.
+//  * Which envs are stepped: the ones the step kernel's body role queued at the end of the previous step (segmented queue,
+//    DevCfg::dyn_queue), sorted by (bank record, steps since the reset) so that the lanes of a wave walk the same path
+//    (dyn_sort_kernel), read through a row-major shadow of the body columns (DevCfg::dyn_row).  Envs whose space is at a
+//    fixed point of cpSpaceStep (the rest bit) are not stepped at all.
+// Per step: dyn_sort_kernel, dyn_step_kernel, then the step kernel, which reads this step's goal positions and the
+// traffic-contact bit from the dyn columns (DevCfg::dyn_*) and queues the envs for the next step.
 //
 // The canonical pair order, the cold GJK start and the unsolved player arbiters are the named assumptions of the
 // oracle (oracle/ssg_dynamics.c header); this file follows the same ones.
@@ -63,24 +45,13 @@
 namespace ssg {
 namespace {
 
-// Per wave: [field][kGrp lanes] columns, then the wave-uniform hull constants (and, UNI, the wave's bank planes).  A workgroup of
-// the UNI kernel has TWO waves, each with its own region (kWaveLds doubles apart; they share nothing): two waves are what a CU's
-// LDS holds, and as ONE workgroup they fill whole CUs — the CUs the queue does not need stay entirely free for the step kernel
-// running beside this one (a 1 024-thread workgroup of it needs a whole CU's LDS and never found one when these waves were
-// spread one or two per CU over the chip).
-// (kUniWpg = 1: measured — two waves of one workgroup on a CU run 74 -> 87 us, and the free CUs bought the step kernel nothing)
-constexpr int kUniWpg = 1;
-extern __shared__ double lds_all[];
-#define lds (lds_all + (threadIdx.x >> 6) * kWaveLds)
+extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-uniform hull constants
 
 // Envs per workgroup of the full step (lanes kGrp..63 of its one wave idle: a lone wave's FP64 chain takes the same time
 // whatever its width).  Measured at 65 536 envs, planes once per wave: 48 (76 KB of LDS, two waves per CU) -> 62.5 us in
 // steady state and 135 us with every env queued; 32 (51 KB, three per CU) -> 63.9 / 132; 64 with per-lane planes (158 KB,
 // one per CU; round 2 and the first half of round 3) -> 60.9 / 165, and 100 whenever the queue outgrew 16 384 envs.
 constexpr int kGrp = kDynGrp;
-// (B_STRIDE * (goals + ships + static) + X_STRIDE * ships + A_STRIDE * kLdsArb + kEpaDoubles) * kGrp + hull constants + both banks'
-// planes, for SSG_MAX_GOALS goals: the UNI kernel's per-wave LDS in doubles (static_assert below)
-constexpr int kWaveLds = (8 * (SSG_MAX_GOALS + SSG_N_TRAFFIC + 1) + 3 * SSG_N_TRAFFIC + 25 * 2 + 56) * kDynGrp + 4 * SSG_SHIP_VERTS * (1 + SSG_N_TRAFFIC) + 2 * 4 * SSG_MAX_HULL;
 static_assert(kGrp == 32 || kGrp == 48 || kGrp == 64, "lds[field * kGrp + lane]: at 32 / 64 a lane keeps its LDS banks whatever the field; 48 pays an occasional 2-way conflict on the solver's per-lane body slots");
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
@@ -485,6 +456,27 @@ __device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info, co
     }
 }
 
+// SAT over both hulls' edge normals after the cpBBIntersects reject: "touching counts" (collide_ship's begin)
+__device__ __forceinline__ bool ships_touch(const ShipShape &a, const ShipShape &b)
+{
+    if (!bb_hit(a.bb(), b.bb())) return false;
+    bool sep = false;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const ShipShape &p = pass ? b : a, &q = pass ? a : b;
+#pragma unroll
+        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+            const V2 n = p.normal(i);
+            const double off = dot(n, p.vert(i));
+            double mn = INFINITY;
+#pragma unroll
+            for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, dot(n, q.vert(j)));
+            sep |= mn > off;
+        }
+    }
+    return !sep;
+}
+
 // ---- arbiter pair ids (bits of the live mask, rows of the arbiter columns) ----
 __device__ __forceinline__ int pid_tb(int k, int s) { return 2 * k + s; }                       // [0, 6)
 __device__ __forceinline__ int pid_tt(int j, int k) { return 6 + j + k - 1; }                   // j < k: [6, 9)
@@ -500,18 +492,16 @@ struct DynCols {
     size_t np;
 };
 
-// (re)create the non-player bodies of one space: a fresh pm.Space() after ShipGame.reset + add_default_traffic
-__device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, int v, const double *rec)
+// (re)create the non-player bodies of one env: a fresh pm.Space() after ShipGame.reset + add_default_traffic
+__device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, int e, const double *rec)
 {
-    double *row = c.dyn_row + (size_t)v * kDynRow; // the row-major shadow the full step loads from
+    double *row = c.dyn_row + (size_t)e * kDynRow; // the row-major shadow the full step loads from
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * col.np + v;
+        double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * col.np + e;
         t[0 * col.np] = d.tx[k]; t[1 * col.np] = d.ty[k];
         for (int f = 2; f < 9; ++f) t[(size_t)f * col.np] = 0.0;
         row[kDynRowTraffic + 9 * k] = d.tx[k]; row[kDynRowTraffic + 9 * k + 1] = d.ty[k];
         for (int f = 2; f < 9; ++f) row[kDynRowTraffic + 9 * k + f] = 0.0;
-        col.f64[(size_t)(DC_TROT + 2 * k) * col.np + v] = 1.0; // cpvforangle(0)
-        col.f64[(size_t)(DC_TROT + 2 * k + 1) * col.np + v] = 0.0;
     }
     // all goal centres first, then the stores: a load issued after a store it might alias waits for nothing, but the
     // compiler keeps program order, and one L2 round trip per goal coordinate made this the slowest part of pass 1
@@ -521,34 +511,14 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
         if (g >= c.n_goals) break;
-        double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * col.np + v;
+        double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * col.np + e;
         q[0 * col.np] = gxy[2 * g];
         q[1 * col.np] = gxy[2 * g + 1];
         for (int f = 2; f < DC_GOAL_COLS; ++f) q[(size_t)f * col.np] = 0.0;
         row[DC_GOAL_COLS * g] = gxy[2 * g]; row[DC_GOAL_COLS * g + 1] = gxy[2 * g + 1];
         for (int f = 2; f < DC_GOAL_COLS; ++f) row[DC_GOAL_COLS * g + f] = 0.0;
     }
-    col.live[v] = 0ull;
-    row[kDynRowLive] = __longlong_as_double(0ll);
-}
-
-// The step kernel's view of env e's other bodies (both step parities): from the columns of space v.
-__device__ void dyn_publish_obs(const DevCfg &c, int e, int v)
-{
-    const size_t dnp = (size_t)c.dyn_np, np = (size_t)c.n_pad;
-    for (int par = 0; par < 2; ++par) {
-        double *o = c.dyn_obs + (size_t)par * kDynObs * np + e;
-        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
-            o[(size_t)(kDynObsGoals + 2 * g) * np] = c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g) * dnp + v];
-            o[(size_t)(kDynObsGoals + 2 * g + 1) * np] = c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g + 1) * dnp + v];
-        }
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-            o[(size_t)(kDynObsTraffic + 4 * k) * np] = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * k) * dnp + v];
-            o[(size_t)(kDynObsTraffic + 4 * k + 1) * np] = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * k + 1) * dnp + v];
-            o[(size_t)(kDynObsTraffic + 4 * k + 2) * np] = c.dyn_f64[(size_t)(DC_TROT + 2 * k) * dnp + v];
-            o[(size_t)(kDynObsTraffic + 4 * k + 3) * np] = c.dyn_f64[(size_t)(DC_TROT + 2 * k + 1) * dnp + v];
-        }
-    }
+    col.live[e] = 0ull;
 }
 
 // An arbiter record: LDS columns of this lane (stride 64 doubles) for the first kLdsArb records of an env, scratch
@@ -564,27 +534,20 @@ struct ArbRef {
 
 } // namespace
 
-// ssg_reset (host side) for the masked envs: the current space is rebuilt right away (the caller sees the fresh bodies).
 __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *__restrict__ mask)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs) return;
     if (mask && !mask[e]) return;
-    DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.dyn_np};
-    const int m = c.i32cols[(size_t)ICOL_MAP * (size_t)c.n_pad + e]; // written by reset_kernel just before (same stream)
+    DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
+    const int m = c.i32cols[(size_t)ICOL_MAP * col.np + e]; // written by reset_kernel just before (same stream)
     const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
     dyn_init(c, d, col, e, rec);
     col.f64[(size_t)(DC_PREV_GOAL + 0) * col.np + e] = rec[SSG_MAP_OFF_SPAWN_GOAL]; // the reset frame's goal
     col.f64[(size_t)(DC_PREV_GOAL + 1) * col.np + e] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
     col.flag[e] = 0;
-    c.dyn_req[e] = 0;
-    const unsigned gen_new = ((unsigned)c.dyn_gen[e] + 1u) & 255u;
-    c.dyn_gen[e] = (uint8_t)gen_new;
-    c.dyn_age[e] = 0;
-    c.dyn_vmap[e] = m;
-    c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, 0u, 0u));
-    dyn_publish_obs(c, e, e);
 }
+
 // 64-bit mixing for the "did this step change anything" test of the full step (inputs vs outputs, no re-reads).
 __device__ __forceinline__ unsigned long long mix(unsigned long long h, unsigned long long v)
 {
@@ -607,6 +570,21 @@ __device__ __forceinline__ void stage_hulls(const DevCfg &c, const DynCfg &d, in
     }
 }
 
+// The player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel).
+__device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int hoff)
+{
+    const size_t np = (size_t)c.n_pad;
+    const double x = c.f64cols[(size_t)COL_X * np + e], y = c.f64cols[(size_t)COL_Y * np + e];
+    const double vx = c.f64cols[(size_t)COL_VX * np + e], vy = c.f64cols[(size_t)COL_VY * np + e];
+    const double ang = c.f64cols[(size_t)COL_A * np + e], w = c.f64cols[(size_t)COL_W * np + e];
+    ShipShape pl;
+    pl.hoff = hoff; pl.hashid = 0;
+    pl.p = mk(x + vx * c.dt, y + vy * c.dt);
+    sincos_body(ang + w * c.dt, &pl.sa, &pl.ca);
+    pl.cache();
+    return pl;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The rest bit.  cpSpaceStep is a deterministic function of the bodies' cpBody fields, the cached arbiters and
 // the static banks (the player never pushes anything: PLAYER assumption).  When a full step wrote back exactly the
@@ -614,12 +592,36 @@ __device__ __forceinline__ void stage_hulls(const DevCfg &c, const DynCfg &d, in
 // mask -- the space is at a fixed point: the next step is the identity.  (That is how a ship resting against a bank
 // ends up: the penetration left beyond the slop shrinks by 99.8 % per step until position + bias*dt rounds to the
 // position.)  The full step records that as the rest bit (with the bank generation it holds for); while it stands,
-// these bodies are skipped (the player's collide_ship test against the parked traffic runs in the step kernel, every
-// step, for every env).  A caller that writes the body columns itself must clear the bit with ssg_dyn_invalidate.
+// these bodies are skipped and only the player's collide_ship test against the parked traffic is left.  A caller
+// that writes the body columns itself must clear the bit with ssg_dyn_invalidate.
 // Everything else is appended to the queue of the full step.  In steady state that is the few steps after each reset in
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kClassifyThreads = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
+
+// collide_ship for a RESTING env: the player after its own cpBodyUpdatePosition against the three parked traffic ships
+// (hull constants at lds[0 ..]; same expressions as player_shape() / the full step).
+__device__ __forceinline__ bool resting_player_hit(const DevCfg &c, int e)
+{
+    const size_t np = (size_t)c.n_pad;
+    double tp[SSG_N_TRAFFIC][3];
+#pragma unroll
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        const double *t = c.dyn_f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+        tp[k][0] = t[0]; tp[k][1] = t[np]; tp[k][2] = t[2 * np];
+    }
+    const ShipShape pl = player_shape(c, e, 0);
+    bool hit = false;
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+        ShipShape sk;
+        sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
+        sk.p = mk(tp[k][0], tp[k][1]);
+        sincos_body(tp[k][2], &sk.sa, &sk.ca);
+        sk.cache();
+        hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
+    }
+    return hit;
+}
 
 // Which goals' cached arbiters leave with the goals the player has reached (deferred space.remove, game.py:252).
 __device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigned long long live, unsigned gmask, int ng)
@@ -634,88 +636,137 @@ __device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigne
     return live;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// dyn_classify_kernel (c.dyn_tick = k: step k is the next one).  In steady state the queues maintain themselves (a stepped
-// space that changed queues itself, the step kernel wakes resting spaces whose goals the player is about to reach, the
-// adopt pass queues what it adopted) and this kernel does not run.  It runs when the host touched the envs in between —
-// ssg_reset, a new bank, ssg_dyn_invalidate, a fresh handle — and rebuilds both queues (whose counters the caller zeroed) and
-// the player-state records from the columns: the record the dyn step of step k reads predicts nothing (the goal mask column is
-// current), the one for step k+1 is the state the columns hold.
-// ---------------------------------------------------------------------------------------------------------
+// In steady state the step kernel's body role classifies every env for the NEXT step at the end of each step (it holds the
+// player's state in registers: shipsim_kernels.hip, role 3) and this kernel does not run.  It runs when the host touched the
+// envs in between — ssg_reset, a new bank, ssg_dyn_invalidate, a fresh handle — and rebuilds the queue from the per-env flags.
 __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const DevCfg c, const DynCfg d)
 {
     const int e = blockIdx.x * kClassifyThreads + threadIdx.x;
-    if (e >= c.n_envs) return;
-    const size_t np = (size_t)c.n_pad;
-    const int ng = c.n_goals;
-    const unsigned tick = c.dyn_tick;
-    // everything this pass can need is requested at once (one memory round trip instead of dependent ones)
-    int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
-    int episode = c.i32cols[(size_t)ICOL_EPISODE * np + e];
-    unsigned flag = c.dyn_flag[e];
-    unsigned req = c.dyn_req[e];
-    unsigned gm_raw = c.mask[e];
-    unsigned long long live0 = c.dyn_live[e];
-    unsigned long long hash0 = c.dyn_hash[e];
-    unsigned long long nvalid0 = c.dyn_nvalid[e], nvalid1 = c.dyn_nvalid[np + e];
-    int vmap0 = c.dyn_vmap[c.n_pad + e], vmap1 = c.dyn_vmap[2 * c.n_pad + e];
-    int age = c.dyn_age[e];
-    double st[kDynPs];
+    const bool valid = e < c.n_envs;
+    bool need_full = false, sat_only = false;
+    unsigned bucket = 0;
+    if (valid) {
+        DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
+        const size_t np = col.np;
+        const int ng = c.n_goals;
+        // Everything this pass can need is requested at once (one memory round trip instead of five dependent ones:
+        // flag -> masks -> hash -> positions -> angles; the pass was latency-bound at 12.8 us for 65 536 envs).
+        int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
+        const int age = c.i32cols[(size_t)ICOL_STEP * np + e]; // steps since the reset: where the env is in its post-reset transient
+        unsigned flag = col.flag[e];
+        unsigned gm_raw = c.mask[e];
+        unsigned long long live0 = col.live[e];
+        unsigned long long hash0 = c.dyn_hash[e];
+        double px = c.f64cols[(size_t)COL_X * np + e], py = c.f64cols[(size_t)COL_Y * np + e];
+        double pvx = c.f64cols[(size_t)COL_VX * np + e], pvy = c.f64cols[(size_t)COL_VY * np + e];
+        double pang = c.f64cols[(size_t)COL_A * np + e], pw = c.f64cols[(size_t)COL_W * np + e];
+        double tp[SSG_N_TRAFFIC][3];
 #pragma unroll
-    for (int f = 0; f < kDynPs; ++f) st[f] = c.f64cols[(size_t)(COL_X + f) * np + e];
-    static_assert(COL_X == 0 && COL_W == 5 && kDynPs == 6, "x, y, vx, vy, angle, w are the first six state columns");
-    asm volatile("" : "+v"(map_id), "+v"(episode), "+v"(flag), "+v"(req), "+v"(gm_raw), "+v"(live0), "+v"(hash0), "+v"(nvalid0), "+v"(nvalid1), "+v"(vmap0), "+v"(vmap1), "+v"(age));
-    const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
-    // the player-state records: step k's dyn step reads parity k (nothing to predict), step k+1's reads parity k+1
-    for (int par = 0; par < 2; ++par) {
-        double *ps = c.dyn_ps + ((size_t)par * np + e) * kDynPsRow;
-#pragma unroll
-        for (int f = 0; f < kDynPs; ++f) ps[f] = st[f];
-        ps[kDynPs] = __longlong_as_double((long long)(gmask | (par == (int)(tick & 1u) ? kDynPsSkip : 0u)));
-    }
-    auto set_vmap = [&](int m, int a) { // the record and age of the current space, and their mirror in the row
-        c.dyn_vmap[e] = m;
-        c.dyn_age[e] = (uint8_t)a;
-        c.dyn_row[(size_t)e * kDynRow + kDynRowMeta] = __longlong_as_double((long long)dyn_meta_pack(m, (unsigned)a, 0u));
-    };
-    // is N slot s usable as episode q on record m?
-    auto n_usable = [&](int q, int m) -> bool {
-        const unsigned long long want = ((unsigned long long)d.bank_epoch << 32) | (unsigned)q;
-        return (q & 1) ? (nvalid1 == want && vmap1 == m) : (nvalid0 == want && vmap0 == m);
-    };
-    c.dyn_row[(size_t)e * kDynRow + kDynRowSelf] = 0.0; // (no DQ_WAKE entry survives the rebuild)
-    if (req & (DR_RESET | DR_ADOPTING)) {
-        // the env was auto-reset one (DR_RESET) or two (DR_ADOPTING) steps ago and its current space still holds the old episode:
-        // the ADOPT entry the step kernel queued is gone with the old queues.  From a usable N slot it is queued again — for
-        // the step it is due in —; without one (a new bank) the space is rebuilt from the record in step k's dyn step, and
-        // the step kernel reads it like any other (an env two steps past its reset cannot be helped: never seen, counted).
-        const bool ok = n_usable(episode, map_id);
-        if (ok) {
-            dyn_enqueue(c, (req & DR_RESET) ? tick + 1u : tick, e, (episode & 1) ? DQ_ADOPT1 : DQ_ADOPT0, dyn_bucket_of(1, map_id));
-        } else {
-            if (req & DR_ADOPTING) atomicAdd(c.dyn_err + 0, 1u);
-            set_vmap(map_id, 0);
-            c.dyn_req[e] = 0;
-            dyn_enqueue(c, tick, e, DQ_FRESH, dyn_bucket_of(0, map_id));
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+            const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+            tp[k][0] = t[0]; tp[k][1] = t[np]; tp[k][2] = t[2 * np];
         }
-    } else {
+        asm volatile("" : "+v"(map_id), "+v"(flag), "+v"(gm_raw), "+v"(live0), "+v"(hash0));
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pvx), "+v"(pvy), "+v"(pang), "+v"(pw));
+#pragma unroll
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]));
+        const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
         // rest bit still valid?  It was established for this bank generation; callers that write the body columns
         // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).  A cached arbiter that left with its goal
-        // was part of the fixed point: the bodies it touched are stepped again.
-        const bool rest = ((flag & 4u) != 0u) && (hash0 == (unsigned long long)d.bank_epoch) &&
-                          (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
-        set_vmap(map_id, age);
-        if (rest) c.dyn_flag[e] = (uint8_t)(flag & 12u);
-        else dyn_enqueue(c, tick, e, DQ_STEP, dyn_bucket_of(age, map_id));
-    }
-    // the next episode's space
-    if (c.flags & SSG_FLAG_AUTO_RESET) {
-        const int nm = next_map_of(c, map_id);
-        if (!n_usable(episode + 1, nm)) {
-            const int vn = (1 + ((episode + 1) & 1)) * c.n_pad + e;
-            c.dyn_row[(size_t)vn * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episode + 1) << 32)));
-            dyn_enqueue(c, tick, vn, DQ_NJOB, dyn_bucket_of(0, nm));
+        // was part of the fixed point: the bodies it touched are stepped again.  (An env the step kernel auto-reset — bit 1 —
+        // gets its bodies rebuilt by the full step.)
+        bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) &&
+                    (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
+        if (rest) {
+            // the player's position after its own cpBodyUpdatePosition; the exact test only if some ship is in reach
+            const double ppx = px + pvx * c.dt;
+            const double ppy = py + pvy * c.dt;
+            bool reach = false;
+#pragma unroll
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                // No vertex of either hull is further than its hull radius from its body position: beyond the sum the
+                // AABBs cannot meet, whatever the rotations (a conservative pre-reject of cpBBIntersects' exact one)
+                const double dx = tp[k][0] - ppx, dy = tp[k][1] - ppy;
+                reach |= (dx * dx + dy * dy) <= d.reach2[k];
+            }
+            col.flag[e] = 4u;     // at rest, traffic bit clear; dyn_sort_kernel sets it for the envs in reach that do touch
+            sat_only = reach;
         }
+        need_full = !rest;
+        bucket = dyn_bucket_of(age, map_id);
+        (void)pang; (void)pw;
+    }
+    // The queue is segmented by tiles of 64 envs (a wave of this kernel = one tile): no atomics to append.
+    const unsigned long long m = __ballot(need_full | sat_only);
+    const int lane = threadIdx.x & 63;
+    const int seg = e >> 6; // (n_pad is a multiple of 256: every wave of the grid owns a whole segment)
+    if (lane == 0 && (size_t)seg < (size_t)c.n_pad / 64) c.dyn_segcnt[seg] = (unsigned)__popcll(m);
+    if (need_full | sat_only) {
+        const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        unsigned long long key = kDynSatOnly;
+        if (need_full) // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
+            key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+        c.dyn_queue[slot] = e;
+        c.dyn_qkey[slot] = key;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dyn_sort_kernel: counting sort of the queue by bucket (the "SAT only" entries stay where they are: dyn_step_kernel's trailing
+// workgroups read them from the segments).  Every
+// workgroup scans the 512 bucket counters itself (2 KB from L2) and scatters its 256 queue entries to base[bucket] + arrival
+// number.  Buckets are map-major (dyn_bucket_of) and a map's eight buckets start on a multiple of kDynGrp slots: no wave of the
+// full step straddles two bank records.  The gaps are not written: the full step leaves -1 behind in every slot it read.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const DynCfg d)
+{
+    __shared__ unsigned base[kDynBuckets];
+    __shared__ unsigned wave_tot[4];
+    static_assert(kDynBuckets == 512, "two buckets per thread of a 256-thread workgroup");
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // this workgroup's four segments of the queue (segment = tile of 64 envs, entries [64*seg, 64*seg + count))
+    const unsigned i = blockIdx.x * 256u + (unsigned)t;
+    const unsigned seg = i >> 6;
+    const unsigned cnt = ((size_t)seg < (size_t)c.n_pad / 64) ? min(c.dyn_segcnt[seg], 64u) : 0u; // (clamped: garbage counters must not index past a segment)
+    const bool valid = (unsigned)lane < cnt;
+    const unsigned long long k = valid ? c.dyn_qkey[i] : 0ull;
+    const bool sat_only = valid & (k == kDynSatOnly);
+    const unsigned n_full = (unsigned)__popcll(__ballot(valid & !sat_only));
+    if (lane == 0) wave_tot[wv] = n_full;
+    __syncthreads();
+    const unsigned wsum = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (wsum == 0u) return; // no full step queued among this workgroup's 256 envs (workgroup-uniform)
+    __syncthreads();
+    const unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
+    static_assert(kDynAgeBuckets == 8, "four threads (two buckets each) per map");
+    // inside the map (threads 4m .. 4m+3): inclusive scan of the bucket counts, the map's total, its wave-rounded length
+    const unsigned two = c0 + c1;
+    unsigned in_map = two;
+    { const unsigned v = __shfl_up(in_map, 1); in_map += ((lane & 3) >= 1) ? v : 0u; }
+    { const unsigned v = __shfl_up(in_map, 2); in_map += ((lane & 3) >= 2) ? v : 0u; }
+    const unsigned n_map = __shfl(in_map, lane | 3);
+    const unsigned r_map = (n_map + (unsigned)(kDynGrp - 1)) / (unsigned)kDynGrp * (unsigned)kDynGrp;
+    // over the maps: inclusive scan of the rounded lengths (each map contributes once, at its last thread)
+    unsigned incl = ((lane & 3) == 3) ? r_map : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        incl += (lane >= o) ? v : 0u;
+    }
+    const unsigned maps_incl = __shfl(incl, lane | 3); // ... up to and including this thread's map
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned off = 0;
+    for (int w = 0; w < wv; ++w) off += wave_tot[w];
+    const unsigned excl = off + maps_incl - r_map + in_map - two; // the map's first slot + the buckets of the map before this thread's
+    base[2 * t] = excl;
+    base[2 * t + 1] = excl + c0;
+    __syncthreads();
+    // the queue's length including the gaps (zeroed by the step kernel; every workgroup that gets here stores the same number)
+    if (t == 0) c.dyn_count[0] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (valid & !sat_only) {
+        const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
+        if (dst < (unsigned)c.n_pad + (unsigned)kDynSortedPad) c.dyn_sorted[dst] = c.dyn_queue[i];
     }
 }
 
@@ -729,171 +780,78 @@ __host__ __device__ constexpr int dyn_lane_doubles(int n_goals, bool uni)
 }
 
 template <bool UNI>
-__global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
+__global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
-    constexpr int kWpg = UNI ? kUniWpg : 1; // waves per workgroup (see lds_all)
-    static_assert(dyn_lane_doubles(SSG_MAX_GOALS, true) * kGrp + kHullDoubles * (1 + SSG_N_TRAFFIC) + 2 * kBankDoubles == kWaveLds, "kWaveLds");
-    const int lane = threadIdx.x & 63;
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime(); // (development aid, see stamp())
-    const unsigned tick = c.dyn_tick, qi = tick & 1u;
-    unsigned *const qcount = c.dyn_count + (size_t)qi * kDynCountWords;
-    // The last workgroup to leave zeroes the queue's counters for its next use, two steps from now (every workgroup has read
-    // them by then: it takes its ticket after its last use of them).
-    auto leave = [&]() {
-        unsigned old = 0;
-        if (lane == 0) old = atomicAdd(qcount, 1u);
-        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        if (old == gridDim.x * (unsigned)kWpg - 1u) {
-            for (int i = lane; i < kDynBuckets; i += 64) qcount[kDynBucket0 + i * kDynBucketStride] = 0u;
-            if (lane == 0) qcount[0] = 0u;
+    const int lane = threadIdx.x;
+    // (clamped: a counter that was never initialised must not index past the queue; include/shipsim.h ssg_bind_state)
+    // The grid's tail — one workgroup per 64-env segment of the step kernel's queue — serves the "SAT only" entries: a resting
+    // env whose player comes within reach of a parked ship gets collide_ship's exact test and the traffic bit of its flag.
+    // These workgroups take the LDS slots the full step's waves leave free (or recycle them) and are long gone before the
+    // slowest of those finishes; inside dyn_sort_kernel the same test sat on the chain sort -> full step -> step kernel.
+    const unsigned n_step_blocks = ((unsigned)c.n_pad + (unsigned)kDynSortedPad) / (unsigned)kGrp;
+    if (blockIdx.x >= n_step_blocks) {
+        const unsigned seg = blockIdx.x - n_step_blocks;
+        const unsigned cnt = min(c.dyn_segcnt[seg], 64u);
+        if (cnt == 0u) return;
+        const bool sat = ((unsigned)lane < cnt) && c.dyn_qkey[seg * 64u + (unsigned)lane] == kDynSatOnly;
+        if (!__any(sat)) return;
+        stage_hulls(c, d, 0, lane);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (sat) {
+            const int e = c.dyn_queue[seg * 64u + (unsigned)lane];
+            if (e >= 0 && e < c.n_envs && resting_player_hit(c, e)) c.dyn_flag[e] = (uint8_t)(4u | 1u);
         }
-    };
-    // ---- which entry is mine?  Lane m reads map m's eight age buckets; the maps' stretches are laid out one after the other,
-    // each rounded up to a whole wave. ----
-    static_assert(kDynMapBuckets == 64 && kDynAgeBuckets == 8, "one lane per map of the bucket table");
-    unsigned cnt[kDynAgeBuckets];
-#pragma unroll
-    for (int j = 0; j < kDynAgeBuckets; ++j) cnt[j] = min(qcount[kDynBucket0 + (lane * kDynAgeBuckets + j) * kDynBucketStride], (unsigned)c.dyn_np);
-    unsigned n_map = 0;
-#pragma unroll
-    for (int j = 0; j < kDynAgeBuckets; ++j) n_map += cnt[j];
-    const unsigned long long t_cnt = __builtin_amdgcn_s_memtime(); // (development aid)
-    const unsigned r_map = (n_map + (unsigned)(kGrp - 1)) / (unsigned)kGrp * (unsigned)kGrp;
-    unsigned incl = r_map;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned vsh = __shfl_up(incl, o);
-        incl += (lane >= o) ? vsh : 0u;
+        return;
     }
-    // One workgroup per wave of the queue (the grid covers the worst case — every space queued —; the workgroups past the
-    // queue's end leave here).  (kPersistent, measured and not kept: a resident set of 2 x CUs workgroups walking the queue with
-    // the grid's stride — the loop-carried counters cost the kernel 47 spilled VGPRs, 74 -> 80 us, and the step kernel beside
-    // it gained nothing.)
-    constexpr bool kPersistent = false;
-    const unsigned q_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned wslot = blockIdx.x * (unsigned)kWpg + (threadIdx.x >> 6);
-    do {
-    if (!(wslot * (unsigned)kGrp < q_total)) break;
-    const unsigned s0 = wslot * (unsigned)kGrp;
-    const unsigned long long mine = __ballot((incl - r_map <= s0) & (s0 < incl));
-    if (mine == 0ull) break; // (cannot happen below q_total)
-    const int wm = __ffsll((long long)mine) - 1; // this wave's map bucket (wave-uniform)
-    const unsigned o_in_map = s0 - (unsigned)__builtin_amdgcn_readlane((int)(incl - r_map), wm) + (unsigned)lane;
-    unsigned entry = 0u;
-    bool queued = false;
-    {
-        unsigned before = 0u;
-#pragma unroll
-        for (int j = 0; j < kDynAgeBuckets; ++j) {
-            const unsigned cj = (unsigned)__builtin_amdgcn_readlane((int)cnt[j], wm);
-            const bool here = (lane < kGrp) & (o_in_map >= before) & (o_in_map < before + cj);
-            if (here) {
-                entry = (unsigned)c.dyn_region[((size_t)qi * kDynBuckets + (size_t)(wm * kDynAgeBuckets + j)) * (size_t)c.dyn_np + (o_in_map - before)];
-                queued = true;
-            }
-            before += cj;
-        }
-    }
-    const unsigned etype = (entry >> 27) & 7u;
-    const unsigned long long t_ent = __builtin_amdgcn_s_memtime(); // (development aid)
-    queued = queued && (int)(entry & kDynVMask) < c.dyn_np;
-    const int v = queued ? (int)(entry & kDynVMask) : 0;          // the space this lane steps (writes)
-    const int e = v % c.n_pad;                                    // its env
-    // an ADOPT entry steps FROM the env's N slot INTO its current space (the env was auto-reset: shipsim_kernels.hip, role 3)
-    const bool adopt_e = (etype == DQ_ADOPT0) | (etype == DQ_ADOPT1);
-    const int nslot = adopt_e ? (int)(etype - DQ_ADOPT0) : (v >= c.n_pad ? v / c.n_pad - 1 : 0);
-    const int vin = adopt_e ? (1 + nslot) * c.n_pad + e : v;      // the space this lane reads
+    // The queue's length is not read: every slot the sort did not write holds -1 (a gap in front of the next map's stretch, or
+    // past the end: this kernel leaves -1 behind in what it read, ssg_step memsets the array whenever the host rebuilt the
+    // queue) — one memory round trip less at the head of every wave's chain.
+    const unsigned slot = (unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane;
+    const bool in_queue = lane < kGrp;
+    const int e_raw = in_queue ? c.dyn_sorted[slot] : -1;
+    const bool queued = (e_raw >= 0) & (e_raw < c.n_envs);
+    if (!__any(queued) && blockIdx.x != 0) return; // wave-uniform: nothing queued for this workgroup
+    if (queued) c.dyn_sorted[slot] = -1;           // the next sort writes entries only
+    const int e = queued ? e_raw : 0;
+    if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
+        for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
     const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
     const int cbase = kGrp * lane_doubles;
     const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
-    DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.dyn_np};
-    const size_t np = col.np;               // stride of the dyn columns (vspaces)
-    const size_t enp = (size_t)c.n_pad;     // stride of the per-env tables
-    // Everything the step reads from memory about this space is requested NOW, in one go, from SIX cache lines of the lane: the
-    // space's row (body fields, live-arbiter mask, record / age / generation, an N job's order) and the env's player-state
-    // record.  (Requested where they were used — and from a table each — these were five more dependent round trips of
-    // 48 scattered lines at the head of every wave's chain: 12 k cycles.)
-    unsigned gen_now = c.dyn_gen[v];
-    unsigned long long nvalid_in = c.dyn_nvalid[(size_t)nslot * enp + e];
-    double rw[kDynRow], ps[kDynPsRow];
-    {
-        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)vin * kDynRow);
-#pragma unroll
-        for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
-        const double2 *ps2 = reinterpret_cast<const double2 *>(c.dyn_ps + ((size_t)qi * enp + e) * kDynPsRow);
-#pragma unroll
-        for (int i = 0; i < kDynPsRow / 2; ++i) { const double2 rv = ps2[i]; ps[2 * i] = rv.x; ps[2 * i + 1] = rv.y; }
-    }
     stage_hulls(c, d, cbase, lane);
-    if (UNI) { // banks of at most 64 records: the bucket's map index IS the record (all lanes of the wave sit on it)
-        const double *rec_u = c.bank + (size_t)wm * SSG_MAP_STRIDE;
+    DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
+    const size_t np = col.np;
+    int map_id = queued ? c.i32cols[(size_t)ICOL_MAP * np + e] : 0;
+    if (UNI) {
+        const unsigned long long qm = __ballot(queued);
+        if (qm == 0ull) return;
+        map_id = __builtin_amdgcn_readlane(map_id, __ffsll((long long)qm) - 1);
+        const double *rec_u = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
         for (int q = lane; q < 2 * kBankDoubles; q += 64) {
             const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
             lds[sbank + q] = rec_u[SSG_MAP_OFF_PLANES + sd * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
         }
     }
-#pragma unroll
-    for (int f = 0; f < kDynPsRow; ++f) asm volatile("" : "+v"(ps[f]));
-#pragma unroll
-    for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
-    const unsigned long long live_in = (unsigned long long)__double_as_longlong(rw[kDynRowLive]);
-    const unsigned long long meta_in = (unsigned long long)__double_as_longlong(rw[kDynRowMeta]);
-    const unsigned long long order_in = (unsigned long long)__double_as_longlong(rw[kDynRowOrder]);
-    const unsigned pgm_in = (unsigned)__double_as_longlong(ps[kDynPs]);
-    asm volatile("" : "+v"(gen_now), "+v"(nvalid_in));
-    const int vmap_in = (int)(unsigned)meta_in, age_in0 = (int)((meta_in >> 32) & 255ull);
-    const int nmap_in = (int)(unsigned)order_in, ntag_in = (int)(unsigned)(order_in >> 32);
-    // (an entry of a space the env has left is stale; a space the step kernel woke that had queued itself has its own entry)
-    queued = queued && (gen_now & 3u) == (entry >> 30) &&
-             !(etype == DQ_WAKE && (unsigned)__double_as_longlong(rw[kDynRowSelf]) == tick);
-    const bool is_n = queued & (etype == DQ_NJOB);      // a coming episode's space: nothing of the player is read
-    const bool fresh = queued & ((etype == DQ_FRESH) | (etype == DQ_NJOB)); // rebuilt from the record: nothing of the space's old state is read
-    const bool adopting = queued & adopt_e;             // reads the N slot, writes every field of the current space
-    if (adopting && !(nvalid_in == (((unsigned long long)d.bank_epoch << 32) | (unsigned)ntag_in) && nmap_in == vmap_in))
-        atomicAdd(c.dyn_err + 0, 1u); // (the slot's N job has not run on this bank: cannot happen — the job is ordered an episode ahead)
-    const int map_id = UNI ? wm : (is_n ? nmap_in : vmap_in);
-    // The slot of the NEXT step's queue this space takes if this step changes anything: reserved now — at the end it would be one
-    // more dependent round trip on every wave's chain — one atomic per distinct bucket of the wave (its lanes sit on one
-    // record and on one or two ages); a space that comes to rest leaves a null entry in its slot.
-    const int age_next = (fresh ? 0 : age_in0) < 255 ? (fresh ? 0 : age_in0) + 1 : 255;
-    const unsigned bnext = dyn_bucket_of(age_next, map_id);
-    unsigned slot_base = 0u;  // (in the leader lane of my bucket: the atomic's result is not waited for here, see the write-back)
-    int slot_leader = 0, slot_rank = 0;
-    {
-        unsigned long long todo = __ballot(queued & !is_n);
-        while (todo) {
-            const int ld = __ffsll((long long)todo) - 1;
-            const unsigned bb = (unsigned)__builtin_amdgcn_readlane((int)bnext, ld);
-            const unsigned long long same = __ballot(queued & !is_n & (bnext == bb)) & todo;
-            if (lane == ld) slot_base = atomicAdd(c.dyn_count + (size_t)(qi ^ 1u) * kDynCountWords + kDynBucket0 + bb * kDynBucketStride, (unsigned)__popcll(same));
-            if ((same >> lane) & 1ull) { slot_leader = ld; slot_rank = __popcll(same & ((1ull << lane) - 1ull)); }
-            todo &= ~same;
-        }
-    }
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave per workgroup: the LDS writes above are visible to its lanes
     __builtin_amdgcn_wave_barrier();
-    if (!__any(queued)) continue;
-    {   // (development aid: how full are the waves?)
-        const unsigned long long qb = __ballot(queued);
-        if (d.stop_after == -1 && lane == 0) { atomicAdd(c.dyn_err + 2, (unsigned)__popcll(qb)); atomicAdd(c.dyn_err + 3, 1u); }
-    }
-    if (queued) {
+    if (!queued) return;
     const double dt = c.dt;
     const int ng = c.n_goals;
     const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
     // development aid (SSG_DYN_STOP=-1): phase stamps of this lane's wave into the unused arbiter rows of pair 50..53
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     auto stamp = [&](int i) {
         if (d.stop_after == -1)
-            col.f64[(size_t)(DC_ARB + 4 * 50 + i) * np + v] = (double)(__builtin_amdgcn_s_memtime() - t_start);
+            col.f64[(size_t)(DC_ARB + 4 * 50 + i) * np + e] = (double)(__builtin_amdgcn_s_memtime() - t_start);
     };
-    stamp(0);
-    if (d.stop_after == -1) {
-        col.f64[(size_t)(DC_ARB + 4 * 53 + 0) * np + v] = (double)(t_cnt - t_start);
-        col.f64[(size_t)(DC_ARB + 4 * 53 + 1) * np + v] = (double)(t_ent - t_start);
-    }
-    // goals still in the space for this cpSpaceStep, and the cached arbiters that survive (set below, once the row is in)
-    unsigned gmask = (1u << ng) - 1u;
-    unsigned long long live = 0ull, live0 = 0ull;
+    const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
+    // bit 1 of the flag: the step kernel auto-reset this env at the end of the last step — a fresh pm.Space(): its bodies are
+    // rebuilt here (ShipGame.reset + add_default_traffic), nothing of the old episode is read
+    const bool fresh = (col.flag[e] & 2u) != 0u;
+    // deferred space.remove of the goals the player reached last step (game.py:252): their cached arbiters go with them
+    unsigned long long live = fresh ? 0ull : drop_removed_goal_arbiters(col.live[e], gmask, ng);
+    const unsigned long long live0 = live;
     // Did this step write back anything but the bits it read?  The body columns are compared directly: what was read stays
     // in registers until the write-back (this kernel runs one wave per SIMD, 512 VGPRs to spare; hashing both sides cost
     // ~150 64-bit multiplies per step).  The arbiters' accumulated impulses, touched for a few pairs only, go through
@@ -919,9 +877,17 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
 
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
     // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
+    // (the player's six columns are requested with everything else: its pose after its own cpBodyUpdatePosition)
+    const ShipShape pl = player_shape(c, e, cbase);
     double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
     {
+        // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
+        // gathers over 75 x 64 lines per wave (the sorted queue scatters a wave's envs over the whole batch)
         static_assert(DC_GOAL_COLS * SSG_MAX_GOALS == kDynRowTraffic && kDynRowTraffic + 9 * SSG_N_TRAFFIC <= kDynRow && kDynRow % 2 == 0, "row layout");
+        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)e * kDynRow);
+        double rw[kDynRow];
+#pragma unroll
+        for (int i = 0; i < kDynRow / 2; ++i) { const double2 v = row2[i]; rw[2 * i] = v.x; rw[2 * i + 1] = v.y; }
 #pragma unroll
         for (int g = 0; g < SSG_MAX_GOALS; ++g)
 #pragma unroll
@@ -948,60 +914,6 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
             }
         }
     }
-    if (!fresh) {
-        // Deferred space.remove (game.py:252) of the goals the player reached in the API step before this one.  The step kernel
-        // of that step may still be running: collide_goal (game.py:243-257) is re-evaluated here from what decides it — the
-        // player state the step before THAT left behind (dyn_ps: its cpBodyUpdatePosition is pose = p + v dt, a + w dt whatever
-        // the action), the goal mask of that moment, and the goal centres this space holds (= where they were after the last
-        // cpSpaceStep).  Same expressions as the step kernel's body role: ship_world(), the box reject, cpPolyShapePointQuery.
-        const unsigned pgm = pgm_in;
-        unsigned gm = pgm & ((1u << ng) - 1u);
-        if (!(pgm & kDynPsSkip)) {
-            const double px = ps[0] + ps[2] * dt, py = ps[1] + ps[3] * dt, pa = ps[4] + ps[5] * dt;
-            double psa, pca;
-            sincos_body(pa, &psa, &pca);
-            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], snx[SSG_SHIP_VERTS], sny[SSG_SHIP_VERTS];
-            double sbl = INFINITY, sbr = -INFINITY, sbb = INFINITY, sbt = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-                const double hx = lds[cbase + 2 * i], hy = lds[cbase + 2 * i + 1];
-                const double nx = lds[cbase + 2 * SSG_SHIP_VERTS + 2 * i], ny = lds[cbase + 2 * SSG_SHIP_VERTS + 2 * i + 1];
-                swx[i] = pca * hx + (-psa) * hy + px;
-                swy[i] = psa * hx + pca * hy + py;
-                snx[i] = pca * nx + (-psa) * ny;
-                sny[i] = psa * nx + pca * ny;
-                sbl = __builtin_fmin(sbl, swx[i]); sbr = __builtin_fmax(sbr, swx[i]);
-                sbb = __builtin_fmin(sbb, swy[i]); sbt = __builtin_fmax(sbt, swy[i]);
-            }
-            const double r = c.goal_r;
-#pragma unroll
-            for (int g = 0; g < SSG_MAX_GOALS; ++g) {
-                if (g >= ng) continue;
-                const double gx = gin[g][0], gy = gin[g][1];
-                const bool near = (bool)((gm >> g) & 1u) & ((gx - r) <= sbr) & (sbl <= (gx + r)) & ((gy - r) <= sbt) & (sbb <= (gy + r));
-                if (near) {
-                    double md = INFINITY;
-                    bool outside = false;
-#pragma unroll
-                    for (int i = 0; i < SSG_SHIP_VERTS; ++i) { // edge from vertex i-1 to vertex i
-                        const int ip = (i == 0) ? SSG_SHIP_VERTS - 1 : i - 1;
-                        const double v1x = swx[i], v1y = swy[i], v0x = swx[ip], v0y = swy[ip];
-                        outside |= (snx[i] * (gx - v1x) + sny[i] * (gy - v1y)) > 0.0;
-                        const double dx = v0x - v1x, dy = v0y - v1y; // cpClosetPointOnSegment(p, v0, v1)
-                        const double tt = __builtin_fmax(0.0, __builtin_fmin((dx * (gx - v1x) + dy * (gy - v1y)) / (dx * dx + dy * dy), 1.0));
-                        const double qx = v1x + dx * tt, qy = v1y + dy * tt;
-                        const double ex_ = gx - qx, ey_ = gy - qy;
-                        md = __builtin_fmin(md, sqrt(ex_ * ex_ + ey_ * ey_));
-                    }
-                    const double sd = outside ? md : -md;
-                    if (sd <= r) gm &= ~(1u << g);
-                }
-            }
-        }
-        gmask = gm;
-        live = drop_removed_goal_arbiters(live_in, gmask, ng);
-    }
-    live0 = live;
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
         if (g >= ng) continue;
@@ -1092,7 +1004,14 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
     };
     auto goal_shape = [&](int g) -> CircleShape { CircleShape s; s.c = mk(BF(g, B_PX), BF(g, B_PY)); s.rad = c.goal_r; return s; };
 
+    stamp(0);
+    if (d.stop_after == 1) return;
+    // the player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel) against traffic
+    bool hit = false;
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) hit |= ships_touch(pl, ship_shape(k)); // collide_ship: type 0 x type 1
+
     stamp(1);
+    if (d.stop_after == 2) return;
     prof_last = __builtin_amdgcn_s_memtime();
     // ---- (3) collide, canonical order ---------------------------------------------------------------------------
     double ovf[(kMaxActive - kLdsArb) * A_STRIDE]; // records beyond the LDS ones: scratch, touched only when used
@@ -1113,14 +1032,14 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
         unsigned old_hash[2] = {0u, 0u};
         double old_jn[2] = {0.0, 0.0}, old_jt[2] = {0.0, 0.0};
         if ((live >> pid) & 1ull) {
-            const unsigned meta = col.u32[(size_t)(DU_META + pid) * np + vin];
+            const unsigned meta = col.u32[(size_t)(DU_META + pid) * np + e];
             state = meta & 7u;
             old_count = (meta >> 5) & 3u;
             if (pid < kPolyPairs) {
-                const unsigned hh = col.u32[(size_t)(DU_HASH + pid) * np + vin];
+                const unsigned hh = col.u32[(size_t)(DU_HASH + pid) * np + e];
                 old_hash[0] = hh & 0xFFFFu; old_hash[1] = hh >> 16;
             }
-            const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + vin;
+            const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
             old_jn[0] = acc[0 * np]; old_jn[1] = acc[1 * np]; old_jt[0] = acc[2 * np]; old_jt[1] = acc[3 * np];
             ain ^= arb_hash(pid, meta & ~0x18u, (pid < kPolyPairs) ? (old_hash[0] | old_hash[1] << 16) : 0u, old_jn[0], old_jn[1],
                             old_jt[0], old_jt[1]); // (age bits are 0 for an arbiter touched every step; a cached one changes anyway)
@@ -1271,18 +1190,19 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
     SSG_TICK(emem, 0);
 #ifdef SSG_DYN_PROFILE
     if (d.stop_after == -1)
-        for (int i = 0; i < 6; ++i) col.f64[(size_t)(DC_ARB + 4 * 45 + i) * np + v] = (double)prof_acc[i]; // unused arbiter rows of pairs 45, 46
+        for (int i = 0; i < 6; ++i) col.f64[(size_t)(DC_ARB + 4 * 45 + i) * np + e] = (double)prof_acc[i]; // unused arbiter rows of pairs 45, 46
     if (d.stop_after == -1)
-        for (int i = 0; i < 5; ++i) col.f64[(size_t)(DC_ARB + 4 * 47 + i) * np + v] = (double)type_acc[i]; // ... and of pairs 47, 48
+        for (int i = 0; i < 5; ++i) col.f64[(size_t)(DC_ARB + 4 * 47 + i) * np + e] = (double)type_acc[i]; // ... and of pairs 47, 48
 #endif
     stamp(2);
+    if (d.stop_after == 3) return;
     // ---- cpSpaceArbiterSetFilter for the cached arbiters that were not touched this step -------------------------
     {
         unsigned long long rest = live & ~touched;
         while (rest) {
             const int pid = __ffsll((long long)rest) - 1;
             rest &= rest - 1ull;
-            unsigned meta = col.u32[(size_t)(DU_META + pid) * np + vin];
+            unsigned meta = col.u32[(size_t)(DU_META + pid) * np + e];
             unsigned age = (meta >> 3) & 3u;
             age += 1u; // ticks >= 1: the arbiter is (now) "cached"
             changed = true; // an ageing arbiter is a state change by itself
@@ -1290,11 +1210,7 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
                 live &= ~(1ull << pid);
             } else {
                 meta = (meta & ~0x1Fu) | (unsigned)ST_CACHED | (age << 3);
-                col.u32[(size_t)(DU_META + pid) * np + v] = meta;
-                if (adopting) { // the record moves from the N slot to the current space with the rest
-                    if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + v] = col.u32[(size_t)(DU_HASH + pid) * np + vin];
-                    for (int f = 0; f < 4; ++f) col.f64[(size_t)(DC_ARB + 4 * pid + f) * np + v] = col.f64[(size_t)(DC_ARB + 4 * pid + f) * np + vin];
-                }
+                col.u32[(size_t)(DU_META + pid) * np + e] = meta;
             }
         }
     }
@@ -1332,6 +1248,7 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
         }
     }
     stamp(3);
+    if (d.stop_after == 4) return;
     // ---- (4) cpBodyUpdateVelocity (no forces on these bodies) -------------------------------------------------------
     for (int s = 0; s < slot_static; ++s) {
         if (s < ng && !((gmask >> s) & 1u)) continue; // goal no longer in the space
@@ -1504,6 +1421,7 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
     }
 
     stamp(4);
+    if (d.stop_after == 5) return;
     // ---- write back, hashing what is written --------------------------------------------------------------------------
     for (int i = 0; i < n_act; ++i) {
         const ArbRef A = arb(i);
@@ -1516,114 +1434,63 @@ __global__ __launch_bounds__(UNI ? 64 * kUniWpg : 64) void dyn_step_kernel(const
         const double j0 = A.cget(0, AC_JN), j1 = count > 1 ? A.cget(1, AC_JN) : 0.0;
         const double t0 = A.cget(0, AC_JT), t1 = count > 1 ? A.cget(1, AC_JT) : 0.0;
         aout ^= arb_hash(pid, meta, hh, j0, j1, t0, t1);
-        col.u32[(size_t)(DU_META + pid) * np + v] = meta;
-        if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + v] = hh;
-        double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + v;
+        col.u32[(size_t)(DU_META + pid) * np + e] = meta;
+        if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + e] = hh;
+        double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
         acc[0 * np] = j0; acc[1 * np] = j1; acc[2 * np] = t0; acc[3 * np] = t1;
     }
     auto differs = [](double a, double b) -> bool { return __double_as_longlong(a) != __double_as_longlong(b); };
-    // what the step kernel reads of this env's other bodies, in this step's parity (an N space has no reader yet: the adopt
-    // pass publishes it); a rebuilt space publishes both parities (it may come to rest at once, and nobody rewrites a resting
-    // space's table)
-    // (an N job publishes to its slot's plane: what the step kernel reads in the step after the env's auto-reset)
-    double *const obs_p = c.dyn_obs + (size_t)(is_n ? 2u + (unsigned)nslot : qi) * kDynObs * enp + e, *const obs_q = c.dyn_obs + (size_t)(qi ^ 1u) * kDynObs * enp + e;
-    const bool both = (fresh | adopting) & !is_n; // nobody rewrites a resting space's planes: a rebuilt / adopted one fills both
 #pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + v;
+        double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
         const int s = slot_ship0 + k;
-        const double val[9] = {BF(s, B_PX), BF(s, B_PY), L(xbase + X_STRIDE * k + X_A), BF(s, B_VX), BF(s, B_VY), BF(s, B_W),
-                               BF(s, B_VBX), BF(s, B_VBY), BF(s, B_WB)};
-        const double rca = L(xbase + X_STRIDE * k + X_CA), rsa = L(xbase + X_STRIDE * k + X_SA);
+        const double v[9] = {BF(s, B_PX), BF(s, B_PY), L(xbase + X_STRIDE * k + X_A), BF(s, B_VX), BF(s, B_VY), BF(s, B_W),
+                             BF(s, B_VBX), BF(s, B_VBY), BF(s, B_WB)};
         // (columns and row hold what was loaded: only the fields this step changed are stored — in the post-reset transient
         // that is ship 1 and whatever it shoves, not the 75 fields of the env)
-        double *row = c.dyn_row + (size_t)v * kDynRow + kDynRowTraffic + 9 * k;
+        double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
         // (one branch per BODY, not per field: a body either moved — nearly all of its fields differ — or it did not)
         bool dfb = false;
 #pragma unroll
-        for (int f = 0; f < 9; ++f) dfb |= differs(val[f], tin[k][f]);
-        if (dfb | fresh | adopting) {
+        for (int f = 0; f < 9; ++f) dfb |= differs(v[f], tin[k][f]);
+        if (dfb | fresh) {
 #pragma unroll
-            for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = val[f]; row[f] = val[f]; }
-            col.f64[(size_t)(DC_TROT + 2 * k) * np + v] = rca; // the rotation of the angle column, for collide_ship in the step kernel
-            col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + v] = rsa;
-        }
-        {
-            obs_p[(size_t)(kDynObsTraffic + 4 * k) * enp] = val[0]; obs_p[(size_t)(kDynObsTraffic + 4 * k + 1) * enp] = val[1];
-            obs_p[(size_t)(kDynObsTraffic + 4 * k + 2) * enp] = rca; obs_p[(size_t)(kDynObsTraffic + 4 * k + 3) * enp] = rsa;
-            if (both) {
-                obs_q[(size_t)(kDynObsTraffic + 4 * k) * enp] = val[0]; obs_q[(size_t)(kDynObsTraffic + 4 * k + 1) * enp] = val[1];
-                obs_q[(size_t)(kDynObsTraffic + 4 * k + 2) * enp] = rca; obs_q[(size_t)(kDynObsTraffic + 4 * k + 3) * enp] = rsa;
-            }
+            for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; row[f] = v[f]; }
         }
         changed |= dfb;
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
         if (g >= ng || !((gmask >> g) & 1u)) continue;
-        double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + v;
-        const double val[DC_GOAL_COLS] = {BF(g, B_PX), BF(g, B_PY), BF(g, B_VX), BF(g, B_VY), BF(g, B_VBX), BF(g, B_VBY),
-                                          BF(g, B_W), BF(g, B_WB)};
-        double *row = c.dyn_row + (size_t)v * kDynRow + DC_GOAL_COLS * g;
+        double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
+        const double v[DC_GOAL_COLS] = {BF(g, B_PX), BF(g, B_PY), BF(g, B_VX), BF(g, B_VY), BF(g, B_VBX), BF(g, B_VBY),
+                                        BF(g, B_W), BF(g, B_WB)};
+        double *row = c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g;
         bool dfb = false;
 #pragma unroll
-        for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= differs(val[f], gin[g][f]);
-        if (dfb | fresh | adopting) {
+        for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= differs(v[f], gin[g][f]);
+        if (dfb | fresh) {
 #pragma unroll
-            for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = val[f]; row[f] = val[f]; }
-        }
-        {
-            obs_p[(size_t)(kDynObsGoals + 2 * g) * enp] = val[0]; obs_p[(size_t)(kDynObsGoals + 2 * g + 1) * enp] = val[1];
-            if (both) { obs_q[(size_t)(kDynObsGoals + 2 * g) * enp] = val[0]; obs_q[(size_t)(kDynObsGoals + 2 * g + 1) * enp] = val[1]; }
+            for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; row[f] = v[f]; }
         }
         changed |= dfb;
     }
     changed |= (live != live0) | (ain != aout);
     stamp(5);
     if (d.stop_after == -1) {
-        col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + v] = (double)n_act;
-        col.f64[(size_t)(DC_ARB + 4 * 50 + 7) * np + v] = (double)dbg_cnt[0];
-        col.f64[(size_t)(DC_ARB + 4 * 50 + 8) * np + v] = (double)dbg_cnt[1];
-        col.f64[(size_t)(DC_ARB + 4 * 50 + 9) * np + v] = (double)dbg_cnt[2];
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + e] = (double)n_act;
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 7) * np + e] = (double)dbg_cnt[0];
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 8) * np + e] = (double)dbg_cnt[1];
+        col.f64[(size_t)(DC_ARB + 4 * 50 + 9) * np + e] = (double)dbg_cnt[2];
     }
-    const unsigned slot_next = (unsigned)__shfl((int)slot_base, slot_leader) + (unsigned)slot_rank; // the slot reserved at the head
-    col.live[v] = live;
-    c.dyn_hash[v] = (unsigned long long)d.bank_epoch; // the bank generation this (possible) rest state belongs to
-    // unchanged = a fixed point of cpSpaceStep: at rest (bit 2); bit 3: ... with cached arbiters on goals (pair ids 9 ..): the one
-    // kind of resting space the player can disturb, by removing such a goal (the step kernel wakes it, shipsim_kernels.hip)
-    col.flag[v] = (uint8_t)(changed ? 0u : (4u | ((live >> 9) ? 8u : 0u)));
-    c.dyn_age[v] = (uint8_t)age_next;
-    {   // the row's mirrors of the live mask and of record / age; the step this space has queued itself for
-        double2 m;
-        m.x = __longlong_as_double((long long)dyn_meta_pack(map_id, (unsigned)age_next, 0u));
-        m.y = rw[kDynRowOrder];
-        c.dyn_row[(size_t)v * kDynRow + kDynRowLive] = __longlong_as_double((long long)live);
-        *reinterpret_cast<double2 *>(c.dyn_row + (size_t)v * kDynRow + kDynRowMeta) = m;
-        if (!is_n) c.dyn_row[(size_t)v * kDynRow + kDynRowSelf] = __longlong_as_double((long long)(changed ? tick + 1u : 0u));
-    }
-    if (fresh | adopting) c.dyn_vmap[v] = map_id;
-    if (is_n) {
-        // the coming episode's space has had its first step: it waits for the env to get there
-        c.dyn_nvalid[(size_t)nslot * enp + e] = ((unsigned long long)d.bank_epoch << 32) | (unsigned)ntag_in;
-    } else {
-        // the slot reserved at the head: stepped again next step if anything changed, a null entry otherwise
-        const unsigned ent = changed ? dyn_entry((unsigned)v, DQ_STEP, gen_now) : kDynNullEntry;
-        if (slot_next < (unsigned)c.dyn_np) c.dyn_region[((size_t)(qi ^ 1u) * kDynBuckets + bnext) * (size_t)c.dyn_np + slot_next] = (int32_t)ent;
-        else atomicAdd(c.dyn_err + 1, 1u);
-    }
-    } // queued
-    if (kPersistent) {
-        __builtin_amdgcn_s_waitcnt(0xC07F); // (the next wave of work reuses the LDS columns)
-        __builtin_amdgcn_wave_barrier();
-    }
-    } while (kPersistent && ((wslot += gridDim.x * (unsigned)kWpg), true));
-    leave();
+    col.live[e] = live;
+    c.dyn_hash[e] = (unsigned long long)d.bank_epoch; // the bank generation this (possible) rest state belongs to
+    col.flag[e] = (uint8_t)((hit ? 1u : 0u) | (changed ? 0u : 4u)); // unchanged = a fixed point of cpSpaceStep: at rest
 }
 
 size_t dyn_lds_bytes(int n_goals, bool uni)
 {
-    if (uni) return (size_t)kUniWpg * kWaveLds * sizeof(double); // kUniWpg waves per workgroup, each with the region of a six-goal space
-    return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC)) * sizeof(double);
+    return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) + (uni ? 2 * kBankDoubles : 0)) * sizeof(double);
 }
 
 // Raise the dynamic-LDS cap of the full-step kernel (once per handle, like prepare_step).
@@ -1637,55 +1504,37 @@ hipError_t prepare_dyn(const DevCfg &c)
                                160 * 1024);
 }
 
-hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream)
+hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream)
 {
-    // the full step over the queue of step c.dyn_tick (grid sized for the worst case: every space queued and every map's stretch
-    // rounded up to a wave; workgroups past the queue's end leave at once)
-    static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid (-1: phase stamps)
+    // (the classify pass over every env only when the host touched the envs,) the sort, then the full step over the sorted
+    // queue (grid sized for the worst case: every env queued and every map's stretch rounded up to a wave; workgroups past the
+    // queue's end leave at once).  The step kernel that follows empties the queue counter.
+    static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
     dd.stop_after = stop_after;
-    // one bank record per wave: the buckets tell records apart only when the bank holds at most kDynMapBuckets of them
+    if (classify)
+        hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_pad + kClassifyThreads - 1) / kClassifyThreads)),
+                           dim3(kClassifyThreads), 0, stream, c, dd);
+    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)(c.n_pad / 256)), dim3(256), 0, stream, c, dd);
+    // one bank record per wave: the sort's buckets tell records apart only when the bank holds at most kDynMapBuckets of them
     // (a per-env ring of worlds never does)
     const bool uni = c.map_ring == 0 && c.n_maps <= kDynMapBuckets;
-    // the resident set: two workgroups (76 KB of LDS each, one wave alone on its SIMD) per CU; each walks the queue with the grid's stride
-    static const unsigned n_cu = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(cu > 0 ? cu : 256); }();
-    const unsigned worst = (unsigned)((c.dyn_np + kDynSortedPad + kGrp - 1) / kGrp);
-    if (uni) { // two waves per CU
-        const unsigned wg = (worst + (unsigned)kUniWpg - 1u) / (unsigned)kUniWpg;
-        hipLaunchKernelGGL(dyn_step_kernel<true>, dim3(wg), dim3(64 * kUniWpg), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
-    } else {
-        hipLaunchKernelGGL(dyn_step_kernel<false>, dim3(worst), dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
-    }
-    (void)n_cu;
+    const dim3 grid((unsigned)((c.n_pad + kDynSortedPad) / kGrp + c.n_pad / 64)); // the full step's waves, then the SAT-only segments
+    if (uni) hipLaunchKernelGGL(dyn_step_kernel<true>, grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
+    else hipLaunchKernelGGL(dyn_step_kernel<false>, grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
     return hipGetLastError();
 }
 
-hipError_t launch_dyn_classify(const DevCfg &c, const DynCfg &d, hipStream_t stream)
-{
-    hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_envs + kClassifyThreads - 1) / kClassifyThreads)), dim3(kClassifyThreads), 0,
-                       stream, c, d);
-    return hipGetLastError();
-}
-
-// ssg_dyn_invalidate: the caller wrote state columns of the masked envs.
 __global__ void dyn_invalidate_kernel(const DevCfg c, const uint8_t *__restrict__ mask)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs || (mask && !mask[e])) return;
-    c.dyn_flag[e] &= (uint8_t)~12u;
-    // bring what shadows the body columns up to date: the row the full step loads from, the rotations of the angle columns,
-    // the step kernel's table
-    const size_t np = (size_t)c.dyn_np;
+    c.dyn_flag[e] &= (uint8_t)~4u;
+    // the caller wrote the body columns: bring the row-major shadow the full step loads from up to date
+    const size_t np = (size_t)c.n_pad;
     double *row = c.dyn_row + (size_t)e * kDynRow;
     for (int i = 0; i < DC_GOAL_COLS * SSG_MAX_GOALS; ++i) row[i] = c.dyn_f64[(size_t)(DC_GOALS + i) * np + e];
     for (int i = 0; i < 9 * SSG_N_TRAFFIC; ++i) row[kDynRowTraffic + i] = c.dyn_f64[(size_t)(DC_TRAFFIC + i) * np + e];
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        double sa, ca;
-        sincos_body(c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * k + 2) * np + e], &sa, &ca);
-        c.dyn_f64[(size_t)(DC_TROT + 2 * k) * np + e] = ca;
-        c.dyn_f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = sa;
-    }
-    dyn_publish_obs(c, e, e);
 }
 
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream)

@@ -26,59 +26,25 @@ enum {
     kDynPairs = 54,                                   // ship-bank 6, ship-ship 3, goal-bank 12, goal-ship 18, goal-goal 15
     kPolyPairs = 9,                                   // the first 9 pair ids are polygon pairs (two hashed contacts)
     DC_PREV_GOAL = DC_ARB + 4 * kDynPairs,            // (gx, gy) of the newest frame: the next observation's older frame
-    DC_TROT = DC_PREV_GOAL + 2,                       // 3 ships x (cos a, sin a) of the angle column: the step kernel's collide_ship
-                                                      // against traffic rebuilds the ship's world hull without a sincos
-    DC_COUNT = DC_TROT + 2 * SSG_N_TRAFFIC
+    DC_COUNT = DC_PREV_GOAL + 2
 };
 // u32 columns of the dyn region
 enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* contact hashes, polygon pairs */,
        DU_COUNT = kDynPairs + kPolyPairs };
 
-// ---------------------------------------------------------------------------------------------------------
-// Config 4 pipeline (shipsim_dynamics.hip header has the whole picture).  Nothing the player does reaches the other bodies
-// except through the goals it removes and through the end of its episode (PLAYER assumption: its arbiters are not solved),
-// and both are decided by the player's pose after cpBodyUpdatePosition — which step k-1's velocities fix exactly.  So the
-// full dyn step of API step k+1 needs nothing from the step kernel of step k: it runs BESIDE it, on a second stream.
-//
-// "vspace" = one Chipmunk space of non-player bodies: env e's current one (C, index e) and two slots for the ones of its coming
-// episodes, built ahead and stepped once (N slot s, index (1 + s) * n_pad + e; episode q uses slot q & 1): an auto-reset continues
-// from N instead of putting a fresh world's first — and hardest — cpSpaceStep on the critical path.  Every dyn column has
-// 3 * n_pad elements.
-//
-// The queue of the full dyn step is BUCKETED by (bank record, steps since the reset): after a reset the traffic ships and goal
+// The queue of the full dyn step is sorted by (bank record, steps since the reset): after a reset the traffic ships and goal
 // bodies of an env replay a transient that depends on its world and age only (the player pushes nothing), so envs of one
-// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.  Every bucket owns
-// a region of 2 * n_pad slots; a producer appends an entry with ONE returning atomic on the bucket's counter (arrival number =
-// slot) — no sort pass.  The full step's waves read the 512 counters themselves and walk the buckets MAP-MAJOR, every map's
-// stretch starting on a wave boundary: the lanes of a wave all sit on one bank record, which it then keeps once per wave
-// instead of once per lane.  Two queues, by the parity of the step they are for: step k's is consumed (and its counters
-// zeroed by the last workgroup to leave) while step k+1's is being produced.
+// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.  The order is
+// MAP-MAJOR and every map's stretch of the sorted queue starts on a wave boundary (kDynGrp slots; the gaps hold -1): the
+// lanes of a wave of the full step all sit on one bank record, which it then keeps once per wave instead of once per lane.
 constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuckets * kDynMapBuckets;
 constexpr int kDynGrp = 48;       // envs per wave of the full step (shipsim_dynamics.hip: kGrp)
-constexpr int kDynSortedPad = kDynMapBuckets * kDynGrp; // wave slots beyond the entries: every map's stretch rounded up to a wave
-constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after word 0 (the consumers' exit ticket)
+constexpr int kDynSortedPad = kDynMapBuckets * kDynGrp; // slots of dyn_sorted beyond n_pad: every map's stretch rounded up to a wave
+constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
-constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride; // per queue
-// queue entry: vspace | type << 27 | (generation & 3) << 30
-enum { DQ_STEP = 0 /* cpSpaceStep of a current space */, DQ_FRESH = 1 /* rebuild the current space from its record, then step */,
-       DQ_NJOB = 2 /* build a next-episode space (the entry's vspace: N slot 0 or 1) from its record and step it once */,
-       DQ_WAKE = 3 /* cpSpaceStep of a current space the step kernel woke: void if the space queued itself for the same step */,
-       DQ_ADOPT0 = 4, DQ_ADOPT1 = 5 /* the env was auto-reset: cpSpaceStep FROM its N slot 0 / 1 INTO its current space */ };
-constexpr unsigned kDynVMask = (1u << 27) - 1u;
-__host__ __device__ __forceinline__ unsigned dyn_entry(unsigned v, unsigned type, unsigned gen) { return v | (type << 27) | ((gen & 3u) << 30); }
-constexpr unsigned kDynNullEntry = 0xFFFFFFFFu; // (vspace out of range: ignored)
-// what the step kernel reads of the other bodies, per env and step parity: goal g centre at 2g, 2g+1; traffic ship k
-// (x, y, cos a, sin a) at 12 + 4k ..
-constexpr int kDynObsGoals = 0, kDynObsTraffic = 2 * SSG_MAX_GOALS, kDynObs = 2 * SSG_MAX_GOALS + 4 * SSG_N_TRAFFIC;
-constexpr int kDynObsPlanes = 4;  // planes 0, 1: the current space by step parity; 2, 3: N slot 0 / 1 after its one step (what an env sees in the
-                                  // step after its auto-reset, before its current space has taken the N slot over)
-constexpr int kDynPs = 6;         // the player state the dyn step predicts the goal removals from: x, y, vx, vy, angle, w
-constexpr int kDynPsRow = 8;      // ... one 64-byte record per env and step parity: the six, [6] the goal mask (bits 0-5; kDynPsSkip), [7] spare
-constexpr unsigned kDynPsSkip = 0x40u; // bit of the ps goal mask: this record predicts nothing (the mask is already current)
-// bits of dyn_req (step kernel -> adopt pass)
-enum { DR_RESET = 2 /* auto-reset in the last step: the coming step reads the N slot's table; an ADOPT entry waits in the queue of the step after */,
-       DR_ADOPTING = 4 /* auto-reset two steps ago: the ADOPT entry is due in the coming step's dyn step */ };
-// sort bucket of a space that is `age` steps into its episode on bank record `map_id`
+constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
+constexpr unsigned long long kDynSatOnly = ~0ull; // queue entry key of a resting env that only needs the player x traffic test
+// sort bucket of an env that is `age` steps into its episode on bank record `map_id`
 __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 {
     const unsigned agek = (unsigned)(age < kDynAgeBuckets - 1 ? (age < 0 ? 0 : age) : kDynAgeBuckets - 1);
@@ -90,19 +56,6 @@ __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 // writes the columns (dyn_init, the full step's write-back, ssg_dyn_invalidate after a caller's own writes); read by the full
 // step only.  The columns stay the interface of everything else (classify pass, step kernel, ssg_state_field).
 constexpr int kDynRow = 80, kDynRowTraffic = 48;
-// ... and what else the full step needs of the space, so that ONE batch of loads on five lines of the lane brings it all
-// (every separately indexed table was another set of 48 scattered lines — and TLB entries — per wave): [75] the live-arbiter mask,
-// [76] bank record | age << 32, [77] (N spaces) the N job's order: bank record | episode index << 32.
-// [75], [76] mirror DevCfg::dyn_live / dyn_vmap / dyn_age, kept by whoever writes those (the generation is read from DevCfg::dyn_gen:
-// the step kernel bumps it while a dyn step may be rewriting the row).
-constexpr int kDynRowLive = 75, kDynRowMeta = 76, kDynRowOrder = 77;
-// [79] the step the space has queued ITSELF for (its last dyn step changed something), 0 = none: a DQ_WAKE entry for that step is a
-// duplicate.
-constexpr int kDynRowSelf = 79;
-__host__ __device__ __forceinline__ unsigned long long dyn_meta_pack(int vmap, unsigned age, unsigned gen)
-{
-    return (unsigned long long)(unsigned)vmap | ((unsigned long long)(age & 255u) << 32) | ((unsigned long long)(gen & 255u) << 40);
-}
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
 constexpr int kStatsDoubles = 4 * kStatsSlots;
@@ -129,30 +82,28 @@ struct DevCfg {
     double *stats;
     const double *bank;
     unsigned long long *dbg; // diagnostic builds only (-DSSG_STAMPS): per-wave s_memtime stamps
-    // config 4 (n_ships == 4): columns of the non-player bodies (shipsim_dynamics.hip); null otherwise.  Every dyn column has
-    // dyn_np = 3 * n_pad elements: vspace v = e (env e's current space) or (1 + s) * n_pad + e (N slot s).
+    // config 4 (n_ships == 4): columns of the non-player bodies (shipsim_dynamics.hip); null otherwise
     int n_ships;
-    int dyn_np;
-    unsigned dyn_tick;            // the API step this launch belongs to (k >= 1): its parity selects obs / ps / queue buffers
     double *dyn_f64;
     uint32_t *dyn_u32;
     unsigned long long *dyn_live; // bit p: pair p has a cached arbiter
-    uint8_t *dyn_flag;            // [dyn_np] bit 2: the space's bodies are at rest (a fixed point of cpSpaceStep); written by the dyn kernels only
-    unsigned long long *dyn_hash; // [dyn_np] bank generation (DynCfg::bank_epoch) the rest bit was established for
-    uint8_t *dyn_gen;             // [dyn_np] generation of the space: queue entries of an older one are stale (the env was reset meanwhile)
-    uint8_t *dyn_age;             // [dyn_np] cpSpaceSteps this space has had (saturating): its sort bucket
-    int32_t *dyn_vmap;            // [dyn_np] bank record the space was built from
-    uint8_t *dyn_req;             // [n_pad] DR_* bits, written by the step kernel (and cleared by a host-side reset)
-    unsigned long long *dyn_nvalid; // [2][n_pad] per N slot: bank generation << 32 | episode index the slot was built for
-    double *dyn_obs;              // [kDynObsPlanes][kDynObs][n_pad] what the step kernel reads of the other bodies
-    double *dyn_ps;               // [2][n_pad][kDynPsRow] by step parity: the player state after the step (post-reset) and its goal mask, step kernel -> dyn step
-    int32_t *dyn_region;          // [2][kDynBuckets][dyn_np] queue entries, bucket b of queue q at [(q * kDynBuckets + b) * dyn_np ..)
-    unsigned *dyn_count;          // [2][kDynCountWords] per queue: [0] exit ticket of the consuming kernel; [kDynBucket0 + b * kDynBucketStride] bucket counters
-    unsigned *dyn_err;            // [4] should-never-happen counters: [0] an ADOPT entry whose N slot was not usable, [1] queue overflow
-    double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS]; // traffic hulls (local), for collide_ship
-    double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2: the step kernel's reject in front of collide_ship's exact test
+    uint8_t *dyn_flag;            // bit 0: player touches a traffic ship this step (dyn -> step kernel);
+                                  // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
+                                  // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
+    unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
+    // The queue of the full dyn step.  Produced for step t+1 by the step kernel's body role at the end of step t (or, after a
+    // host-side reset / bank change / ssg_dyn_invalidate, by dyn_classify_kernel): SEGMENTED, one segment of 64 slots per tile
+    // of 64 envs (entries dyn_queue[64*s + i], i < dyn_segcnt[s]: no atomics to append), each entry with its sort bucket and
+    // arrival number; dyn_sort_kernel turns it into dyn_sorted and counts it.
+    int32_t *dyn_queue;
+    unsigned *dyn_segcnt;         // [n_pad / 64] entries per segment; every producer writes every segment's count
+    unsigned *dyn_count;          // [0] length of dyn_sorted incl. its gaps (dyn_sort_kernel writes, the step kernel zeroes); [kDynBucket0 ..) bucket counts
+    unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
+    double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2, for the step kernel's classification of resting envs
     double dyn_hull_r;                // the player's hull radius about its body position
-    double *dyn_row;              // [dyn_np][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
+    int32_t *dyn_sorted;          // [n_pad + kDynSortedPad] the queue ordered by bucket (dyn_sort_kernel), -1 in the gaps: what the full dyn
+                                  // step walks (and resets to -1 behind itself)
+    double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
 };
 
 // Constants of the traffic ships and of Chipmunk's solver, by value to the dyn kernels only.
@@ -162,6 +113,7 @@ struct DynCfg {
     double goal_m_inv, goal_i_inv;
     double ship_friction;  // 0.7 (models.py:98); banks and goals keep Chipmunk's default 0
     double bias_coef, slop; // 1 - pow(collisionBias, dt), collisionSlop
+    double reach2[SSG_N_TRAFFIC]; // (player hull radius + ship k hull radius + margin)^2 about the body positions
     unsigned bank_epoch;    // bumped whenever the map bank changes: part of the pose hash
     int stop_after;         // development aid (SSG_DYN_STOP): leave the dyn kernel after phase n; 0 = run it all
 };
@@ -172,12 +124,9 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
 size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
-// Config 4, all with c.dyn_tick = k, the API step being prepared (shipsim_dynamics.hip):
-// the cpSpaceStep of step k for the spaces queued for it (queue k & 1)
-hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, hipStream_t stream);
-// rebuild the queues of steps k and k+1 and the player-state records from the columns (after the host touched the envs: ssg_reset,
-// a new bank, ssg_dyn_invalidate, a fresh handle); the caller has zeroed both queues' counters on the stream
-hipError_t launch_dyn_classify(const DevCfg &c, const DynCfg &d, hipStream_t stream);
+// sort + full step of the queue; classify = true: rebuild the queue first from the per-env flags (the step kernel did not
+// produce it: first step after a host-side reset, bank change or ssg_dyn_invalidate)
+hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream);
 hipError_t prepare_dyn(const DevCfg &c);
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream);
 hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
@@ -196,30 +145,6 @@ hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long e
                                hipStream_t stream);
 
 #ifdef __HIPCC__
-// The bank record an env moves to when ShipGame.reset gives it its next world: the next record of the shared bank, or —
-// map_ring mode — the next record of the env's own ring [base, base + R).
-__device__ __forceinline__ int next_map_of(const DevCfg &c, int map_id)
-{
-    if (c.map_ring > 0) {
-        const int base = map_id - map_id % c.map_ring;
-        const int nxt = map_id + 1;
-        return (nxt - base >= c.map_ring) ? base : nxt;
-    }
-    const int nxt = map_id + 1;
-    return (nxt >= c.n_maps) ? 0 : nxt;
-}
-
-// Append an entry to the queue of step `tick`.  (A space may be queued twice for one step — by the dyn step that stepped it and, as
-// DQ_WAKE, by the step kernel: the consumer drops a DQ_WAKE entry of a space that queued itself, kDynRowSelf.)
-__device__ __forceinline__ void dyn_enqueue(const DevCfg &c, unsigned tick, int v, unsigned type, unsigned bucket)
-{
-    const unsigned q = tick & 1u;
-    const unsigned slot = atomicAdd(c.dyn_count + (size_t)q * kDynCountWords + kDynBucket0 + bucket * kDynBucketStride, 1u);
-    if (slot >= (unsigned)c.dyn_np) { atomicAdd(c.dyn_err + 1, 1u); return; }
-    c.dyn_region[((size_t)q * kDynBuckets + bucket) * (size_t)c.dyn_np + slot] =
-            (int32_t)dyn_entry((unsigned)v, type, (unsigned)c.dyn_gen[v]);
-}
-
 // sin / cos of a body angle (cpvforangle).  The library's sincos is ~190 instructions of full-range machinery; body
 // angles stay within a few turns, so for |a| <= 2^18 this is a three-term Cody-Waite reduction by pi/2 with FMAs
 // (error < 2^-100 |a|) followed by the fdlibm / musl kernels on [-pi/4, pi/4] with the reduction's tail: within 1 ulp

@@ -138,19 +138,12 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
 }
 
 // Goal g's centre (comp 0 = x, 1 = y).  Configs 1-3: the goal bodies never move, so the map record holds them
-// (goff = the record's goal block).  Config 4 (DYN): goals are dynamic bodies; the dyn step of this API step has left their
-// positions in this step parity's table (goff = env index; DevCfg::dyn_obs, shipsim_dynamics.hip) — the body columns
-// themselves may already be a step ahead.  In the step after an env's auto-reset the table is the one its N slot published
-// (DR_RESET, shipsim_internal.h).
-__device__ __forceinline__ int dyn_goff(const DevCfg &c, int e, unsigned req, int episodes)
-{
-    const unsigned plane = (req & DR_RESET) ? 2u + ((unsigned)episodes & 1u) : (c.dyn_tick & 1u);
-    return (int)(plane * (unsigned)(kDynObs * c.n_pad)) + e;
-}
+// (goff = the record's goal block).  Config 4 (DYN): goals are dynamic bodies; the dyn kernel has just written this
+// step's positions into the env's goal columns (goff = env index, shipsim_dynamics.hip).
 template <bool LDS_BANK, bool DYN>
 __device__ __forceinline__ double goal_at(const DevCfg &c, int goff, int g, int comp)
 {
-    if constexpr (DYN) return c.dyn_obs[(size_t)(kDynObsGoals + 2 * g + comp) * (size_t)c.n_pad + (size_t)goff]; // (goff: plane * kDynObs * n_pad + env, dyn_goff())
+    if constexpr (DYN) return c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g + comp) * (size_t)c.n_pad + goff];
     else return bank_at<LDS_BANK>(c, goff + 2 * g + comp);
 }
 
@@ -188,7 +181,18 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
     }
 }
 
-__device__ __forceinline__ int next_map(const DevCfg &c, int map_id) { return next_map_of(c, map_id); }
+// The bank record an env moves to when ShipGame.reset gives it its next world: the next record of the shared bank, or —
+// map_ring mode — the next record of the env's own ring [base, base + R).
+__device__ __forceinline__ int next_map(const DevCfg &c, int map_id)
+{
+    if (c.map_ring > 0) {
+        const int base = map_id - map_id % c.map_ring;
+        const int nxt = map_id + 1;
+        return (nxt - base >= c.map_ring) ? base : nxt;
+    }
+    const int nxt = map_id + 1;
+    return (nxt >= c.n_maps) ? 0 : nxt;
+}
 
 // Beam i of an env whose body rotation is (ca, sa): direction heading + phi_i by the angle-addition identity from
 // host-computed cos/sin(phi_i), endpoint = origin + range * direction.  Owner lanes (culling) and worker lanes
@@ -226,12 +230,11 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 __host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
-constexpr int kTrafficTabBytes = SSG_N_TRAFFIC * 4 * 8 * 8; // config 4: per traffic ship k, [k][0..3][i] = local vertex x, y, plane normal x, y
 constexpr int kPoseDoubles = 7;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
-    return kBeamTabBytes + kShipTabBytes + kTrafficTabBytes + kPoseDoubles * epw * 8 + 6 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * kGoalScratchBytes;
+    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 6 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * kGoalScratchBytes;
 }
 __host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
 __host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
@@ -832,8 +835,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *traffictab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [3][4][8], config 4
-    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes + kTrafficTabBytes); // [7][EPW]
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [7][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
     int *poser = posem + EPW;                                                                // [EPW]
     unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
@@ -871,13 +873,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[0 * 8 + i] = c.hull[2 * i];     shiptab[1 * 8 + i] = c.hull[2 * i + 1];   // vertex i
         shiptab[2 * 8 + i] = c.nrm[2 * i];      shiptab[3 * 8 + i] = c.nrm[2 * i + 1];    // plane normal i
         shiptab[4 * 8 + i] = c.hull[2 * ip];    shiptab[5 * 8 + i] = c.hull[2 * ip + 1];  // vertex i-1 (edge start)
-    }
-    if constexpr (DYN) {
-        if (threadIdx.x >= 160 && threadIdx.x < 160 + SSG_N_TRAFFIC * SSG_SHIP_VERTS) {
-            const int kk = (threadIdx.x - 160) / SSG_SHIP_VERTS, i = (threadIdx.x - 160) % SSG_SHIP_VERTS;
-            traffictab[(kk * 4 + 0) * 8 + i] = c.thull[kk][2 * i]; traffictab[(kk * 4 + 1) * 8 + i] = c.thull[kk][2 * i + 1];
-            traffictab[(kk * 4 + 2) * 8 + i] = c.tnrm[kk][2 * i];  traffictab[(kk * 4 + 3) * 8 + i] = c.tnrm[kk][2 * i + 1];
-        }
     }
     if (threadIdx.x == 128) {
         // lidar origin of a freshly reset ship (angle 0: cpvforangle(0) = (1, 0)): pos + half the world AABB extents,
@@ -1001,20 +996,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
         constexpr int F = 6 + NB;
         double pv[F];
-        int obs_goff = 0; // config 4: where this step's goal centres are (dyn_goff)
         {
             const int el = el_;
             const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
             const int rud0 = colRud[el], map0 = colMap[el];
             const unsigned gm0 = c.mask[el];
-            if constexpr (DYN) obs_goff = dyn_goff(c, el, c.dyn_req[el], c.i32cols[(size_t)ICOL_EPISODE * np + el]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) pv[6 + i] = colLid[(size_t)i * np + el];
             pv[0] = x0; pv[1] = y0; pv[2] = (double)rud0; pv[3] = a0;
             if constexpr (DYN) {
                 // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
-                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * (size_t)c.dyn_np + el];
-                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * (size_t)c.dyn_np + el];
+                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el];
+                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[i])); // (in registers before barrier 0, as role 3's state)
@@ -1099,7 +1092,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(4);
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
             double nf_gx = 0, nf_gy = 0;
-            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? obs_goff : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
+            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
             SSG_STAMP_K(5);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
@@ -1120,8 +1113,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             nv[5] = do_reset ? rs_gy : nf_gy;
             if constexpr (DYN) { // the newest frame's goal: the next observation's older frame (goals move: kept in two columns)
                 if (live) {
-                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * (size_t)c.dyn_np + el_] = nv[4];
-                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * (size_t)c.dyn_np + el_] = nv[5];
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = nv[4];
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = nv[5];
                 }
             }
             {
@@ -1181,7 +1174,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // =========================================================================================================
     double x, y, vx, vy, ang, w, cum;
     unsigned gm;
-    unsigned req0 = 0; // config 4: DR_* bits the previous step left for this env
     int map_id, rudder, steps, episodes;
     {
         const int el = el_;
@@ -1191,7 +1183,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         rudder = colRud[el];
         steps = colStep[el];
         episodes = c.i32cols[(size_t)ICOL_EPISODE * np + el];
-        if constexpr (DYN) req0 = c.dyn_req[el];
     }
     if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // (gathered bank: this env's goal centres -> LDS, before barrier 0)
     int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
@@ -1223,7 +1214,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     asm volatile("" : "+v"(el));
     const int act = act_next;
     const int rec_off = map_id * SSG_MAP_STRIDE;
-    const int goff = DYN ? dyn_goff(c, el_, req0, episodes) : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
+    const int goff = DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS; // where goal_at() finds this env's goal centres
 
     // ---- handle_discrete_action (game.py:140-153) on the pre-step pose --------------------------------------------
     double fx = 0.0, fy = 0.0, tq = 0.0;
@@ -1284,87 +1275,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
-    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep left them
-    // (DevCfg::dyn_obs): cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the rejects
-    // run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world box is
-    // further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass go
-    // into the tile's pair queue (the goal narrowphase's, which runs after this) and are served 12 at a time by the whole wave:
-    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.
-    bool hit_traffic = false;
     unsigned dflag = 0;
-    if constexpr (DYN) {
-        dflag = c.dyn_flag[el_];
-        const double *tob = c.dyn_obs + (size_t)kDynObsTraffic * np + (size_t)goff; // (this env's plane of the table, traffic block)
-        unsigned short *tq = reinterpret_cast<unsigned short *>(goal_scratch0 + (tl >> 6) * kGoalScratchBytes);
-        unsigned *tw = reinterpret_cast<unsigned *>(tq + 64 * SSG_MAX_GOALS);
-        static_assert(SSG_N_TRAFFIC <= SSG_MAX_GOALS, "the traffic pairs of a tile fit the goal pair queue");
-        tw[lane] = 0u;
-        int n_tp = 0;
-#pragma unroll
-        for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
-            const double tx = tob[(size_t)(4 * kk) * np], ty = tob[(size_t)(4 * kk + 1) * np];
-            const double dx = dmax(dmax(sbl - tx, tx - sbr), 0.0), dy = dmax(dmax(sbb - ty, ty - sbt), 0.0);
-            bool cand = false;
-            if (live & ((dx * dx + dy * dy) <= c.dyn_reach2[kk])) {
-                const double tca = tob[(size_t)(4 * kk + 2) * np], tsa = tob[(size_t)(4 * kk + 3) * np];
-                double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
-#pragma unroll
-                for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-                    const double gx = traffictab[(kk * 4 + 0) * 8 + i], gy = traffictab[(kk * 4 + 1) * 8 + i];
-                    const double wx = tca * gx + (-tsa) * gy + tx, wy = tsa * gx + tca * gy + ty;
-                    bl = dmin(bl, wx); br = dmax(br, wx); bb = dmin(bb, wy); bt = dmax(bt, wy);
-                }
-                cand = (sbl <= br) & (bl <= sbr) & (sbb <= bt) & (bb <= sbt); // cpBBIntersects(player, ship k)
-            }
-            const unsigned long long m = __ballot(cand);
-            const int pos = n_tp + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (cand) tq[pos] = (unsigned short)(lane | (kk << 6));
-            n_tp += __popcll(m);
-        }
-        for (int base = 0; base < n_tp; base += 12) {
-            const int p = base + wq;
-            const bool valid = (lane < 60) & (p < n_tp);
-            const unsigned code = tq[valid ? p : 0];
-            const int src = code & 63, kk = code >> 6;
-            const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
-            const double *tsrc = c.dyn_obs + (size_t)kDynObsTraffic * np + (size_t)__shfl(goff, src); // env `src` of this tile (a live one: it queued the pair), in ITS plane
-            const double tx = tsrc[(size_t)(4 * kk) * np], ty = tsrc[(size_t)(4 * kk + 1) * np];
-            const double tca = tsrc[(size_t)(4 * kk + 2) * np], tsa = tsrc[(size_t)(4 * kk + 3) * np];
-            const double *tt = traffictab + kk * 32;
-            bool sep;
-            {   // axis = the player's edge normal i: every vertex of the ship strictly in front of the player's vertex i?
-                const double nx = bca * w_nx + (-bsa) * w_ny, ny = bsa * w_nx + bca * w_ny;
-                const double vx_ = bca * w_hx + (-bsa) * w_hy + bx, vy_ = bsa * w_hx + bca * w_hy + by;
-                const double off = nx * vx_ + ny * vy_;
-                double mn = INFINITY;
-#pragma unroll
-                for (int j = 0; j < SSG_SHIP_VERTS; ++j) {
-                    const double gx = tt[0 * 8 + j], gy = tt[1 * 8 + j];
-                    const double qx = tca * gx + (-tsa) * gy + tx, qy = tsa * gx + tca * gy + ty;
-                    mn = dmin(mn, nx * qx + ny * qy);
-                }
-                sep = mn > off;
-            }
-            {   // axis = the ship's edge normal i
-                const double lnx = tt[2 * 8 + wi], lny = tt[3 * 8 + wi], lvx = tt[0 * 8 + wi], lvy = tt[1 * 8 + wi];
-                const double nx = tca * lnx + (-tsa) * lny, ny = tsa * lnx + tca * lny;
-                const double vx_ = tca * lvx + (-tsa) * lvy + tx, vy_ = tsa * lvx + tca * lvy + ty;
-                const double off = nx * vx_ + ny * vy_;
-                double mn = INFINITY;
-#pragma unroll
-                for (int j = 0; j < SSG_SHIP_VERTS; ++j) {
-                    const double hx = shiptab[0 * 8 + j], hy = shiptab[1 * 8 + j];
-                    const double qx = bca * hx + (-bsa) * hy + bx, qy = bsa * hx + bca * hy + by;
-                    mn = dmin(mn, nx * qx + ny * qy);
-                }
-                sep |= mn > off;
-            }
-            const unsigned long long ms = __ballot(valid & sep);
-            const bool separated = ((ms >> (5 * wq)) & 31ull) != 0ull;
-            if (valid & (wi == 0) & !separated) atomicOr(&tw[src], 1u);
-        }
-        hit_traffic = tw[lane] != 0u;
-    }
+    if constexpr (DYN) dflag = c.dyn_flag[el_]; // bit 0: the dyn kernels found the player touching a traffic ship
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -1437,7 +1349,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
     // (the observer, role 2, finds the new frame's nearest goal among the goals this leaves listed)
-    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | (hit_traffic ? 2u : 0u) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
+    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
                                 ((steps_after >= c.max_steps) ? 16u : 0u) | ((alive == 0u) ? 32u : 0u) | (alive << 8);
     if (k + 1 < K) act_next = actions_kn[(size_t)(k + 1) * c.n_envs + el];
 
@@ -1446,7 +1358,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     SSG_STAMP_K(4);
 
     bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
-    if constexpr (DYN) colliding |= hit_traffic; // ... and against the traffic ships
+    if constexpr (DYN) {
+        colliding |= (dflag & 1u) != 0; // ... and against the traffic ships (dyn kernels)
+        if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
+    }
 
     // ---- determine_reward (ship_env.py:62-77) ----
     double rew = goal_reached ? 1.0 : ((oob_x | oob_y) ? -1.0 : -0.01);
@@ -1475,49 +1390,65 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // the new world's goal centres (only these lanes gather)
     }
     if constexpr (DYN) {
-        // What the dyn kernels need from this step (shipsim_dynamics.hip): an auto-reset env continues on the space of its new
-        // episode (below).  A space that is stepped queues itself; one at REST must be woken
-        // if the player is about to remove a goal from it (the removed goal's cached arbiters leave with it): whether the
-        // player's hull can reach a goal after its next cpBodyUpdatePosition is decided here, conservatively — every hull
-        // vertex moves by at most |v dt| + (hull radius) |w dt| per axis, and a resting space's goals stay where this step's
-        // table has them — and the env is queued for the cpSpaceStep after the next one, which evaluates collide_goal exactly.
         if (live) {
-            const unsigned req_new = do_reset ? (unsigned)DR_RESET : ((req0 & DR_RESET) ? (unsigned)DR_ADOPTING : 0u);
-            if (req_new != req0) c.dyn_req[el_] = (uint8_t)req_new;
+            // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
+            c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
         }
-        if (live && do_reset) {
-            // ShipGame.reset + add_default_traffic for the other bodies: the world of the episode that starts now sits in the env's
-            // N slot (episodes & 1; `episodes`, `map_id` are already the new episode's), built and stepped once by an N job an
-            // episode ago.  The NEXT step reads its table (DR_RESET); the dyn step of the step after continues from the slot into
-            // the current space (ADOPT) — and the N job of the episode after this one is ordered into the other slot.  Whatever
-            // the old space still has in the queues is void from here on (generation).
-            const unsigned gen_new = ((unsigned)c.dyn_gen[el_] + 1u) & 255u;
-            c.dyn_gen[el_] = (uint8_t)gen_new;
-            const unsigned tq = c.dyn_tick + 2u, qq = tq & 1u;
-            const int nm = next_map(c, map_id);
-            const int vn = (1 + ((episodes + 1) & 1)) * c.n_pad + el_;
-            const unsigned ba = dyn_bucket_of(1, map_id), bn = dyn_bucket_of(0, nm);
-            unsigned *cnt = c.dyn_count + (size_t)qq * kDynCountWords + kDynBucket0;
-            const unsigned slot_a = atomicAdd(cnt + ba * kDynBucketStride, 1u), slot_n = atomicAdd(cnt + bn * kDynBucketStride, 1u);
-            c.dyn_row[(size_t)vn * kDynRow + kDynRowOrder] = __longlong_as_double((long long)((unsigned long long)(unsigned)nm | ((unsigned long long)(unsigned)(episodes + 1) << 32)));
-            int32_t *region = c.dyn_region + (size_t)qq * kDynBuckets * (size_t)c.dyn_np;
-            if (slot_a < (unsigned)c.dyn_np) region[(size_t)ba * c.dyn_np + slot_a] = (int32_t)dyn_entry((unsigned)el_, (episodes & 1) ? DQ_ADOPT1 : DQ_ADOPT0, gen_new);
-            else atomicAdd(c.dyn_err + 1, 1u);
-            if (slot_n < (unsigned)c.dyn_np) region[(size_t)bn * c.dyn_np + slot_n] = (int32_t)dyn_entry((unsigned)vn, DQ_NJOB, (unsigned)c.dyn_gen[vn]);
-            else atomicAdd(c.dyn_err + 1, 1u);
-        }
-        // (only a resting space with cached arbiters on goals can be disturbed — dyn_flag bits 2, 3; the flag of a space the
-        // concurrent dyn step is stepping may be read old or new: old = "not at rest" is the safe side, new is exact; the flag
-        // of a space that is still being taken over from its N slot says nothing)
-        if (live && !do_reset && (((dflag & 12u) != 4u) | (req0 != 0u))) {
-            const double wr = c.dyn_hull_r * fabs(w * c.dt);
-            const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr, r = c.goal_r;
-            bool reach = false;
-            for (int g = 0; g < c.n_goals; ++g) {
-                const double gx = goal_at<LDS_BANK, DYN>(c, goff, g, 0), gy = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
-                reach |= (bool)((gm >> g) & 1u) & ((gx - r) <= (sbr + mx)) & ((sbl - mx) <= (gx + r)) & ((gy - r) <= (sbt + my)) & ((sbb - my) <= (gy + r));
+        // Which envs need the full cpSpaceStep of their other bodies NEXT step (shipsim_dynamics.hip)?  Everything that decides
+        // it is in this role's registers now: a reset env (fresh bodies), an env whose bodies are not at rest, one that lost a
+        // goal holding a cached arbiter this step.  A resting env whose player will be within reach of a parked
+        // traffic ship after its next cpBodyUpdatePosition is queued for collide_ship's exact test only (dyn_sort_kernel runs it).
+        // The others keep their rest bit, traffic bit clear.  Queue = one segment per tile:
+        // no atomics to append; the entry carries its sort bucket (steps since the reset, bank record).
+        bool need_full = false, sat_only = false;
+        if (live) {
+            bool resting = !do_reset & ((dflag & 4u) != 0u);
+            if (resting & goal_reached) {
+                // the goal(s) reached this step leave the space: the rest state survives unless one of them had a cached arbiter
+                // (pair ids of shipsim_dynamics.hip: goal g x bank s = 9 + 2g + s, goal g x ship k = 21 + 3g + k, goals h < g = 39 + g(g-1)/2 + h)
+                const unsigned long long lv = c.dyn_live[el_];
+                unsigned long long gone = 0ull;
+                const unsigned removed = ~gm & ((1u << c.n_goals) - 1u);
+                for (int g = 0; g < c.n_goals; ++g) {
+                    if (!((removed >> g) & 1u)) continue;
+                    gone |= 3ull << (9 + 2 * g);
+                    gone |= 7ull << (21 + 3 * g);
+                    for (int h = 0; h < c.n_goals; ++h)
+                        if (h != g) gone |= 1ull << (h < g ? 39 + g * (g - 1) / 2 + h : 39 + h * (h - 1) / 2 + g);
+                }
+                resting = (lv & gone) == 0ull;
             }
-            if (reach) dyn_enqueue(c, c.dyn_tick + 2u, el_, DQ_WAKE, dyn_bucket_of(kDynAgeBuckets - 1, map_id));
+            bool reach = false;
+            if (resting) {
+                // Can the player's hull touch a parked ship after its next cpBodyUpdatePosition?  Every hull vertex moves by at
+                // most |v dt| + (hull radius) |w dt| per axis, so the next hull lies inside this step's world box widened by that;
+                // a parked ship's hull lies inside the circle of its hull radius about its body position.  (A conservative
+                // pre-reject of cpBBIntersects: the exact test decides; tighter than the two hull-radius circles, which put a
+                // quarter of all envs "in reach" of the ship parked in mid-river.)
+                const double wr = c.dyn_hull_r * fabs(w * c.dt);
+                const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr;
+#pragma unroll
+                for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
+                    const double tx = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk) * np + el_], ty = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk + 1) * np + el_];
+                    const double dx = dmax(dmax((sbl - mx) - tx, tx - (sbr + mx)), 0.0), dy = dmax(dmax((sbb - my) - ty, ty - (sbt + my)), 0.0);
+                    reach |= (dx * dx + dy * dy) <= c.dyn_reach2[kk];
+                }
+            }
+            need_full = !resting;
+            sat_only = resting & reach;
+        }
+        const unsigned long long qm = __ballot(need_full | sat_only);
+        const int seg = (blockIdx.x * EPW + tl) >> 6; // this tile's segment (wave-uniform)
+        if (lane == 0) c.dyn_segcnt[seg] = (unsigned)__popcll(qm);
+        if (need_full | sat_only) {
+            const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(qm & ((1ull << lane) - 1ull));
+            unsigned long long key = kDynSatOnly; // a resting env within reach of a parked ship: collide_ship's exact test only
+            if (need_full) {
+                const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
+                key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+            }
+            c.dyn_queue[slot] = el_;
+            c.dyn_qkey[slot] = key;
         }
     }
     if (do_reset) {
@@ -1526,17 +1457,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         gm = (1u << c.n_goals) - 1u;
         // the pre-step rotation the next step's thrust will read: cpvforangle(0)
         pose[2 * EPW + tl] = 1.0; pose[3 * EPW + tl] = 0.0;
-    }
-    if constexpr (DYN) {
-        // the player state the cpSpaceStep after the next one predicts the next step's goal removals from (post-reset)
-        if (live) {
-            // (one 64-byte record per env: the 64 lanes of the wave write 4 KB in a row)
-            double2 *ps = reinterpret_cast<double2 *>(c.dyn_ps + ((size_t)(c.dyn_tick & 1u) * np + el_) * kDynPsRow);
-            double2 a0, a1, a2, a3;
-            a0.x = x; a0.y = y; a1.x = vx; a1.y = vy; a2.x = ang; a2.y = w;
-            a3.x = __longlong_as_double((long long)(gm & ((1u << c.n_goals) - 1u))); a3.y = 0.0;
-            ps[0] = a0; ps[1] = a1; ps[2] = a2; ps[3] = a3;
-        }
     }
     if (k == K - 1 && live && !SSG_ABL(9)) { // the state goes back to its columns with the last step of the launch
         st_out(&colX[el], x); st_out(&colY[el], y); st_out(&colVX[el], vx); st_out(&colVY[el], vy); st_out(&colA[el], ang);

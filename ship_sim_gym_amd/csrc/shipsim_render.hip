@@ -70,7 +70,7 @@ __global__ void render_kernel(const DevCfg c, const DynCfg d, int e, int width, 
 {
     __shared__ double beam_x[SSG_MAX_BEAMS], beam_y[SSG_MAX_BEAMS];
     __shared__ int beam_hit[SSG_MAX_BEAMS];
-    const size_t np = (size_t)c.n_pad, dnp = (size_t)c.dyn_np; // (dyn columns: the envs' current spaces come first)
+    const size_t np = (size_t)c.n_pad;
     const double px = c.f64cols[(size_t)COL_X * np + e], py = c.f64cols[(size_t)COL_Y * np + e];
     const double ang = c.f64cols[(size_t)COL_A * np + e];
     const int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
@@ -109,15 +109,15 @@ __global__ void render_kernel(const DevCfg c, const DynCfg d, int e, int width, 
         for (int g = 0; g < c.n_goals; ++g) {
             if (!((gmask >> g) & 1u)) continue;
             double gx, gy;
-            if (c.n_ships > 1) { gx = c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g) * dnp + e]; gy = c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g + 1) * dnp + e]; }
+            if (c.n_ships > 1) { gx = c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e]; gy = c.dyn_f64[(size_t)(DC_GOALS + DC_GOAL_COLS * g + 1) * np + e]; }
             else { gx = rec[SSG_MAP_OFF_GOALS + 2 * g]; gy = rec[SSG_MAP_OFF_GOALS + 2 * g + 1]; }
             if ((x - gx) * (x - gx) + (y - gy) * (y - gy) <= c.goal_r * c.goal_r) { R = 0; G = 255; B = 0; }
         }
         if (in_ship(c.hull, c.nrm, px, py, ang, x, y)) { R = 255; G = 255; B = 255; }
         if (c.n_ships > 1)
             for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-                const double *t = c.dyn_f64 + (size_t)(DC_TRAFFIC + 9 * k) * dnp + e;
-                if (in_ship(d.thull[k], d.tnrm[k], t[0], t[dnp], t[2 * dnp], x, y)) { R = 0; G = 0; B = 0; }
+                const double *t = c.dyn_f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+                if (in_ship(d.thull[k], d.tnrm[k], t[0], t[np], t[2 * np], x, y)) { R = 0; G = 0; B = 0; }
             }
         const double sxr = c.width / width; // the circles have a radius of 10 screen pixels of the reference's screen
         for (int i = 0; i < c.n_beams; ++i) {

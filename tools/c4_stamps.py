@@ -20,17 +20,12 @@ st = cols[DC_ARB + 200: DC_ARB + 210, :n].cpu().numpy()
 fl = vec.field(N.F_DYN_FLAGS).cpu().numpy()
 sel = st[5] > 0
 print("envs with stamps", sel.sum(), "of", n)
-_e = (C.c_uint32 * 4)()
-N.check(N.lib().ssg_debug_dyn_errors(vec._h, _e, vec._stream()), vec._h, "err")
-print("dyn_err", list(_e), "-> lanes per wave with work: %.1f" % (_e[2] / max(1, _e[3])))
-names = ["head (queue, staging)", "load+predict+pos", "collide", "prestep", "vel+solver", "writeback+enqueue"]
+names = ["load+pos", "player hit", "collide", "prestep", "vel+solver", "writeback"]
 prev = np.zeros(sel.sum())
 for i, nm in enumerate(names):
     cur = st[i][sel]
     print("%-12s median %8.0f  p90 %8.0f  max %8.0f cycles" % (nm, np.median(cur - prev), np.percentile(cur - prev, 90), (cur - prev).max()))
     prev = cur
-hd = cols[DC_ARB + 212: DC_ARB + 214, :n].cpu().numpy()
-print("head: counters in at median %.0f p90 %.0f; entry in at median %.0f p90 %.0f cycles" % (np.median(hd[0][sel]), np.percentile(hd[0][sel], 90), np.median(hd[1][sel]), np.percentile(hd[1][sel], 90)))
 print("total median %8.0f max %8.0f ; n_act hist" % (np.median(st[5][sel]), st[5][sel].max()), np.bincount(st[6][sel].astype(int)))
 print("per env: gjk iterations mean %.2f max %d | epa iterations mean %.2f max %d | narrowphase queries mean %.2f max %d" % (
     st[7][sel].mean(), st[7][sel].max(), st[8][sel].mean(), st[8][sel].max(), st[9][sel].mean(), st[9][sel].max()))

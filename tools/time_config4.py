@@ -10,9 +10,7 @@ from ship_sim_gym_amd.vec_env import ShipVecEnv
 
 n = int(os.environ.get("N", "65536"))
 K, W = int(os.environ.get("K", "300")), 50
-vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4, bank_in_global=os.environ.get("BIG", "0") == "1")
-if os.environ.get("STREAM", "0") == "1":   # run everything on a non-default torch stream
-    torch.cuda.set_stream(torch.cuda.Stream())
+vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
 acts = vec.random_actions(12345, 0, K + W)
 vec.reset_tensor()
 vec.rollout_tensor(acts[:W])
