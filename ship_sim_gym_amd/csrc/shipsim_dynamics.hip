@@ -852,6 +852,44 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // deferred space.remove of the goals the player reached last step (game.py:252): their cached arbiters go with them
     unsigned long long live = fresh ? 0ull : drop_removed_goal_arbiters(col.live[e], gmask, ng);
     const unsigned long long live0 = live;
+    // The records of the cached arbiters (a handful of pairs at most: the bits of `live`) are requested NOW, with the body row:
+    // fetched where cpArbiterUpdate needs them (push(), below; the ageing loop after the narrowphase) each was a dependent
+    // L2 / HBM round trip in the middle of the collide phase — 8 k cycles of a wave's chain with two arbiters.
+    constexpr int kPre = 4;
+    int ppid[kPre];
+    unsigned pmeta[kPre], phh[kPre];
+    double pacc[kPre][4];
+    {
+        unsigned long long lv = live;
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            ppid[i] = -1; pmeta[i] = 0u; phh[i] = 0u;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) pacc[i][f] = 0.0;
+            if (lv) {
+                const int pid = __ffsll((long long)lv) - 1;
+                lv &= lv - 1ull;
+                ppid[i] = pid;
+                pmeta[i] = col.u32[(size_t)(DU_META + pid) * np + e];
+                if (pid < kPolyPairs) phh[i] = col.u32[(size_t)(DU_HASH + pid) * np + e];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) pacc[i][f] = col.f64[(size_t)(DC_ARB + 4 * pid + f) * np + e];
+            }
+        }
+    }
+    // (a cached arbiter beyond the first kPre of the mask — never seen — is fetched on the spot)
+    auto arb_old = [&](int pid, unsigned &meta, unsigned &hh, double &a0, double &a1, double &a2, double &a3) {
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < kPre; ++i)
+            if (ppid[i] == pid) { meta = pmeta[i]; hh = phh[i]; a0 = pacc[i][0]; a1 = pacc[i][1]; a2 = pacc[i][2]; a3 = pacc[i][3]; found = true; }
+        if (!found) {
+            meta = col.u32[(size_t)(DU_META + pid) * np + e];
+            hh = (pid < kPolyPairs) ? col.u32[(size_t)(DU_HASH + pid) * np + e] : 0u;
+            const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
+            a0 = acc[0 * np]; a1 = acc[1 * np]; a2 = acc[2 * np]; a3 = acc[3 * np];
+        }
+    };
     // Did this step write back anything but the bits it read?  The body columns are compared directly: what was read stays
     // in registers until the write-back (this kernel runs one wave per SIMD, 512 VGPRs to spare; hashing both sides cost
     // ~150 64-bit multiplies per step).  The arbiters' accumulated impulses, touched for a few pairs only, go through
@@ -1032,15 +1070,11 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         unsigned old_hash[2] = {0u, 0u};
         double old_jn[2] = {0.0, 0.0}, old_jt[2] = {0.0, 0.0};
         if ((live >> pid) & 1ull) {
-            const unsigned meta = col.u32[(size_t)(DU_META + pid) * np + e];
+            unsigned meta = 0u, hh = 0u;
+            arb_old(pid, meta, hh, old_jn[0], old_jn[1], old_jt[0], old_jt[1]);
             state = meta & 7u;
             old_count = (meta >> 5) & 3u;
-            if (pid < kPolyPairs) {
-                const unsigned hh = col.u32[(size_t)(DU_HASH + pid) * np + e];
-                old_hash[0] = hh & 0xFFFFu; old_hash[1] = hh >> 16;
-            }
-            const double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
-            old_jn[0] = acc[0 * np]; old_jn[1] = acc[1 * np]; old_jt[0] = acc[2 * np]; old_jt[1] = acc[3 * np];
+            if (pid < kPolyPairs) { old_hash[0] = hh & 0xFFFFu; old_hash[1] = hh >> 16; }
             ain ^= arb_hash(pid, meta & ~0x18u, (pid < kPolyPairs) ? (old_hash[0] | old_hash[1] << 16) : 0u, old_jn[0], old_jn[1],
                             old_jt[0], old_jt[1]); // (age bits are 0 for an arbiter touched every step; a cached one changes anyway)
             if ((meta >> 3) & 3u) changed = true;
@@ -1202,7 +1236,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         while (rest) {
             const int pid = __ffsll((long long)rest) - 1;
             rest &= rest - 1ull;
-            unsigned meta = col.u32[(size_t)(DU_META + pid) * np + e];
+            unsigned meta = 0u, hh_ = 0u;
+            double a0_, a1_, a2_, a3_;
+            arb_old(pid, meta, hh_, a0_, a1_, a2_, a3_);
             unsigned age = (meta >> 3) & 3u;
             age += 1u; // ticks >= 1: the arbiter is (now) "cached"
             changed = true; // an ageing arbiter is a state change by itself

@@ -35,8 +35,12 @@ pr = cols[DC_ARB + 180: DC_ARB + 186, :n].cpu().numpy()
 if pr[1][sel].max() > 0:
     names_p = ["loops / rejects / shapes", "gjk", "epa", "closest + edges + clip", "push", "bank staging"]
     print("collide phase by category (SSG_DYN_PROFILE build), median cycles per wave:")
+    heavy_ = st[5][sel] >= np.percentile(st[5][sel], 97)
     for i, nm in enumerate(names_p):
-        print("   %-26s %8.0f" % (nm, np.median(pr[i][sel])))
+        print("   %-26s %8.0f   slowest 3 %% of the waves: %8.0f" % (nm, np.median(pr[i][sel]), np.median(pr[i][sel][heavy_])))
+    for i, nm in enumerate(names):
+        cur = st[i][sel][heavy_]; prv = st[i - 1][sel][heavy_] if i else 0
+        print("   phase %-12s in the slowest 3 %%: median %8.0f" % (nm, np.median(cur - prv)))
 # do the iteration counts depend on the episode's age (would age-binned waves be more homogeneous)?
 age = vec.field(N.F_STEP_COUNT).cpu().numpy()
 tot = st[7] + 2.5 * st[8]  # rough cost: an EPA iteration ~2.5 GJK iterations
