@@ -477,6 +477,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring must be 0 or in 2..64");
     if (cfg->map_ring != 0 && cfg->history > 2)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring needs history <= 2");
+    if (cfg->n_ships > 1 && cfg->n_envs > ssg::kDynSortedEnvMask) // (a sorted dyn-queue entry keeps 25 bits for the env)
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_ships = 4 supports at most 33 554 431 envs per handle");
     if (cfg->n_ships > 1 && (cfg->flags & SSG_FLAG_EXACT_LIDAR))
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: SSG_FLAG_EXACT_LIDAR is not built for n_ships = 4");
     ssg_handle *h = new (std::nothrow) ssg_handle();

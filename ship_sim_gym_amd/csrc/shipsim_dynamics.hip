@@ -776,7 +776,10 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
     if (t == 0) c.dyn_count[0] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     if (valid & !sat_only) {
         const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
-        if (dst < (unsigned)c.n_pad + (unsigned)kDynSortedPad) c.dyn_sorted[dst] = c.dyn_queue[i];
+        // (the entry carries its bucket's map index in bits 25 ..: the full step's waves — one bank record per wave when the bank
+        // holds at most 64 — stage their record's planes without first fetching the env's map id, a dependent round trip)
+        if (dst < (unsigned)c.n_pad + (unsigned)kDynSortedPad)
+            c.dyn_sorted[dst] = (int32_t)((unsigned)c.dyn_queue[i] | ((((unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)) / (unsigned)kDynAgeBuckets) << kDynSortedMapShift));
     }
 }
 
@@ -817,32 +820,59 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // The queue's length is not read: every slot the sort did not write holds -1 (a gap in front of the next map's stretch, or
     // past the end: this kernel leaves -1 behind in what it read, ssg_step memsets the array whenever the host rebuilt the
     // queue) — one memory round trip less at the head of every wave's chain.
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(); // (development aid, see stamp())
     const unsigned slot = (unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane;
     const bool in_queue = lane < kGrp;
     const int e_raw = in_queue ? c.dyn_sorted[slot] : -1;
-    const bool queued = (e_raw >= 0) & (e_raw < c.n_envs);
+    const bool queued = (e_raw >= 0) & ((e_raw & kDynSortedEnvMask) < c.n_envs);
     if (!__any(queued) && blockIdx.x != 0) return; // wave-uniform: nothing queued for this workgroup
     if (queued) c.dyn_sorted[slot] = -1;           // the next sort writes entries only
-    const int e = queued ? e_raw : 0;
+    const int e = queued ? (e_raw & kDynSortedEnvMask) : 0;
     if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
         for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
     const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
     const int cbase = kGrp * lane_doubles;
     const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
-    stage_hulls(c, d, cbase, lane);
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
     const size_t np = col.np;
-    int map_id = queued ? c.i32cols[(size_t)ICOL_MAP * np + e] : 0;
+    // Everything the step reads from memory about this env — goal mask, flags, live-arbiter mask, the player's six columns,
+    // the body row, (UNI) the wave's bank planes — is requested NOW, in one batch behind the queue entry.  (Requested where
+    // they were used these were four dependent round trips at the head of every wave's chain: the entry, the env's map id,
+    // the planes of that record, then the body state.)
+    int map_col = c.i32cols[(size_t)ICOL_MAP * np + e];
+    unsigned gm_raw = c.mask[e];
+    unsigned flag_raw = col.flag[e];
+    unsigned long long live_raw = col.live[e];
+    double pl_in[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) pl_in[f] = c.f64cols[(size_t)(COL_X + f) * np + e];
+    static_assert(COL_X == 0 && COL_Y == 1 && COL_VX == 2 && COL_VY == 3 && COL_A == 4 && COL_W == 5, "the player's columns");
+    double rw[kDynRow];
+    {
+        // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
+        // gathers over 75 x 64 lines per wave (the sorted queue scatters a wave's envs over the whole batch)
+        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)e * kDynRow);
+#pragma unroll
+        for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
+    }
+    stage_hulls(c, d, cbase, lane);
+    int map_id = map_col;
     if (UNI) {
         const unsigned long long qm = __ballot(queued);
         if (qm == 0ull) return;
-        map_id = __builtin_amdgcn_readlane(map_id, __ffsll((long long)qm) - 1);
+        map_id = __builtin_amdgcn_readlane(e_raw >> kDynSortedMapShift, __ffsll((long long)qm) - 1); // (the sort put it there)
         const double *rec_u = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
         for (int q = lane; q < 2 * kBankDoubles; q += 64) {
             const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
             lds[sbank + q] = rec_u[SSG_MAP_OFF_PLANES + sd * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
         }
     }
+    asm volatile("" : "+v"(map_col), "+v"(gm_raw), "+v"(flag_raw), "+v"(live_raw));
+#pragma unroll
+    for (int f = 0; f < 6; ++f) asm volatile("" : "+v"(pl_in[f]));
+#pragma unroll
+    for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
+    if (!UNI) map_id = map_col;
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave per workgroup: the LDS writes above are visible to its lanes
     __builtin_amdgcn_wave_barrier();
     if (!queued) return;
@@ -850,17 +880,16 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     const int ng = c.n_goals;
     const double *rec = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
     // development aid (SSG_DYN_STOP=-1): phase stamps of this lane's wave into the unused arbiter rows of pair 50..53
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     auto stamp = [&](int i) {
         if (d.stop_after == -1)
             col.f64[(size_t)(DC_ARB + 4 * 50 + i) * np + e] = (double)(__builtin_amdgcn_s_memtime() - t_start);
     };
-    const unsigned gmask = (unsigned)c.mask[e] & ((1u << ng) - 1u); // goals still in the space
+    const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
     // bit 1 of the flag: the step kernel auto-reset this env at the end of the last step — a fresh pm.Space(): its bodies are
     // rebuilt here (ShipGame.reset + add_default_traffic), nothing of the old episode is read
-    const bool fresh = (col.flag[e] & 2u) != 0u;
+    const bool fresh = (flag_raw & 2u) != 0u;
     // deferred space.remove of the goals the player reached last step (game.py:252): their cached arbiters go with them
-    unsigned long long live = fresh ? 0ull : drop_removed_goal_arbiters(col.live[e], gmask, ng);
+    unsigned long long live = fresh ? 0ull : drop_removed_goal_arbiters(live_raw, gmask, ng);
     const unsigned long long live0 = live;
     // The records of the cached arbiters (a handful of pairs at most: the bits of `live`) are requested NOW, with the body row:
     // fetched where cpArbiterUpdate needs them (push(), below; the ageing loop after the narrowphase) each was a dependent
@@ -926,16 +955,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
     // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
     // (the player's six columns are requested with everything else: its pose after its own cpBodyUpdatePosition)
-    const ShipShape pl = player_shape(c, e, cbase);
+    ShipShape pl; // the player's pose after its own cpBodyUpdatePosition (player_shape()'s expressions on the preloaded columns)
+    pl.hoff = cbase; pl.hashid = 0;
+    pl.p = mk(pl_in[0] + pl_in[2] * c.dt, pl_in[1] + pl_in[3] * c.dt);
+    sincos_body(pl_in[4] + pl_in[5] * c.dt, &pl.sa, &pl.ca);
+    pl.cache();
     double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
     {
-        // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
-        // gathers over 75 x 64 lines per wave (the sorted queue scatters a wave's envs over the whole batch)
         static_assert(DC_GOAL_COLS * SSG_MAX_GOALS == kDynRowTraffic && kDynRowTraffic + 9 * SSG_N_TRAFFIC <= kDynRow && kDynRow % 2 == 0, "row layout");
-        const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)e * kDynRow);
-        double rw[kDynRow];
-#pragma unroll
-        for (int i = 0; i < kDynRow / 2; ++i) { const double2 v = row2[i]; rw[2 * i] = v.x; rw[2 * i + 1] = v.y; }
 #pragma unroll
         for (int g = 0; g < SSG_MAX_GOALS; ++g)
 #pragma unroll

@@ -40,6 +40,7 @@ enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* c
 constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuckets * kDynMapBuckets;
 constexpr int kDynGrp = 48;       // envs per wave of the full step (shipsim_dynamics.hip: kGrp)
 constexpr int kDynSortedPad = kDynMapBuckets * kDynGrp; // slots of dyn_sorted beyond n_pad: every map's stretch rounded up to a wave
+constexpr int kDynSortedMapShift = 25, kDynSortedEnvMask = (1 << 25) - 1; // a dyn_sorted entry: env | bucket's map index << 25
 constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
