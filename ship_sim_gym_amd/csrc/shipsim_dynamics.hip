@@ -1189,6 +1189,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             for (int j = 0; j < k; ++j) cand |= (unsigned long long)bb_hit(kbx[j], kbx[k]) << (o_ship(k) + 2 + SSG_MAX_GOALS + j);
         }
     }
+    SSG_TICK(emem, 5); // (profile builds: category 5 = the broadphase)
     // ---- narrowphase (cpCollide) of the surviving pairs, canonical order per env; one code site per pair type -------------
     Info info;
     for (;;) {

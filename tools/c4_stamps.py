@@ -33,7 +33,7 @@ print("per env: gjk iterations mean %.2f max %d | epa iterations mean %.2f max %
 
 pr = cols[DC_ARB + 180: DC_ARB + 186, :n].cpu().numpy()
 if pr[1][sel].max() > 0:
-    names_p = ["loops / rejects / shapes", "gjk", "epa", "closest + edges + clip", "push", "bank staging"]
+    names_p = ["loops / rejects / shapes", "gjk", "epa", "closest + edges + clip", "push", "broadphase (54 box tests)"]
     print("collide phase by category (SSG_DYN_PROFILE build), median cycles per wave:")
     heavy_ = st[5][sel] >= np.percentile(st[5][sel], 97)
     for i, nm in enumerate(names_p):
