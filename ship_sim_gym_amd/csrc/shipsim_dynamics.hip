@@ -39,6 +39,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "shipsim_internal.h"
 
@@ -304,6 +305,20 @@ struct EpaMem {
         }
         return ov[buf * (kMaxEpa + 4 - kEpaLds) + i - kEpaLds];
     }
+    // ... when every lane's hull is known to fit the LDS entries (wave-uniformly): no scratch alternative behind the access
+    __device__ __forceinline__ Mink get_lds(int buf, int i) const
+    {
+        const int o = base + ((buf * kEpaLds + i) * 4) * kGrp;
+        Mink m;
+        m.a = mk(lds[o], lds[o + kGrp]); m.b = mk(lds[o + 2 * kGrp], lds[o + 3 * kGrp]);
+        m.ab = m.b - m.a;
+        return m;
+    }
+    __device__ __forceinline__ void set_lds(int buf, int i, const Mink &m) const
+    {
+        const int o = base + ((buf * kEpaLds + i) * 4) * kGrp;
+        lds[o] = m.a.x; lds[o + kGrp] = m.a.y; lds[o + 2 * kGrp] = m.b.x; lds[o + 3 * kGrp] = m.b.y;
+    }
     __device__ __forceinline__ void set(int buf, int i, const Mink &m) const
     {
         if (i < kEpaLds) {
@@ -320,45 +335,60 @@ __device__ __forceinline__ Closest epa(const SA &s1, const SB &s2, const Mink &v
 {
     int cur = 0; // buffer holding the hull; the other one receives the rebuilt hull
     int count = 3;
-    mem.set(0, 0, v0); mem.set(0, 1, v1); mem.set(0, 2, v2);
-    for (int iteration = 1;; ++iteration) {
+    mem.set_lds(0, 0, v0); mem.set_lds(0, 1, v1); mem.set_lds(0, 2, v2);
+    static_assert(kEpaLds >= 4, "the first hull and its first rebuild sit in LDS");
+    Closest result;
+    bool done = false;
+    // One EPA iteration; LDSONLY (a compile-time tag): every lane's hull — and the one it may grow into — fits the LDS entries,
+    // so the accessors carry no scratch alternative (the select between the two doubled the instructions of every access).
+    auto iterate = [&](auto ldsonly, int iteration) {
+        constexpr bool F = decltype(ldsonly)::value;
+        auto get = [&](int buf, int i) -> Mink { if constexpr (F) return mem.get_lds(buf, i); else return mem.get(buf, i); };
+        auto set = [&](int buf, int i, const Mink &m) { if constexpr (F) mem.set_lds(buf, i, m); else mem.set(buf, i, m); };
         mem.cnt[1]++;
         int mini = 0;
         double min_dist = INFINITY;
         {
-            V2 hi = mem.get(cur, count - 1).ab;
+            V2 hi = get(cur, count - 1).ab;
             for (int j = 0, i = count - 1; j < count; i = j, ++j) {
-                const V2 hj = mem.get(cur, j).ab;
+                const V2 hj = get(cur, j).ab;
                 const double d = closest_dist(hi, hj);
                 if (d < min_dist) { min_dist = d; mini = i; }
                 hi = hj;
             }
         }
         const int mini1 = (mini + 1 == count) ? 0 : mini + 1; // (mini + 1) % count
-        const Mink e0 = mem.get(cur, mini), e1 = mem.get(cur, mini1);
+        const Mink e0 = get(cur, mini), e1 = get(cur, mini1);
         const Mink p = support(s1, s2, perp(e1.ab - e0.ab));
         const double area2x = cross(e1.ab - e0.ab, (p.ab - e0.ab) + (p.ab - e1.ab));
         if (area2x > 0.0 && iteration < kMaxEpa) {
             int count2 = 1;
-            mem.set(cur ^ 1, 0, p);
+            set(cur ^ 1, 0, p);
             V2 h0 = p.ab; // ab of the last entry written to the new hull
             int index = mini1; // (mini + 1 + i) % count, stepped
             for (int i = 0; i < count; ++i) {
                 const int next = (index + 1 == count) ? 0 : index + 1;
-                const Mink hm = mem.get(cur, index);
+                const Mink hm = get(cur, index);
                 const V2 h1 = hm.ab;
-                const V2 h2 = (i + 1 < count) ? mem.get(cur, next).ab : p.ab;
-                if (cross(h2 - h0, h1 - h0) > 0.0) { mem.set(cur ^ 1, count2++, hm); h0 = h1; }
+                const V2 h2 = (i + 1 < count) ? get(cur, next).ab : p.ab;
+                if (cross(h2 - h0, h1 - h0) > 0.0) { set(cur ^ 1, count2++, hm); h0 = h1; }
                 index = next;
             }
             cur ^= 1;
             count = count2;
         } else {
             SSG_TICK(mem, 2);
-            const Closest r_ = closest_new(e0, e1);
-            return r_;
+            result = closest_new(e0, e1);
+            done = true;
         }
+    };
+    for (int iteration = 1;; ++iteration) {
+        // (wave-uniform: a hull of `count` entries is rebuilt into at most count + 1)
+        if (!__any(count + 1 > kEpaLds)) iterate(std::true_type{}, iteration);
+        else iterate(std::false_type{}, iteration);
+        if (done) break;
     }
+    return result;
 }
 
 template <class SA, class SB>
