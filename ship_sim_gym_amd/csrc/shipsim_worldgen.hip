@@ -236,11 +236,13 @@ __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double wid
     const double y_start = -100.0;
     const double y_delta = (height * 1.2 - y_start) / N;
     const double bank_width = width_frac * width / 2;
-    HullR hl, hr;
-    auto build_side = [&](const int s, HullR &h) {
+    // Only ONE hull's planes are live at a time (two were 128 doubles = every VGPR of the lane, and the kernel ran on 241
+    // spilled registers): all random draws are taken first, in the stream's order — side 0's vertices, side 1's, the goals' —
+    // then side 0 is hulled and every goal's two rays are cast against it, then side 1.  gen_goal_path asks the left bank
+    // first and the right one only on a miss; asking them in two passes returns the same answers (the queries are pure).
+    auto draw_side = [&](const int s, P2 (&pts)[SSG_MAX_HULL]) {
         const double x_min = s ? width - bank_width : 0.0, x_max = s ? width : bank_width;
         const double centre = x_min + (x_max - x_min); // the reference's x_middle is x_max (game_map.py:48)
-        P2 pts[SSG_MAX_HULL];
 #pragma unroll
         for (int k = 0; k < SSG_MAX_HULL; ++k) pts[k] = P2{0.0, 0.0};
         // gen_river_poly draws, per vertex, x ~ gauss(centre, 50) until it falls inside the bank's strip [x_min, x_max] (at most
@@ -273,11 +275,9 @@ __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double wid
 #pragma unroll
             for (int i = 0; i < SSG_MAX_HULL; ++i) { rw[s * 24 + 2 * i] = pts[i].x; rw[s * 24 + 2 * i + 1] = pts[i].y; }
         }
-#if defined(SSG_GEN_STOP) && SSG_GEN_STOP == 1 /* timing-only development builds */
-        rec[SSG_MAP_OFF_PLANES + s] = pts[3].x + pts[7].y;
-        return;
-#endif
-        // ---- pm.Poly: hull + splitting planes + cached AABB (models.py:180) ----
+    };
+    // ---- pm.Poly: hull + splitting planes + cached AABB (models.py:180) ----
+    auto build_hull = [&](const int s, P2 (&pts)[SSG_MAX_HULL], HullR &h) {
         const int n = convex_hull(pts, stk, lane);
         h.n = n;
         rec[SSG_MAP_OFF_COUNTS + s] = (double)n;
@@ -304,23 +304,63 @@ __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double wid
         double *bbp = rec + SSG_MAP_OFF_AABB + 4 * s;
         bbp[0] = l; bbp[1] = b; bbp[2] = r; bbp[3] = t;
     };
-    build_side(0, hl);
-    build_side(1, hr);
+    P2 pts1[SSG_MAX_HULL];
+    HullR h;
+    {
+        P2 pts0[SSG_MAX_HULL];
+        draw_side(0, pts0);
+        draw_side(1, pts1);
+#if defined(SSG_GEN_STOP) && SSG_GEN_STOP == 1 /* timing-only development builds */
+        rec[SSG_MAP_OFF_PLANES] = pts0[3].x + pts0[7].y + pts1[3].x + pts1[7].y;
+        return;
+#endif
+        // ---- gen_goal_path's draws (game.py:300-330), before any geometry: see above ----
+        // (per-goal values sit in registers; the loops over goals stay ROLLED — unrolled, their twenty-four inlined segment
+        // queries would be four times the instruction cache — and reach them through static select sweeps)
+        build_hull(0, pts0, h);
+    }
+    const double gy_delta = height / (n_goals + 1), x_middle = width / 2;
+    double gy[SSG_MAX_GOALS], gu[SSG_MAX_GOALS], gfb[SSG_MAX_GOALS], glx[SSG_MAX_GOALS], grx[SSG_MAX_GOALS];
+    unsigned ghit = 0u; // bit 2i: the left ray of goal i has its hit, bit 2i + 1: the right one
+#pragma unroll
+    for (int k = 0; k < SSG_MAX_GOALS; ++k) gy[k] = gu[k] = gfb[k] = glx[k] = grx[k] = 0.0;
+    auto put = [](double (&arr)[SSG_MAX_GOALS], int i, double v) {
+#pragma unroll
+        for (int k = 0; k < SSG_MAX_GOALS; ++k) arr[k] = (k == i) ? v : arr[k];
+    };
+    auto at = [](const double (&arr)[SSG_MAX_GOALS], int i) -> double {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < SSG_MAX_GOALS; ++k) v = (k == i) ? arr[k] : v;
+        return v;
+    };
+    for (int i = 1; i <= n_goals; ++i) { // (the stream's order: y, u, fallback per goal — after both sides' vertices)
+        put(gy, i - 1, gy_delta * i + rng.randint(-20, 20));
+        put(gu, i - 1, rng.uniform());
+        put(gfb, i - 1, x_middle * i + rng.randint(-50, 50));
+    }
 #if defined(SSG_GEN_STOP) && SSG_GEN_STOP <= 2
+    build_hull(1, pts1, h);
     return;
 #endif
-    // ---- gen_goal_path (game.py:300-330) ----
-    const double gy_delta = height / (n_goals + 1), x_middle = width / 2;
-    double best = 0.0, sgx = -1.0, sgy = -1.0;
-    for (int i = 1; i <= n_goals; ++i) {
-        const double y = gy_delta * i + rng.randint(-20, 20);
-        const double u = rng.uniform();
-        const double fallback = x_middle * i + rng.randint(-50, 50);
+    // ---- pass 1: both rays of every goal against the LEFT bank ----
+    for (int i = 0; i < n_goals; ++i) {
+        const double y = at(gy, i);
         double lx, rx2;
-        bool lh = segment_query_x(hl, x_middle, y, 0.0, y, 10.0, lx);
-        if (!lh) lh = segment_query_x(hr, x_middle, y, 0.0, y, 10.0, lx);
-        bool rh = segment_query_x(hl, x_middle, y, width, y, 10.0, rx2);
-        if (!rh) rh = segment_query_x(hr, x_middle, y, width, y, 10.0, rx2);
+        const bool lh = segment_query_x(h, x_middle, y, 0.0, y, 10.0, lx);
+        const bool rh = segment_query_x(h, x_middle, y, width, y, 10.0, rx2);
+        put(glx, i, lx); put(grx, i, rx2);
+        ghit |= (lh ? 1u : 0u) << (2 * i) | (rh ? 1u : 0u) << (2 * i + 1);
+    }
+    build_hull(1, pts1, h);
+    // ---- pass 2: the rays that missed, against the RIGHT bank; the goal itself ----
+    double best = 0.0, sgx = -1.0, sgy = -1.0;
+    for (int i = 0; i < n_goals; ++i) {
+        const double y = at(gy, i), u = at(gu, i), fallback = at(gfb, i);
+        double lx = at(glx, i), rx2 = at(grx, i);
+        bool lh = (ghit >> (2 * i)) & 1u, rh = (ghit >> (2 * i + 1)) & 1u;
+        if (!lh) lh = segment_query_x(h, x_middle, y, 0.0, y, 10.0, lx);
+        if (!rh) rh = segment_query_x(h, x_middle, y, width, y, 10.0, rx2);
         double x;
         if (lh && rh) {
             const double lo = lx + 60.0, hi = rx2 - 60.0;
@@ -328,12 +368,12 @@ __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double wid
         } else {
             x = fallback;
         }
-        rec[SSG_MAP_OFF_GOALS + 2 * (i - 1)] = x;
-        rec[SSG_MAP_OFF_GOALS + 2 * (i - 1) + 1] = y;
-        if (rw) { rw[48 + 3 * (i - 1)] = y; rw[48 + 3 * (i - 1) + 1] = u; rw[48 + 3 * (i - 1) + 2] = fallback; }
+        rec[SSG_MAP_OFF_GOALS + 2 * i] = x;
+        rec[SSG_MAP_OFF_GOALS + 2 * i + 1] = y;
+        if (rw) { rw[48 + 3 * i] = y; rw[48 + 3 * i + 1] = u; rw[48 + 3 * i + 2] = fallback; }
         const double dx = x - spawn_x, dy = y - spawn_y;
         const double d = sqrt(dx * dx + dy * dy);
-        if (i == 1 || d < best) { best = d; sgx = x; sgy = y; }
+        if (i == 0 || d < best) { best = d; sgx = x; sgy = y; }
     }
     rec[SSG_MAP_OFF_SPAWN_GOAL] = sgx;
     rec[SSG_MAP_OFF_SPAWN_GOAL + 1] = sgy;
