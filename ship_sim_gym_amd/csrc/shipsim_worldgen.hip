@@ -228,7 +228,12 @@ __device__ __forceinline__ bool segment_query_x(const HullR &h, double ax, doubl
 __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double width, double height, double width_frac, double spawn_x,
                                                double spawn_y, double *__restrict__ rec, double *__restrict__ rw, double *stk, int lane)
 {
-    for (int i = 0; i < SSG_MAP_STRIDE; ++i) rec[i] = 0.0;
+    // (every double of the record is written exactly once below — the unused plane and goal slots as zeros where their used
+    // neighbours are written; a zeroing sweep over all 145 first was 145 scattered stores per lane in front of everything)
+    static_assert(SSG_MAP_OFF_PLANES + 2 * SSG_MAX_HULL * SSG_PLANE_DOUBLES + 1 == SSG_MAP_STRIDE && SSG_MAP_OFF_SPAWN_GOAL + 2 == SSG_MAP_OFF_PLANES &&
+                  SSG_MAP_OFF_GOALS + 2 * SSG_MAX_GOALS == SSG_MAP_OFF_SPAWN_GOAL && SSG_MAP_OFF_AABB + 8 == SSG_MAP_OFF_GOALS && SSG_MAP_OFF_COUNTS + 2 == SSG_MAP_OFF_AABB,
+                  "record layout: counts, boxes, goals, spawn goal, planes, one pad double");
+    rec[SSG_MAP_STRIDE - 1] = 0.0;
 
     // ---- gen_river_poly (game_map.py:22-73) ----
     constexpr int N = 10;
@@ -298,6 +303,9 @@ __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double wid
                 q[0] = h.vx[i]; q[1] = h.vy[i]; q[2] = h.nx[i]; q[3] = h.ny[i]; q[4] = h.d[i];
                 l = fmin(l, bb.x); r = fmax(r, bb.x); b = fmin(b, bb.y); t = fmax(t, bb.y);
                 a = bb;
+            } else {
+                double *q = pp + SSG_PLANE_DOUBLES * i;
+                q[0] = 0.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0;
             }
         }
         h.l = l; h.b = b; h.r = r; h.t = t;
@@ -375,6 +383,7 @@ __device__ __forceinline__ void generate_world(Rng &rng, int n_goals, double wid
         const double d = sqrt(dx * dx + dy * dy);
         if (i == 0 || d < best) { best = d; sgx = x; sgy = y; }
     }
+    for (int i = n_goals; i < SSG_MAX_GOALS; ++i) { rec[SSG_MAP_OFF_GOALS + 2 * i] = 0.0; rec[SSG_MAP_OFF_GOALS + 2 * i + 1] = 0.0; }
     rec[SSG_MAP_OFF_SPAWN_GOAL] = sgx;
     rec[SSG_MAP_OFF_SPAWN_GOAL + 1] = sgy;
 }
