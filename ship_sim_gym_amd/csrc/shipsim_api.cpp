@@ -362,7 +362,8 @@ void refresh_dev(ssg_handle *h)
             const double r = radius(h->dyn.thull[k]) * 1.001 + 1.0;
             d.dyn_reach2[k] = r * r;
         }
-        d.dyn_hull_r = radius(c.ship_hull) * 1.001;
+        std::memcpy(d.thull, h->dyn.thull, sizeof(d.thull));
+        std::memcpy(d.tnrm, h->dyn.tnrm, sizeof(d.tnrm));
     }
     h->dyn_queue_valid = false; // (anything that refreshes the kernel arguments may have changed what the queue was built from)
 }

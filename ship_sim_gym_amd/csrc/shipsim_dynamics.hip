@@ -486,27 +486,6 @@ __device__ __forceinline__ void collide(const SA &a, const SB &b, Info &info, co
     }
 }
 
-// SAT over both hulls' edge normals after the cpBBIntersects reject: "touching counts" (collide_ship's begin)
-__device__ __forceinline__ bool ships_touch(const ShipShape &a, const ShipShape &b)
-{
-    if (!bb_hit(a.bb(), b.bb())) return false;
-    bool sep = false;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const ShipShape &p = pass ? b : a, &q = pass ? a : b;
-#pragma unroll
-        for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
-            const V2 n = p.normal(i);
-            const double off = dot(n, p.vert(i));
-            double mn = INFINITY;
-#pragma unroll
-            for (int j = 0; j < SSG_SHIP_VERTS; ++j) mn = fmin(mn, dot(n, q.vert(j)));
-            sep |= mn > off;
-        }
-    }
-    return !sep;
-}
-
 // ---- arbiter pair ids (bits of the live mask, rows of the arbiter columns) ----
 __device__ __forceinline__ int pid_tb(int k, int s) { return 2 * k + s; }                       // [0, 6)
 __device__ __forceinline__ int pid_tt(int j, int k) { return 6 + j + k - 1; }                   // j < k: [6, 9)
@@ -532,6 +511,8 @@ __device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, i
         for (int f = 2; f < 9; ++f) t[(size_t)f * col.np] = 0.0;
         row[kDynRowTraffic + 9 * k] = d.tx[k]; row[kDynRowTraffic + 9 * k + 1] = d.ty[k];
         for (int f = 2; f < 9; ++f) row[kDynRowTraffic + 9 * k + f] = 0.0;
+        col.f64[(size_t)(DC_TROT + 2 * k) * col.np + e] = 1.0; // cpvforangle(0): the rotation of the angle column (step kernel's collide_ship)
+        col.f64[(size_t)(DC_TROT + 2 * k + 1) * col.np + e] = 0.0;
     }
     // all goal centres first, then the stores: a load issued after a store it might alias waits for nothing, but the
     // compiler keeps program order, and one L2 round trip per goal coordinate made this the slowest part of pass 1
@@ -610,21 +591,6 @@ __device__ __forceinline__ void stage_hulls(const DevCfg &c, const DynCfg &d, in
     }
 }
 
-// The player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel).
-__device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int hoff)
-{
-    const size_t np = (size_t)c.n_pad;
-    const double x = c.f64cols[(size_t)COL_X * np + e], y = c.f64cols[(size_t)COL_Y * np + e];
-    const double vx = c.f64cols[(size_t)COL_VX * np + e], vy = c.f64cols[(size_t)COL_VY * np + e];
-    const double ang = c.f64cols[(size_t)COL_A * np + e], w = c.f64cols[(size_t)COL_W * np + e];
-    ShipShape pl;
-    pl.hoff = hoff; pl.hashid = 0;
-    pl.p = mk(x + vx * c.dt, y + vy * c.dt);
-    sincos_body(ang + w * c.dt, &pl.sa, &pl.ca);
-    pl.cache();
-    return pl;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // The rest bit.  cpSpaceStep is a deterministic function of the bodies' cpBody fields, the cached arbiters and
 // the static banks (the player never pushes anything: PLAYER assumption).  When a full step wrote back exactly the
@@ -638,30 +604,6 @@ __device__ __forceinline__ ShipShape player_shape(const DevCfg &c, int e, int ho
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kClassifyThreads = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
-
-// collide_ship for a RESTING env: the player after its own cpBodyUpdatePosition against the three parked traffic ships
-// (hull constants at lds[0 ..]; same expressions as player_shape() / the full step).
-__device__ __forceinline__ bool resting_player_hit(const DevCfg &c, int e)
-{
-    const size_t np = (size_t)c.n_pad;
-    double tp[SSG_N_TRAFFIC][3];
-#pragma unroll
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        const double *t = c.dyn_f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-        tp[k][0] = t[0]; tp[k][1] = t[np]; tp[k][2] = t[2 * np];
-    }
-    const ShipShape pl = player_shape(c, e, 0);
-    bool hit = false;
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        ShipShape sk;
-        sk.hoff = kHullDoubles * (1 + k); sk.hashid = 0;
-        sk.p = mk(tp[k][0], tp[k][1]);
-        sincos_body(tp[k][2], &sk.sa, &sk.ca);
-        sk.cache();
-        hit |= ships_touch(pl, sk); // collide_ship: player (type 0) x traffic (type 1)
-    }
-    return hit;
-}
 
 // Which goals' cached arbiters leave with the goals the player has reached (deferred space.remove, game.py:252).
 __device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigned long long live, unsigned gmask, int ng)
@@ -683,77 +625,46 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
 {
     const int e = blockIdx.x * kClassifyThreads + threadIdx.x;
     const bool valid = e < c.n_envs;
-    bool need_full = false, sat_only = false;
+    bool need_full = false;
     unsigned bucket = 0;
     if (valid) {
         DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
         const size_t np = col.np;
         const int ng = c.n_goals;
-        // Everything this pass can need is requested at once (one memory round trip instead of five dependent ones:
-        // flag -> masks -> hash -> positions -> angles; the pass was latency-bound at 12.8 us for 65 536 envs).
+        // everything this pass can need is requested at once (one memory round trip instead of dependent ones)
         int map_id = c.i32cols[(size_t)ICOL_MAP * np + e];
-        const int age = c.i32cols[(size_t)ICOL_STEP * np + e]; // steps since the reset: where the env is in its post-reset transient
+        int age = c.i32cols[(size_t)ICOL_STEP * np + e]; // steps since the reset: where the env is in its post-reset transient
         unsigned flag = col.flag[e];
         unsigned gm_raw = c.mask[e];
         unsigned long long live0 = col.live[e];
         unsigned long long hash0 = c.dyn_hash[e];
-        double px = c.f64cols[(size_t)COL_X * np + e], py = c.f64cols[(size_t)COL_Y * np + e];
-        double pvx = c.f64cols[(size_t)COL_VX * np + e], pvy = c.f64cols[(size_t)COL_VY * np + e];
-        double pang = c.f64cols[(size_t)COL_A * np + e], pw = c.f64cols[(size_t)COL_W * np + e];
-        double tp[SSG_N_TRAFFIC][3];
-#pragma unroll
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-            const double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-            tp[k][0] = t[0]; tp[k][1] = t[np]; tp[k][2] = t[2 * np];
-        }
-        asm volatile("" : "+v"(map_id), "+v"(flag), "+v"(gm_raw), "+v"(live0), "+v"(hash0));
-        asm volatile("" : "+v"(px), "+v"(py), "+v"(pvx), "+v"(pvy), "+v"(pang), "+v"(pw));
-#pragma unroll
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]));
+        asm volatile("" : "+v"(map_id), "+v"(age), "+v"(flag), "+v"(gm_raw), "+v"(live0), "+v"(hash0));
         const unsigned gmask = gm_raw & ((1u << ng) - 1u); // goals still in the space
         // rest bit still valid?  It was established for this bank generation; callers that write the body columns
         // themselves clear it with ssg_dyn_invalidate (include/shipsim.h).  A cached arbiter that left with its goal
         // was part of the fixed point: the bodies it touched are stepped again.  (An env the step kernel auto-reset — bit 1 —
         // gets its bodies rebuilt by the full step.)
-        bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) &&
-                    (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
-        if (rest) {
-            // the player's position after its own cpBodyUpdatePosition; the exact test only if some ship is in reach
-            const double ppx = px + pvx * c.dt;
-            const double ppy = py + pvy * c.dt;
-            bool reach = false;
-#pragma unroll
-            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-                // No vertex of either hull is further than its hull radius from its body position: beyond the sum the
-                // AABBs cannot meet, whatever the rotations (a conservative pre-reject of cpBBIntersects' exact one)
-                const double dx = tp[k][0] - ppx, dy = tp[k][1] - ppy;
-                reach |= (dx * dx + dy * dy) <= d.reach2[k];
-            }
-            col.flag[e] = 4u;     // at rest, traffic bit clear; dyn_sort_kernel sets it for the envs in reach that do touch
-            sat_only = reach;
-        }
+        const bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) &&
+                          (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
+        if (rest) col.flag[e] = 4u;
         need_full = !rest;
         bucket = dyn_bucket_of(age, map_id);
-        (void)pang; (void)pw;
     }
     // The queue is segmented by tiles of 64 envs (a wave of this kernel = one tile): no atomics to append.
-    const unsigned long long m = __ballot(need_full | sat_only);
+    const unsigned long long m = __ballot(need_full);
     const int lane = threadIdx.x & 63;
     const int seg = e >> 6; // (n_pad is a multiple of 256: every wave of the grid owns a whole segment)
     if (lane == 0 && (size_t)seg < (size_t)c.n_pad / 64) c.dyn_segcnt[seg] = (unsigned)__popcll(m);
-    if (need_full | sat_only) {
+    if (need_full) {
         const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        unsigned long long key = kDynSatOnly;
-        if (need_full) // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
-            key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+        // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
         c.dyn_queue[slot] = e;
-        c.dyn_qkey[slot] = key;
+        c.dyn_qkey[slot] = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// dyn_sort_kernel: counting sort of the queue by bucket (the "SAT only" entries stay where they are: dyn_step_kernel's trailing
-// workgroups read them from the segments).  Every
+// dyn_sort_kernel: counting sort of the queue by bucket.  Every
 // workgroup scans the 512 bucket counters itself (2 KB from L2) and scatters its 256 queue entries to base[bucket] + arrival
 // number.  Buckets are map-major (dyn_bucket_of) and a map's eight buckets start on a multiple of kDynGrp slots: no wave of the
 // full step straddles two bank records.  The gaps are not written: the full step leaves -1 behind in every slot it read.
@@ -770,8 +681,7 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
     const unsigned cnt = ((size_t)seg < (size_t)c.n_pad / 64) ? min(c.dyn_segcnt[seg], 64u) : 0u; // (clamped: garbage counters must not index past a segment)
     const bool valid = (unsigned)lane < cnt;
     const unsigned long long k = valid ? c.dyn_qkey[i] : 0ull;
-    const bool sat_only = valid & (k == kDynSatOnly);
-    const unsigned n_full = (unsigned)__popcll(__ballot(valid & !sat_only));
+    const unsigned n_full = (unsigned)__popcll(__ballot(valid));
     if (lane == 0) wave_tot[wv] = n_full;
     __syncthreads();
     const unsigned wsum = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -804,7 +714,7 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
     __syncthreads();
     // the queue's length including the gaps (zeroed by the step kernel; every workgroup that gets here stores the same number)
     if (t == 0) c.dyn_count[0] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    if (valid & !sat_only) {
+    if (valid) {
         const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
         // (the entry carries its bucket's map index in bits 25 ..: the full step's waves — one bank record per wave when the bank
         // holds at most 64 — stage their record's planes without first fetching the env's map id, a dependent round trip)
@@ -826,27 +736,6 @@ template <bool UNI>
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
     const int lane = threadIdx.x;
-    // (clamped: a counter that was never initialised must not index past the queue; include/shipsim.h ssg_bind_state)
-    // The grid's tail — one workgroup per 64-env segment of the step kernel's queue — serves the "SAT only" entries: a resting
-    // env whose player comes within reach of a parked ship gets collide_ship's exact test and the traffic bit of its flag.
-    // These workgroups take the LDS slots the full step's waves leave free (or recycle them) and are long gone before the
-    // slowest of those finishes; inside dyn_sort_kernel the same test sat on the chain sort -> full step -> step kernel.
-    const unsigned n_step_blocks = ((unsigned)c.n_pad + (unsigned)kDynSortedPad) / (unsigned)kGrp;
-    if (blockIdx.x >= n_step_blocks) {
-        const unsigned seg = blockIdx.x - n_step_blocks;
-        const unsigned cnt = min(c.dyn_segcnt[seg], 64u);
-        if (cnt == 0u) return;
-        const bool sat = ((unsigned)lane < cnt) && c.dyn_qkey[seg * 64u + (unsigned)lane] == kDynSatOnly;
-        if (!__any(sat)) return;
-        stage_hulls(c, d, 0, lane);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        if (sat) {
-            const int e = c.dyn_queue[seg * 64u + (unsigned)lane];
-            if (e >= 0 && e < c.n_envs && resting_player_hit(c, e)) c.dyn_flag[e] = (uint8_t)(4u | 1u);
-        }
-        return;
-    }
     // The queue's length is not read: every slot the sort did not write holds -1 (a gap in front of the next map's stretch, or
     // past the end: this kernel leaves -1 behind in what it read, ssg_step memsets the array whenever the host rebuilt the
     // queue) — one memory round trip less at the head of every wave's chain.
@@ -865,18 +754,13 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
     const size_t np = col.np;
-    // Everything the step reads from memory about this env — goal mask, flags, live-arbiter mask, the player's six columns,
-    // the body row, (UNI) the wave's bank planes — is requested NOW, in one batch behind the queue entry.  (Requested where
+    // Everything the step reads from memory about this env — goal mask, flags, live-arbiter mask, the body row, (UNI) the wave's bank planes — is requested NOW, in one batch behind the queue entry.  (Requested where
     // they were used these were four dependent round trips at the head of every wave's chain: the entry, the env's map id,
     // the planes of that record, then the body state.)
     int map_col = c.i32cols[(size_t)ICOL_MAP * np + e];
     unsigned gm_raw = c.mask[e];
     unsigned flag_raw = col.flag[e];
     unsigned long long live_raw = col.live[e];
-    double pl_in[6];
-#pragma unroll
-    for (int f = 0; f < 6; ++f) pl_in[f] = c.f64cols[(size_t)(COL_X + f) * np + e];
-    static_assert(COL_X == 0 && COL_Y == 1 && COL_VX == 2 && COL_VY == 3 && COL_A == 4 && COL_W == 5, "the player's columns");
     double rw[kDynRow];
     {
         // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
@@ -898,8 +782,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
     }
     asm volatile("" : "+v"(map_col), "+v"(gm_raw), "+v"(flag_raw), "+v"(live_raw));
-#pragma unroll
-    for (int f = 0; f < 6; ++f) asm volatile("" : "+v"(pl_in[f]));
 #pragma unroll
     for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
     if (!UNI) map_id = map_col;
@@ -985,11 +867,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // ---- (1) load + cpBodyUpdatePosition ------------------------------------------------------------------------
     // every body column of this env is requested at once (one memory round trip; per goal and ship it was five dependent ones)
     // (the player's six columns are requested with everything else: its pose after its own cpBodyUpdatePosition)
-    ShipShape pl; // the player's pose after its own cpBodyUpdatePosition (player_shape()'s expressions on the preloaded columns)
-    pl.hoff = cbase; pl.hashid = 0;
-    pl.p = mk(pl_in[0] + pl_in[2] * c.dt, pl_in[1] + pl_in[3] * c.dt);
-    sincos_body(pl_in[4] + pl_in[5] * c.dt, &pl.sa, &pl.ca);
-    pl.cache();
     double gin[SSG_MAX_GOALS][DC_GOAL_COLS], tin[SSG_N_TRAFFIC][9];
     {
         static_assert(DC_GOAL_COLS * SSG_MAX_GOALS == kDynRowTraffic && kDynRowTraffic + 9 * SSG_N_TRAFFIC <= kDynRow && kDynRow % 2 == 0, "row layout");
@@ -1111,10 +988,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 
     stamp(0);
     if (d.stop_after == 1) return;
-    // the player's pose after its own cpBodyUpdatePosition (same expressions as the step kernel) against traffic
-    bool hit = false;
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) hit |= ships_touch(pl, ship_shape(k)); // collide_ship: type 0 x type 1
-
+    // (collide_ship, the player against the traffic ships, is the step kernel's: it reads the poses this step writes)
     stamp(1);
     if (d.stop_after == 2) return;
     prof_last = __builtin_amdgcn_s_memtime();
@@ -1571,6 +1445,10 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         if (dfb | fresh) {
 #pragma unroll
             for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = v[f]; row[f] = v[f]; }
+            // the rotation of the angle column (cos, sin as this step's cpBodyUpdatePosition computed them): what the step
+            // kernel's collide_ship builds the ship's world hull from
+            col.f64[(size_t)(DC_TROT + 2 * k) * np + e] = L(xbase + X_STRIDE * k + X_CA);
+            col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = L(xbase + X_STRIDE * k + X_SA);
         }
         changed |= dfb;
     }
@@ -1600,7 +1478,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     }
     col.live[e] = live;
     c.dyn_hash[e] = (unsigned long long)d.bank_epoch; // the bank generation this (possible) rest state belongs to
-    col.flag[e] = (uint8_t)((hit ? 1u : 0u) | (changed ? 0u : 4u)); // unchanged = a fixed point of cpSpaceStep: at rest
+    col.flag[e] = (uint8_t)(changed ? 0u : 4u); // unchanged = a fixed point of cpSpaceStep: at rest
 }
 
 size_t dyn_lds_bytes(int n_goals, bool uni)
@@ -1634,7 +1512,7 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipS
     // one bank record per wave: the sort's buckets tell records apart only when the bank holds at most kDynMapBuckets of them
     // (a per-env ring of worlds never does)
     const bool uni = c.map_ring == 0 && c.n_maps <= kDynMapBuckets;
-    const dim3 grid((unsigned)((c.n_pad + kDynSortedPad) / kGrp + c.n_pad / 64)); // the full step's waves, then the SAT-only segments
+    const dim3 grid((unsigned)((c.n_pad + kDynSortedPad) / kGrp));
     if (uni) hipLaunchKernelGGL(dyn_step_kernel<true>, grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
     else hipLaunchKernelGGL(dyn_step_kernel<false>, grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
     return hipGetLastError();
@@ -1650,6 +1528,12 @@ __global__ void dyn_invalidate_kernel(const DevCfg c, const uint8_t *__restrict_
     double *row = c.dyn_row + (size_t)e * kDynRow;
     for (int i = 0; i < DC_GOAL_COLS * SSG_MAX_GOALS; ++i) row[i] = c.dyn_f64[(size_t)(DC_GOALS + i) * np + e];
     for (int i = 0; i < 9 * SSG_N_TRAFFIC; ++i) row[kDynRowTraffic + i] = c.dyn_f64[(size_t)(DC_TRAFFIC + i) * np + e];
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) { // ... and the rotations of the (possibly rewritten) angle columns
+        double sa, ca;
+        sincos_body(c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * k + 2) * np + e], &sa, &ca);
+        c.dyn_f64[(size_t)(DC_TROT + 2 * k) * np + e] = ca;
+        c.dyn_f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = sa;
+    }
 }
 
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream)

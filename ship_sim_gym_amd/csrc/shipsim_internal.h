@@ -26,7 +26,9 @@ enum {
     kDynPairs = 54,                                   // ship-bank 6, ship-ship 3, goal-bank 12, goal-ship 18, goal-goal 15
     kPolyPairs = 9,                                   // the first 9 pair ids are polygon pairs (two hashed contacts)
     DC_PREV_GOAL = DC_ARB + 4 * kDynPairs,            // (gx, gy) of the newest frame: the next observation's older frame
-    DC_COUNT = DC_PREV_GOAL + 2
+    DC_TROT = DC_PREV_GOAL + 2,                       // 3 ships x (cos a, sin a) of the angle column: the step kernel's collide_ship
+                                                      // against traffic rebuilds the ship's world hull without a sincos
+    DC_COUNT = DC_TROT + 2 * SSG_N_TRAFFIC
 };
 // u32 columns of the dyn region
 enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* contact hashes, polygon pairs */,
@@ -44,7 +46,6 @@ constexpr int kDynSortedMapShift = 25, kDynSortedEnvMask = (1 << 25) - 1; // a d
 constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
 constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
 constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
-constexpr unsigned long long kDynSatOnly = ~0ull; // queue entry key of a resting env that only needs the player x traffic test
 // sort bucket of an env that is `age` steps into its episode on bank record `map_id`
 __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 {
@@ -88,7 +89,7 @@ struct DevCfg {
     double *dyn_f64;
     uint32_t *dyn_u32;
     unsigned long long *dyn_live; // bit p: pair p has a cached arbiter
-    uint8_t *dyn_flag;            // bit 0: player touches a traffic ship this step (dyn -> step kernel);
+    uint8_t *dyn_flag;            // (bit 0 unused: the step kernel runs collide_ship against the traffic ships itself)
                                   // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
                                   // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
     unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
@@ -100,8 +101,8 @@ struct DevCfg {
     unsigned *dyn_segcnt;         // [n_pad / 64] entries per segment; every producer writes every segment's count
     unsigned *dyn_count;          // [0] length of dyn_sorted incl. its gaps (dyn_sort_kernel writes, the step kernel zeroes); [kDynBucket0 ..) bucket counts
     unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
-    double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2, for the step kernel's classification of resting envs
-    double dyn_hull_r;                // the player's hull radius about its body position
+    double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2: the step kernel's reject in front of collide_ship's exact test
+    double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS]; // the traffic hulls (local), for that test
     int32_t *dyn_sorted;          // [n_pad + kDynSortedPad] the queue ordered by bucket (dyn_sort_kernel), -1 in the gaps: what the full dyn
                                   // step walks (and resets to -1 behind itself)
     double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)

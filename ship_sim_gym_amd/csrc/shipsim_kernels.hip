@@ -216,10 +216,11 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //   gres     [2][EPW] u32   colliding with a bank, by step parity: low half-word = the left bank (role 0), high = the right
 //                           one (role 1) (-> role 3, role 2, the lidar roles)
 //   gdone    [2][EPW] u32   role 3's results of the step, by step parity: bit 0 = no goals left | out of bounds | max_steps,
-//                           bit 1 = the player touches a traffic ship (config 4), bits 2-5 = goal reached, out of bounds,
+//                           (bit 1 unused), bits 2-5 = goal reached, out of bounds,
 //                           max_steps, no goals left, bits 8.. = goals still listed after this step
 //                           (-> role 2: reset decision, reward / done / flags outputs, nearest goal; -> the lidar roles:
 //                           reset decision)
+//   gtraf    [2][EPW] u32   config 4: the player touches a traffic ship (collide_ship, by role 2 before the rendezvous)
 //   sync     [3][EPW/64] u32  per tile: `ready` = number of poses role 3 has published, `ack` = number of pose reads the
 //                           three consumer waves have completed, `bar` = arrivals at the tile's per-step rendezvous
 //   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
@@ -230,11 +231,13 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 __host__ __device__ __forceinline__ constexpr int nb_lo(int nb) { return (nb + 1) / 2; }
 constexpr int kBeamTabBytes = 2 * SSG_MAX_BEAMS * 8;
 constexpr int kShipTabBytes = 6 * 8 * 8;
+constexpr int kTrafficTabBytes = SSG_N_TRAFFIC * 4 * 8 * 8; // config 4: per traffic ship k, [k][0..3][i] = local vertex x, y, plane normal x, y
 constexpr int kPoseDoubles = 7;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
+constexpr int kTrafficScratchBytes = 64 * SSG_N_TRAFFIC * 2 + 64 * 4; // config 4, per observer wave: (lane, ship) pair queue (u16) + hit words
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
-    return kBeamTabBytes + kShipTabBytes + kPoseDoubles * epw * 8 + 6 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * kGoalScratchBytes;
+    return kBeamTabBytes + kShipTabBytes + kTrafficTabBytes + kPoseDoubles * epw * 8 + 8 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * (kGoalScratchBytes + kTrafficScratchBytes);
 }
 __host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
 __host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
@@ -835,15 +838,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *lds_fixed = reinterpret_cast<char *>(lds_base()) + bank_bytes;
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
-    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [7][EPW]
+    double *traffictab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [3][4][8], config 4
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes + kTrafficTabBytes); // [7][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
     int *poser = posem + EPW;                                                                // [EPW]
     unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
     unsigned *gdone = gres + 2 * EPW;                                                        // [2 parities][EPW]
-    unsigned *sync_ready = gdone + 2 * EPW;                                                  // [EPW/64]
+    unsigned *gtraf = gdone + 2 * EPW;                                                       // [2 parities][EPW] config 4: the player touches a traffic ship (role 2 -> all)
+    unsigned *sync_ready = gtraf + 2 * EPW;                                                  // [EPW/64]
     unsigned *sync_ack = sync_ready + EPW / 64;                                              // [EPW/64]
     unsigned *sync_bar = sync_ack + EPW / 64;                                                // [EPW/64] (+ one pad word each)
     char *goal_scratch0 = reinterpret_cast<char *>(sync_bar + 2 * (EPW / 64));
+    char *traffic_scratch0 = goal_scratch0 + (EPW / 64) * kGoalScratchBytes;
     char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
     char *tile_base = scratch0 + (tl >> 6) * lds_tile_bytes(NB); // this env tile's lidar buffers
     // gathered bank: the record heads in LDS (see lds_hdr_bytes); hL = this env's column of the lidar role's copy, hG = of the goals
@@ -873,6 +879,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[0 * 8 + i] = c.hull[2 * i];     shiptab[1 * 8 + i] = c.hull[2 * i + 1];   // vertex i
         shiptab[2 * 8 + i] = c.nrm[2 * i];      shiptab[3 * 8 + i] = c.nrm[2 * i + 1];    // plane normal i
         shiptab[4 * 8 + i] = c.hull[2 * ip];    shiptab[5 * 8 + i] = c.hull[2 * ip + 1];  // vertex i-1 (edge start)
+    }
+    if constexpr (DYN) {
+        if (threadIdx.x >= 160 && threadIdx.x < 160 + SSG_N_TRAFFIC * SSG_SHIP_VERTS) {
+            const int kk = (threadIdx.x - 160) / SSG_SHIP_VERTS, i = (threadIdx.x - 160) % SSG_SHIP_VERTS;
+            traffictab[(kk * 4 + 0) * 8 + i] = c.thull[kk][2 * i]; traffictab[(kk * 4 + 1) * 8 + i] = c.thull[kk][2 * i + 1];
+            traffictab[(kk * 4 + 2) * 8 + i] = c.tnrm[kk][2 * i];  traffictab[(kk * 4 + 3) * 8 + i] = c.tnrm[kk][2 * i + 1];
+        }
     }
     if (threadIdx.x == 128) {
         // lidar origin of a freshly reset ship (angle 0: cpvforangle(0) = (1, 0)): pos + half the world AABB extents,
@@ -956,7 +969,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(1);
             if (k + 1 < K) {
                 // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
-                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 3u)) != 0u);
+                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? gtraf[(k & 1) * EPW + tl] : 0u)) != 0u);
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
                 map_id = rs ? next_map(c, nmap) : nmap;
@@ -972,7 +985,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // A single-step launch: the sticky readings' columns hold exactly the previous frame's values, so "a miss keeps
             // the previous reading" (models.py:68-72) is "a miss stores nothing".  The lidar waves, idle after the step's only
             // rendezvous, store their own beams' hits (or the -1 of a fresh episode) while the observer builds the rows.
-            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 3u)) != 0u);
+            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 1u) | (DYN ? gtraf[tl] : 0u)) != 0u);
             const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(tile_base); // parity 0
             for (int kb = 0; kb < b_count; ++kb) {
                 const int i = b_first + kb;
@@ -1022,6 +1035,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
                 nearest_goal<LDS_BANK, false>(c, map0_ * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0_, pv[0], pv[1], pv[4], pv[5], hG, EPW);
         }
+        const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local): config 4's collide_ship below
+        const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
         const bool hist2 = c.history >= 2;
         ObsTile<NB> ot;
         ot.init(lane);
@@ -1053,8 +1068,97 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const double ang = pose[6 * EPW + tl];
             const int rudder = poser[tl];
             const int map_id = posem[tl];
+            double ca = 1.0, sa = 0.0;
+            if constexpr (DYN) { ca = pose[2 * EPW + tl]; sa = pose[3 * EPW + tl]; }
             ack_pose();
             const int rec_off = map_id * SSG_MAP_STRIDE;
+    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep (the dyn kernels, just
+    // before this launch) left them: cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the
+    // rejects run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world
+    // box is further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass
+    // go into a pair queue of the tile and are served 12 at a time by the whole wave:
+    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.  (Rounds
+    // 2-3 ran this test in the dyn kernels: on every wave of the full step's chain, and in extra workgroups for resting envs.
+    // It runs on the OBSERVER wave, which has nothing to do between the pose hand-over and the rendezvous.)
+            if constexpr (DYN) {
+                bool hit_traffic = false;
+                double sbl, sbr, sbb, sbt;
+                {
+                    double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
+                    ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
+                }
+        const double *tcol = c.dyn_f64 + (size_t)DC_TRAFFIC * np, *trot = c.dyn_f64 + (size_t)DC_TROT * np;
+        unsigned short *tq = reinterpret_cast<unsigned short *>(traffic_scratch0 + (tl >> 6) * kTrafficScratchBytes);
+        unsigned *tw = reinterpret_cast<unsigned *>(tq + 64 * SSG_N_TRAFFIC);
+        tw[lane] = 0u;
+        int n_tp = 0;
+#pragma unroll
+        for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
+            const double tx = tcol[(size_t)(9 * kk) * np + el_], ty = tcol[(size_t)(9 * kk + 1) * np + el_];
+            const double dx = dmax(dmax(sbl - tx, tx - sbr), 0.0), dy = dmax(dmax(sbb - ty, ty - sbt), 0.0);
+            bool cand = false;
+            if (live & ((dx * dx + dy * dy) <= c.dyn_reach2[kk])) {
+                const double tca = trot[(size_t)(2 * kk) * np + el_], tsa = trot[(size_t)(2 * kk + 1) * np + el_];
+                double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
+                    const double gx = traffictab[(kk * 4 + 0) * 8 + i], gy = traffictab[(kk * 4 + 1) * 8 + i];
+                    const double wx = tca * gx + (-tsa) * gy + tx, wy = tsa * gx + tca * gy + ty;
+                    bl = dmin(bl, wx); br = dmax(br, wx); bb = dmin(bb, wy); bt = dmax(bt, wy);
+                }
+                cand = (sbl <= br) & (bl <= sbr) & (sbb <= bt) & (bb <= sbt); // cpBBIntersects(player, ship k)
+            }
+            const unsigned long long m = __ballot(cand);
+            const int pos = n_tp + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (cand) tq[pos] = (unsigned short)(lane | (kk << 6));
+            n_tp += __popcll(m);
+        }
+        for (int base = 0; base < n_tp; base += 12) {
+            const int p = base + wq;
+            const bool valid = (lane < 60) & (p < n_tp);
+            const unsigned code = tq[valid ? p : 0];
+            const int src = code & 63, kk = code >> 6;
+            const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
+            const int esrc = blockIdx.x * EPW + (tl & ~63) + src; // env `src` of this tile (a live one: it queued the pair)
+            const double tx = tcol[(size_t)(9 * kk) * np + esrc], ty = tcol[(size_t)(9 * kk + 1) * np + esrc];
+            const double tca = trot[(size_t)(2 * kk) * np + esrc], tsa = trot[(size_t)(2 * kk + 1) * np + esrc];
+            const double *tt = traffictab + kk * 32;
+            bool sep;
+            {   // axis = the player's edge normal i: every vertex of the ship strictly in front of the player's vertex i?
+                const double nx = bca * w_nx + (-bsa) * w_ny, ny = bsa * w_nx + bca * w_ny;
+                const double vx_ = bca * w_hx + (-bsa) * w_hy + bx, vy_ = bsa * w_hx + bca * w_hy + by;
+                const double off = nx * vx_ + ny * vy_;
+                double mn = INFINITY;
+#pragma unroll
+                for (int j = 0; j < SSG_SHIP_VERTS; ++j) {
+                    const double gx = tt[0 * 8 + j], gy = tt[1 * 8 + j];
+                    const double qx = tca * gx + (-tsa) * gy + tx, qy = tsa * gx + tca * gy + ty;
+                    mn = dmin(mn, nx * qx + ny * qy);
+                }
+                sep = mn > off;
+            }
+            {   // axis = the ship's edge normal i
+                const double lnx = tt[2 * 8 + wi], lny = tt[3 * 8 + wi], lvx = tt[0 * 8 + wi], lvy = tt[1 * 8 + wi];
+                const double nx = tca * lnx + (-tsa) * lny, ny = tsa * lnx + tca * lny;
+                const double vx_ = tca * lvx + (-tsa) * lvy + tx, vy_ = tsa * lvx + tca * lvy + ty;
+                const double off = nx * vx_ + ny * vy_;
+                double mn = INFINITY;
+#pragma unroll
+                for (int j = 0; j < SSG_SHIP_VERTS; ++j) {
+                    const double hx = shiptab[0 * 8 + j], hy = shiptab[1 * 8 + j];
+                    const double qx = bca * hx + (-bsa) * hy + bx, qy = bsa * hx + bca * hy + by;
+                    mn = dmin(mn, nx * qx + ny * qy);
+                }
+                sep |= mn > off;
+            }
+            const unsigned long long ms = __ballot(valid & sep);
+            const bool separated = ((ms >> (5 * wq)) & 31ull) != 0ull;
+            if (valid & (wi == 0) & !separated) atomicOr(&tw[src], 1u);
+        }
+        hit_traffic = tw[lane] != 0u;
+                gtraf[(k & 1) * EPW + tl] = hit_traffic ? 1u : 0u;
+            }
+
             SSG_STAMP_K(1);
             tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
@@ -1067,7 +1171,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // inside a fused launch.
             // =================================================================================================
             const unsigned gd = gdone[(k & 1) * EPW + tl];
-            const bool colliding = (gres[(k & 1) * EPW + tl] != 0u) | ((gd & 2u) != 0u); // collide_ship: a bank, or traffic
+            const bool colliding = (gres[(k & 1) * EPW + tl] != 0u) | (DYN && gtraf[(k & 1) * EPW + tl] != 0u); // collide_ship: a bank, or traffic
             const bool do_reset = auto_reset & (colliding | ((gd & 1u) != 0u));
             // (a launch's last step: role 3, idle by then, writes these after its loop — the observer's tail is what the
             // launch waits for)
@@ -1276,7 +1380,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
     unsigned dflag = 0;
-    if constexpr (DYN) dflag = c.dyn_flag[el_]; // bit 0: the dyn kernels found the player touching a traffic ship
+    if constexpr (DYN) dflag = c.dyn_flag[el_]; // bit 2: the env's other bodies are at rest
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -1349,7 +1453,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const unsigned alive = gm & ((1u << c.n_goals) - 1u);
     const bool done3 = (alive == 0u) | oob_x | oob_y | (steps >= c.max_steps);
     // (the observer, role 2, finds the new frame's nearest goal among the goals this leaves listed)
-    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | ((dflag & 1u) << 1) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
+    gdone[(k & 1) * EPW + tl] = (done3 ? 1u : 0u) | (goal_reached ? 4u : 0u) | ((oob_x | oob_y) ? 8u : 0u) |
                                 ((steps_after >= c.max_steps) ? 16u : 0u) | ((alive == 0u) ? 32u : 0u) | (alive << 8);
     if (k + 1 < K) act_next = actions_kn[(size_t)(k + 1) * c.n_envs + el];
 
@@ -1359,7 +1463,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
     if constexpr (DYN) {
-        colliding |= (dflag & 1u) != 0; // ... and against the traffic ships (dyn kernels)
+        colliding |= gtraf[(k & 1) * EPW + tl] != 0u; // ... and against the traffic ships (role 2)
         if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
     }
 
@@ -1396,11 +1500,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         }
         // Which envs need the full cpSpaceStep of their other bodies NEXT step (shipsim_dynamics.hip)?  Everything that decides
         // it is in this role's registers now: a reset env (fresh bodies), an env whose bodies are not at rest, one that lost a
-        // goal holding a cached arbiter this step.  A resting env whose player will be within reach of a parked
-        // traffic ship after its next cpBodyUpdatePosition is queued for collide_ship's exact test only (dyn_sort_kernel runs it).
-        // The others keep their rest bit, traffic bit clear.  Queue = one segment per tile:
+        // goal holding a cached arbiter this step.  The others keep their rest bit.  Queue = one segment per tile:
         // no atomics to append; the entry carries its sort bucket (steps since the reset, bank record).
-        bool need_full = false, sat_only = false;
+        bool need_full = false;
         if (live) {
             bool resting = !do_reset & ((dflag & 4u) != 0u);
             if (resting & goal_reached) {
@@ -1418,37 +1520,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 }
                 resting = (lv & gone) == 0ull;
             }
-            bool reach = false;
-            if (resting) {
-                // Can the player's hull touch a parked ship after its next cpBodyUpdatePosition?  Every hull vertex moves by at
-                // most |v dt| + (hull radius) |w dt| per axis, so the next hull lies inside this step's world box widened by that;
-                // a parked ship's hull lies inside the circle of its hull radius about its body position.  (A conservative
-                // pre-reject of cpBBIntersects: the exact test decides; tighter than the two hull-radius circles, which put a
-                // quarter of all envs "in reach" of the ship parked in mid-river.)
-                const double wr = c.dyn_hull_r * fabs(w * c.dt);
-                const double mx = fabs(vx * c.dt) + wr, my = fabs(vy * c.dt) + wr;
-#pragma unroll
-                for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
-                    const double tx = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk) * np + el_], ty = c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * kk + 1) * np + el_];
-                    const double dx = dmax(dmax((sbl - mx) - tx, tx - (sbr + mx)), 0.0), dy = dmax(dmax((sbb - my) - ty, ty - (sbt + my)), 0.0);
-                    reach |= (dx * dx + dy * dy) <= c.dyn_reach2[kk];
-                }
-            }
             need_full = !resting;
-            sat_only = resting & reach;
         }
-        const unsigned long long qm = __ballot(need_full | sat_only);
+        const unsigned long long qm = __ballot(need_full);
         const int seg = (blockIdx.x * EPW + tl) >> 6; // this tile's segment (wave-uniform)
         if (lane == 0) c.dyn_segcnt[seg] = (unsigned)__popcll(qm);
-        if (need_full | sat_only) {
+        if (need_full) {
             const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(qm & ((1ull << lane) - 1ull));
-            unsigned long long key = kDynSatOnly; // a resting env within reach of a parked ship: collide_ship's exact test only
-            if (need_full) {
-                const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
-                key = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
-            }
+            const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
             c.dyn_queue[slot] = el_;
-            c.dyn_qkey[slot] = key;
+            c.dyn_qkey[slot] = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
         }
     }
     if (do_reset) {
@@ -1473,7 +1554,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         const int par = (K - 1) & 1;
         const size_t el = (size_t)el_ + (size_t)(K - 1) * (size_t)traj;
         const unsigned gd = gdone[par * EPW + tl];
-        const bool colliding = (gres[par * EPW + tl] != 0u) | ((gd & 2u) != 0u);
+        const bool colliding = (gres[par * EPW + tl] != 0u) | (DYN && gtraf[par * EPW + tl] != 0u);
         const bool goal_reached = (gd & 4u) != 0u;
         double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
         if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;
