@@ -142,8 +142,8 @@ typedef enum ssg_field {
                            v_bias.y, w_bias (cpBody fields of add_default_traffic's ships) */
     SSG_F_GOAL_BODIES,  /* f64 x 8*SSG_MAX_GOALS, n_ships == 4 only: goal g = columns 8g..8g+7: x, y, vx, vy, v_bias.x,
                            v_bias.y, w, w_bias (add_goal's dynamic circle bodies, game.py:77-95) */
-    SSG_F_DYN_FLAGS,    /* u8, n_ships == 4 only: bit 0 = the player touches a traffic ship (input of the step kernel),
-                           bit 1 = bodies to be rebuilt after an in-kernel auto-reset, bit 2 = the traffic ships and
+    SSG_F_DYN_FLAGS,    /* u8, n_ships == 4 only: bit 0 unused (rounds 2-3: the player touches a traffic ship; the step kernel
+                           now runs that test itself), bit 1 = bodies to be rebuilt after an in-kernel auto-reset, bit 2 = the traffic ships and
                            goal bodies are at rest (their cpSpaceStep is skipped as the identity; inspection only) */
     SSG_F_EPISODES,     /* i32: episodes this env has started so far (every reset counts; in map_ring mode episode p lives in
                            bank record e*R + p mod R) */

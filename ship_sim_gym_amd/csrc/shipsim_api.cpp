@@ -267,16 +267,6 @@ int set_traffic(ssg_handle *h)
         d.tx[k] = kTraffic[k][0];
         d.ty[k] = kTraffic[k][1];
     }
-    // furthest hull vertex from the body position, for the conservative reach test of the player x traffic pairs
-    auto hull_radius = [](const double *hull) {
-        double r2 = 0.0;
-        for (int i = 0; i < SSG_SHIP_VERTS; ++i) r2 = std::max(r2, hull[2 * i] * hull[2 * i] + hull[2 * i + 1] * hull[2 * i + 1]);
-        return std::sqrt(r2);
-    };
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-        const double r = (hull_radius(h->cfg.ship_hull) + hull_radius(d.thull[k])) * 1.001 + 1.0;
-        d.reach2[k] = r * r;
-    }
     d.t_m_inv = h->cfg.ship_m_inv;
     // add_goal (game.py:77-95): mass 1, pm.moment_for_circle(1, 0, radius) = m * 0.5 * (r1^2 + r2^2)
     d.goal_m_inv = 1.0 / 1.0;
@@ -352,7 +342,8 @@ void refresh_dev(ssg_handle *h)
     d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
     d.dyn_segcnt = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_segcnt) : nullptr;
-    {   // the step kernel's reach test: (hull radius of traffic ship k, with a margin)^2 and the player's own hull radius
+    {   // the step kernel's reject in front of collide_ship's exact player x traffic test: no vertex of ship k's hull is further than
+        // its hull radius from its body position
         auto radius = [](const double *hull) {
             double r2 = 0.0;
             for (int i = 0; i < SSG_SHIP_VERTS; ++i) r2 = std::max(r2, hull[2 * i] * hull[2 * i] + hull[2 * i + 1] * hull[2 * i + 1]);

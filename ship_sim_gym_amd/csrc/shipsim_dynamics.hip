@@ -7,7 +7,8 @@
 //   cpBodyUpdatePosition (v_bias / w_bias), cpPolyShapeCacheData, cpCollide (GJK + EPA closest points, support-edge
 //   clipping, circle cases), cpArbiterUpdate / PreStep / ApplyCachedImpulse / ApplyImpulse (10 iterations),
 //   cpSpaceArbiterSetFilter (collision persistence 3), cpBodyUpdateVelocity.
-// and the player's `collide_ship` begin-callback against traffic (collision_type 1, models.py:100; game.py:232-241).
+// (The player's `collide_ship` begin-callback against traffic — collision_type 1, models.py:100; game.py:232-241 — is the step
+// kernel's since round 4: it reads the poses, and the rotations of the angle columns, this file's kernels leave behind.)
 //
 // Design (MI355X).  One lane per env, one wave per workgroup.  The work per env is a short, branchy, strictly
 // sequential chain (Gauss-Seidel over at most a handful of contacts), so the kernel is bound by the latency of that
@@ -29,8 +30,8 @@
 //    DevCfg::dyn_queue), sorted by (bank record, steps since the reset) so that the lanes of a wave walk the same path
 //    (dyn_sort_kernel), read through a row-major shadow of the body columns (DevCfg::dyn_row).  Envs whose space is at a
 //    fixed point of cpSpaceStep (the rest bit) are not stepped at all.
-// Per step: dyn_sort_kernel, dyn_step_kernel, then the step kernel, which reads this step's goal positions and the
-// traffic-contact bit from the dyn columns (DevCfg::dyn_*) and queues the envs for the next step.
+// Per step: dyn_sort_kernel, dyn_step_kernel, then the step kernel, which reads this step's goal and traffic positions from
+// the dyn columns (DevCfg::dyn_*) and queues the envs for the next step.
 //
 // The canonical pair order, the cold GJK start and the unsolved player arbiters are the named assumptions of the
 // oracle (oracle/ssg_dynamics.c header); this file follows the same ones.
@@ -598,8 +599,8 @@ __device__ __forceinline__ void stage_hulls(const DevCfg &c, const DynCfg &d, in
 // mask -- the space is at a fixed point: the next step is the identity.  (That is how a ship resting against a bank
 // ends up: the penetration left beyond the slop shrinks by 99.8 % per step until position + bias*dt rounds to the
 // position.)  The full step records that as the rest bit (with the bank generation it holds for); while it stands,
-// these bodies are skipped and only the player's collide_ship test against the parked traffic is left.  A caller
-// that writes the body columns itself must clear the bit with ssg_dyn_invalidate.
+// these bodies are skipped (the player's collide_ship test against the parked traffic runs in the step kernel, every step,
+// for every env).  A caller that writes the body columns itself must clear the bit with ssg_dyn_invalidate.
 // Everything else is appended to the queue of the full step.  In steady state that is the few steps after each reset in
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------

@@ -115,7 +115,6 @@ struct DynCfg {
     double goal_m_inv, goal_i_inv;
     double ship_friction;  // 0.7 (models.py:98); banks and goals keep Chipmunk's default 0
     double bias_coef, slop; // 1 - pow(collisionBias, dt), collisionSlop
-    double reach2[SSG_N_TRAFFIC]; // (player hull radius + ship k hull radius + margin)^2 about the body positions
     unsigned bank_epoch;    // bumped whenever the map bank changes: part of the pose hash
     int stop_after;         // development aid (SSG_DYN_STOP): leave the dyn kernel after phase n; 0 = run it all
 };

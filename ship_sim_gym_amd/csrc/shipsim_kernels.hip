@@ -964,123 +964,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // first step the lidar waves have just finished the first query and would idle until B)
             reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
                     bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
-            SSG_STAMP_K(3);
-            tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
-            SSG_STAMP_K(1);
-            if (k + 1 < K) {
-                // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
-                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? gtraf[(k & 1) * EPW + tl] : 0u)) != 0u);
-                ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
-                cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
-                map_id = rs ? next_map(c, nmap) : nmap;
-                if constexpr (!LDS_BANK) {
-                    if (rs) load_hdr_lidar(map_id * SSG_MAP_STRIDE); // only the lanes whose env moved to its next record gather
-                }
-                lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base + ((k + 1) & 1) * lds_res_bytes(NB)),
-                                                 queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
-            }
-            SSG_STAMP_K(2);
-        }
-        if (K == 1 && live) {
-            // A single-step launch: the sticky readings' columns hold exactly the previous frame's values, so "a miss keeps
-            // the previous reading" (models.py:68-72) is "a miss stores nothing".  The lidar waves, idle after the step's only
-            // rendezvous, store their own beams' hits (or the -1 of a fresh episode) while the observer builds the rows.
-            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 1u) | (DYN ? gtraf[tl] : 0u)) != 0u);
-            const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(tile_base); // parity 0
-            for (int kb = 0; kb < b_count; ++kb) {
-                const int i = b_first + kb;
-                const unsigned long long key = rk[i * 64 + lane];
-                const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
-                if (rs | (key != kLidarMiss)) st_out(&colLid[(size_t)i * np + el_], rs ? -1.0 : hitd);
-            }
-        }
-        SSG_STAMP(10);
-        SSG_STAMP_FLUSH(3);
-        return;
-    }
-
-    const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
-
-    if (role == 2) {
-        // =====================================================================================================
-        // ROLE 2: the OBSERVER of every step
-        // =====================================================================================================
-        // The observer's previous frame (ship_env.py:79-113: [x, y, rudder, angle, goal x, goal y, L...]) of the first step =
-        // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
-        constexpr int F = 6 + NB;
-        double pv[F];
-        {
-            const int el = el_;
-            const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
-            const int rud0 = colRud[el], map0 = colMap[el];
-            const unsigned gm0 = c.mask[el];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) pv[6 + i] = colLid[(size_t)i * np + el];
-            pv[0] = x0; pv[1] = y0; pv[2] = (double)rud0; pv[3] = a0;
-            if constexpr (DYN) {
-                // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
-                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el];
-                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[i])); // (in registers before barrier 0, as role 3's state)
-#pragma unroll
-            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(pv[6 + i]));
-            if constexpr (DYN) asm volatile("" : "+v"(pv[4]), "+v"(pv[5]));
-            int map0_ = map0; unsigned gm0_ = gm0;
-            asm volatile("" : "+v"(map0_), "+v"(gm0_));
-            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads(); // barrier 0
-            SSG_STAMP(9);
-            if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
-                nearest_goal<LDS_BANK, false>(c, map0_ * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0_, pv[0], pv[1], pv[4], pv[5], hG, EPW);
-        }
-        const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local): config 4's collide_ship below
-        const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
-        const bool hist2 = c.history >= 2;
-        ObsTile<NB> ot;
-        ot.init(lane);
-        constexpr int kObsPasses = (2 * F + ObsTile<NB>::CP - 1) / ObsTile<NB>::CP; // passes of the widest row
-        // A launch ends with the observer's rows of its LAST step (nobody is left to overlap them with).  Half of such a row
-        // is the previous frame, in this wave's registers since the step before: on the last step those columns go out
-        // EARLY, while the body role still integrates — speculatively, because an env that turns out to be done at this step
-        // shows a history of -1 instead (ShipEnv.reset); its lanes rewrite their 6 + NB doubles after the rendezvous.
-        // (Only when the previous frame is a whole number of column passes: 8 and 10 beams are.)
-        constexpr bool kSplitOk = (F % ObsTile<NB>::CP) == 0;
-        const bool split_last = kSplitOk && hist2 && c.history == 2 && !SSG_ABL(7);
-        for (int k = 0; k < K; ++k) {
-            const bool early = split_last && (k == K - 1);
-            if constexpr (kSplitOk) {
-                if (early) {
-                    int tw = __builtin_amdgcn_readfirstlane(tl >> 6);
-                    int te0 = blockIdx.x * EPW + 64 * tw;
-                    asm volatile("" : "+s"(tw), "+s"(te0));
-                    // the other parity's result buffer: emptied by this wave a step ago, written again only after B(k)
-                    double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + ((k + 1) & 1) * lds_res_bytes(NB));
-                    double *__restrict__ ob = obs + ((size_t)te0 + (size_t)k * (size_t)traj) * (size_t)(2 * F);
-                    write_obs_tile<NB, true, 0, F / ObsTile<NB>::CP>(ot, colbuf, [&](int j) -> double { return pv[(j < F) ? j : 0]; }, ob,
-                                                                    min(64, c.n_envs - te0), lane);
-                }
-            }
-            wait_pose(k);
-            SSG_STAMP_K(0);
-            const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl];
-            const double ang = pose[6 * EPW + tl];
-            const int rudder = poser[tl];
-            const int map_id = posem[tl];
-            double ca = 1.0, sa = 0.0;
-            if constexpr (DYN) { ca = pose[2 * EPW + tl]; sa = pose[3 * EPW + tl]; }
-            ack_pose();
-            const int rec_off = map_id * SSG_MAP_STRIDE;
-    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep (the dyn kernels, just
-    // before this launch) left them: cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the
-    // rejects run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world
-    // box is further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass
-    // go into a pair queue of the tile and are served 12 at a time by the whole wave:
-    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.  (Rounds
-    // 2-3 ran this test in the dyn kernels: on every wave of the full step's chain, and in extra workgroups for resting envs.
-    // It runs on the OBSERVER wave, which has nothing to do between the pose hand-over and the rendezvous.)
-            if constexpr (DYN) {
+            if (DYN && role == 1) {
+                const int wq = lane / 5, wi = lane - 5 * wq;
+                const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi], w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi];
+                const double x = npx, y = npy, ca = nca, sa = nsa;
                 bool hit_traffic = false;
                 double sbl, sbr, sbb, sbt;
                 {
@@ -1159,6 +1046,118 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 gtraf[(k & 1) * EPW + tl] = hit_traffic ? 1u : 0u;
             }
 
+            SSG_STAMP_K(3);
+            tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
+            SSG_STAMP_K(1);
+            if (k + 1 < K) {
+                // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
+                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? gtraf[(k & 1) * EPW + tl] : 0u)) != 0u);
+                ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
+                cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
+                map_id = rs ? next_map(c, nmap) : nmap;
+                if constexpr (!LDS_BANK) {
+                    if (rs) load_hdr_lidar(map_id * SSG_MAP_STRIDE); // only the lanes whose env moved to its next record gather
+                }
+                lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base + ((k + 1) & 1) * lds_res_bytes(NB)),
+                                                 queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
+            }
+            SSG_STAMP_K(2);
+        }
+        if (K == 1 && live) {
+            // A single-step launch: the sticky readings' columns hold exactly the previous frame's values, so "a miss keeps
+            // the previous reading" (models.py:68-72) is "a miss stores nothing".  The lidar waves, idle after the step's only
+            // rendezvous, store their own beams' hits (or the -1 of a fresh episode) while the observer builds the rows.
+            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 1u) | (DYN ? gtraf[tl] : 0u)) != 0u);
+            const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(tile_base); // parity 0
+            for (int kb = 0; kb < b_count; ++kb) {
+                const int i = b_first + kb;
+                const unsigned long long key = rk[i * 64 + lane];
+                const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
+                if (rs | (key != kLidarMiss)) st_out(&colLid[(size_t)i * np + el_], rs ? -1.0 : hitd);
+            }
+        }
+        SSG_STAMP(10);
+        SSG_STAMP_FLUSH(3);
+        return;
+    }
+
+    const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
+
+    if (role == 2) {
+        // =====================================================================================================
+        // ROLE 2: the OBSERVER of every step
+        // =====================================================================================================
+        // The observer's previous frame (ship_env.py:79-113: [x, y, rudder, angle, goal x, goal y, L...]) of the first step =
+        // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
+        constexpr int F = 6 + NB;
+        double pv[F];
+        {
+            const int el = el_;
+            const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
+            const int rud0 = colRud[el], map0 = colMap[el];
+            const unsigned gm0 = c.mask[el];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) pv[6 + i] = colLid[(size_t)i * np + el];
+            pv[0] = x0; pv[1] = y0; pv[2] = (double)rud0; pv[3] = a0;
+            if constexpr (DYN) {
+                // goals move in config 4: the previous frame's goal cannot be recomputed, it is kept in two columns
+                pv[4] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el];
+                pv[5] = c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[i])); // (in registers before barrier 0, as role 3's state)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(pv[6 + i]));
+            if constexpr (DYN) asm volatile("" : "+v"(pv[4]), "+v"(pv[5]));
+            int map0_ = map0; unsigned gm0_ = gm0;
+            asm volatile("" : "+v"(map0_), "+v"(gm0_));
+            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads(); // barrier 0
+            SSG_STAMP(9);
+            if constexpr (!DYN) // closest_goal (game.py:333-349) from the pre-step position
+                nearest_goal<LDS_BANK, false>(c, map0_ * SSG_MAP_STRIDE + SSG_MAP_OFF_GOALS, gm0_, pv[0], pv[1], pv[4], pv[5], hG, EPW);
+        }
+        const bool hist2 = c.history >= 2;
+        ObsTile<NB> ot;
+        ot.init(lane);
+        constexpr int kObsPasses = (2 * F + ObsTile<NB>::CP - 1) / ObsTile<NB>::CP; // passes of the widest row
+        // A launch ends with the observer's rows of its LAST step (nobody is left to overlap them with).  Half of such a row
+        // is the previous frame, in this wave's registers since the step before: on the last step those columns go out
+        // EARLY, while the body role still integrates — speculatively, because an env that turns out to be done at this step
+        // shows a history of -1 instead (ShipEnv.reset); its lanes rewrite their 6 + NB doubles after the rendezvous.
+        // (Only when the previous frame is a whole number of column passes: 8 and 10 beams are.)
+        constexpr bool kSplitOk = (F % ObsTile<NB>::CP) == 0;
+        const bool split_last = kSplitOk && hist2 && c.history == 2 && !SSG_ABL(7);
+        for (int k = 0; k < K; ++k) {
+            const bool early = split_last && (k == K - 1);
+            if constexpr (kSplitOk) {
+                if (early) {
+                    int tw = __builtin_amdgcn_readfirstlane(tl >> 6);
+                    int te0 = blockIdx.x * EPW + 64 * tw;
+                    asm volatile("" : "+s"(tw), "+s"(te0));
+                    // the other parity's result buffer: emptied by this wave a step ago, written again only after B(k)
+                    double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + ((k + 1) & 1) * lds_res_bytes(NB));
+                    double *__restrict__ ob = obs + ((size_t)te0 + (size_t)k * (size_t)traj) * (size_t)(2 * F);
+                    write_obs_tile<NB, true, 0, F / ObsTile<NB>::CP>(ot, colbuf, [&](int j) -> double { return pv[(j < F) ? j : 0]; }, ob,
+                                                                    min(64, c.n_envs - te0), lane);
+                }
+            }
+            wait_pose(k);
+            SSG_STAMP_K(0);
+            const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl];
+            const double ang = pose[6 * EPW + tl];
+            const int rudder = poser[tl];
+            const int map_id = posem[tl];
+            ack_pose();
+            const int rec_off = map_id * SSG_MAP_STRIDE;
+    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep (the dyn kernels, just
+    // before this launch) left them: cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the
+    // rejects run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world
+    // box is further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass
+    // go into a pair queue of the tile and are served 12 at a time by the whole wave:
+    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.  (Rounds
+    // 2-3 ran this test in the dyn kernels: on every wave of the full step's chain, and in extra workgroups for resting envs.
+    // It runs on the OBSERVER wave, which has nothing to do between the pose hand-over and the rendezvous.)
             SSG_STAMP_K(1);
             tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
