@@ -1379,7 +1379,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
     unsigned dflag = 0;
-    if constexpr (DYN) dflag = c.dyn_flag[el_]; // bit 2: the env's other bodies are at rest
+    unsigned long long dlive = 0ull; // config 4: the env's cached arbiters (asked for here: where the classification needs it —
+                                     // a resting env that reached a goal — the load was a dependent round trip after the rendezvous)
+    if constexpr (DYN) { dflag = c.dyn_flag[el_]; dlive = c.dyn_live[el_]; } // bit 2 of the flag: the env's other bodies are at rest
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -1507,7 +1509,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (resting & goal_reached) {
                 // the goal(s) reached this step leave the space: the rest state survives unless one of them had a cached arbiter
                 // (pair ids of shipsim_dynamics.hip: goal g x bank s = 9 + 2g + s, goal g x ship k = 21 + 3g + k, goals h < g = 39 + g(g-1)/2 + h)
-                const unsigned long long lv = c.dyn_live[el_];
+                const unsigned long long lv = dlive;
                 unsigned long long gone = 0ull;
                 const unsigned removed = ~gm & ((1u << c.n_goals) - 1u);
                 for (int g = 0; g < c.n_goals; ++g) {
