@@ -181,6 +181,24 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
     }
 }
 
+// The same over goal centres held in registers (config 4: gp[2g], gp[2g+1], requested in one batch at the head of the launch).
+__device__ __forceinline__ void nearest_goal_regs(int n_goals, unsigned gm, double x, double y, const double *gp, double &gx, double &gy)
+{
+    gx = -1.0;
+    gy = -1.0;
+    double best = INFINITY;
+#pragma unroll
+    for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+        const double px = gp[2 * g], py = gp[2 * g + 1];
+        const double dx = px - x, dy = py - y;
+        const double d = dx * dx + dy * dy;
+        const bool take = (g < n_goals) & (bool)((gm >> g) & 1u) & (d < best);
+        best = take ? d : best;
+        gx = take ? px : gx;
+        gy = take ? py : gy;
+    }
+}
+
 // The bank record an env moves to when ShipGame.reset gives it its next world: the next record of the shared bank, or —
 // map_ring mode — the next record of the env's own ring [base, base + R).
 __device__ __forceinline__ int next_map(const DevCfg &c, int map_id)
@@ -807,8 +825,12 @@ template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
 __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
                                                        uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out,
-                                                       const int K, const long long traj)
+                                                       const int K_launch, const long long traj)
 {
+    // (config 4 steps its dyn kernels between any two steps: its launches are single steps, and the compiler is told so — the
+    // body role's queue entry, a returning atomic, otherwise counts as live around the step loop and is spilled, i.e. waited
+    // for, the moment it is issued)
+    const int K = DYN ? 1 : K_launch;
     // K consecutive steps in one launch (K = 1 for ssg_step): the bank is staged once and role 3 keeps the body state in
     // registers.  Step k reads actions_kn + k*n_envs and writes its obs / reward / done / flags `k * traj` env rows past the
     // buffers' starts: traj = 0 rewrites the same [n_envs] rows every step (ssg_rollout), traj >= n_envs lays the steps of
@@ -926,66 +948,37 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             __builtin_amdgcn_s_sleep(1);
     };
 
-    if (role < 2) {
-        // =====================================================================================================
-        // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step)
-        // =====================================================================================================
-        unsigned short *queue = reinterpret_cast<unsigned short *>(tile_base + 2 * lds_res_bytes(NB) + role * lds_queue_bytes(NB0));
-        const int b_first = role ? NB0 : 0, b_count = role ? (NB - NB0) : NB0;
-        // the first step's pre-step pose comes from the state columns
-        double ca, sa, cx, cy;
-        int map_id;
-        {
-            const double x = colX[el_], y = colY[el_], ang = colA[el_];
-            map_id = colMap[el_];
-            if constexpr (!LDS_BANK) load_hdr_lidar(map_id * SSG_MAP_STRIDE);
-            { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; } // body->transform rotation
-            if (role == 0) { pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa; } // -> role 3: the first step's thrust direction
-            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
-            __syncthreads();                             // barrier 0: bank + tables visible
-            SSG_STAMP(9);
-            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], bl, br, bb, bt;
-            ship_world(shiptab, ca, sa, x, y, swx, swy, bl, br, bb, bt);
-            cx = x + (br - bl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
-            cy = y + (bt - bb) / 2;
-        }
-        // the first step's query needs nothing from role 3: it runs while role 3 integrates
-        lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first, b_count,
-                                         cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
-        for (int k = 0; k < K; ++k) {
-            wait_pose(k); // role 3 has published this step's post-step pose
-            SSG_STAMP_K(0);
-            const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
-            const double ncx = pose[4 * EPW + tl], ncy = pose[5 * EPW + tl];
-            const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
-            const int nmap = posem[tl];
-            ack_pose();
-            // collide_ship of this step, one bank hull per lidar role (role 2 is writing the previous step's rows; in a launch's
-            // first step the lidar waves have just finished the first query and would idle until B)
-            reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
-                    bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
-            if (DYN && role == 1) {
+    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep (the dyn kernels, just
+    // before this launch) left them: cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the
+    // rejects run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world
+    // box is further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass
+    // go into a pair queue of the tile and are served 12 at a time by the whole wave:
+    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.  (Rounds
+    // 2-3 ran this test in the dyn kernels: on every wave of the full step's chain, and in extra workgroups for resting envs.
+    // It runs on the lidar-hi wave, after its bank hull: that wave is then the last to reach the rendezvous, by ~4 k cycles; on
+    // the OBSERVER wave, idle between the pose hand-over and the rendezvous, the rendezvous came 3 k cycles earlier and the step
+    // 0.6 us later — holding the ships' 12 doubles next to its two frames, that wave spilled 32 registers into its tail, which
+    // is the end of the launch.)
+    auto traffic_collide = [&](const double *tpre, double x, double y, double ca, double sa, int k_) {
                 const int wq = lane / 5, wi = lane - 5 * wq;
                 const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi], w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi];
-                const double x = npx, y = npy, ca = nca, sa = nsa;
                 bool hit_traffic = false;
                 double sbl, sbr, sbb, sbt;
                 {
                     double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
                     ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
                 }
-        const double *tcol = c.dyn_f64 + (size_t)DC_TRAFFIC * np, *trot = c.dyn_f64 + (size_t)DC_TROT * np;
         unsigned short *tq = reinterpret_cast<unsigned short *>(traffic_scratch0 + (tl >> 6) * kTrafficScratchBytes);
         unsigned *tw = reinterpret_cast<unsigned *>(tq + 64 * SSG_N_TRAFFIC);
         tw[lane] = 0u;
         int n_tp = 0;
 #pragma unroll
         for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
-            const double tx = tcol[(size_t)(9 * kk) * np + el_], ty = tcol[(size_t)(9 * kk + 1) * np + el_];
+            const double tx = tpre[4 * kk + 0], ty = tpre[4 * kk + 1];
             const double dx = dmax(dmax(sbl - tx, tx - sbr), 0.0), dy = dmax(dmax(sbb - ty, ty - sbt), 0.0);
             bool cand = false;
             if (live & ((dx * dx + dy * dy) <= c.dyn_reach2[kk])) {
-                const double tca = trot[(size_t)(2 * kk) * np + el_], tsa = trot[(size_t)(2 * kk + 1) * np + el_];
+                const double tca = tpre[4 * kk + 2], tsa = tpre[4 * kk + 3];
                 double bl = INFINITY, br = -INFINITY, bb = INFINITY, bt = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < SSG_SHIP_VERTS; ++i) {
@@ -1006,9 +999,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const unsigned code = tq[valid ? p : 0];
             const int src = code & 63, kk = code >> 6;
             const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
-            const int esrc = blockIdx.x * EPW + (tl & ~63) + src; // env `src` of this tile (a live one: it queued the pair)
-            const double tx = tcol[(size_t)(9 * kk) * np + esrc], ty = tcol[(size_t)(9 * kk + 1) * np + esrc];
-            const double tca = trot[(size_t)(2 * kk) * np + esrc], tsa = trot[(size_t)(2 * kk + 1) * np + esrc];
+            // the source lane holds its env's ships
+            double tx = __shfl(tpre[0], src), ty = __shfl(tpre[1], src), tca = __shfl(tpre[2], src), tsa = __shfl(tpre[3], src);
+#pragma unroll
+            for (int h = 1; h < SSG_N_TRAFFIC; ++h) {
+                const double a0 = __shfl(tpre[4 * h + 0], src), a1 = __shfl(tpre[4 * h + 1], src);
+                const double a2 = __shfl(tpre[4 * h + 2], src), a3 = __shfl(tpre[4 * h + 3], src);
+                tx = (kk == h) ? a0 : tx; ty = (kk == h) ? a1 : ty; tca = (kk == h) ? a2 : tca; tsa = (kk == h) ? a3 : tsa;
+            }
             const double *tt = traffictab + kk * 32;
             bool sep;
             {   // axis = the player's edge normal i: every vertex of the ship strictly in front of the player's vertex i?
@@ -1043,8 +1041,69 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (valid & (wi == 0) & !separated) atomicOr(&tw[src], 1u);
         }
         hit_traffic = tw[lane] != 0u;
-                gtraf[(k & 1) * EPW + tl] = hit_traffic ? 1u : 0u;
+                gtraf[(k_ & 1) * EPW + tl] = hit_traffic ? 1u : 0u;
+    };
+    if (role < 2) {
+        // =====================================================================================================
+        // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step)
+        // =====================================================================================================
+        unsigned short *queue = reinterpret_cast<unsigned short *>(tile_base + 2 * lds_res_bytes(NB) + role * lds_queue_bytes(NB0));
+        const int b_first = role ? NB0 : 0, b_count = role ? (NB - NB0) : NB0;
+        // the first step's pre-step pose comes from the state columns
+        double ca, sa, cx, cy;
+        int map_id;
+        double tpre[DYN ? 4 * SSG_N_TRAFFIC : 1];
+        {
+            const double x = colX[el_], y = colY[el_], ang = colA[el_];
+            map_id = colMap[el_];
+            if constexpr (!LDS_BANK) load_hdr_lidar(map_id * SSG_MAP_STRIDE);
+            { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; } // body->transform rotation
+            if (role == 0) { pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa; } // -> role 3: the first step's thrust direction
+            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
+            __syncthreads();                             // barrier 0: bank + tables visible
+            SSG_STAMP(9);
+            if constexpr (DYN) {
+                // The traffic ships' positions and rotations of this step (the dyn kernels' output), asked for in one batch under
+                // the first query: read where they are used, they were two dependent round trips per ship between the bank hull
+                // and the rendezvous.  (Asked for BEFORE barrier 0, with the state, they delayed the barrier for every role: the
+                // whole grid starts at once and the extra megabytes queue up behind the bank's staging.)
+                if (role == 1) {
+                    const double *tcol = c.dyn_f64 + (size_t)DC_TRAFFIC * np, *trot = c.dyn_f64 + (size_t)DC_TROT * np;
+#pragma unroll
+                    for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
+                        tpre[4 * kk + 0] = tcol[(size_t)(9 * kk) * np + el_]; tpre[4 * kk + 1] = tcol[(size_t)(9 * kk + 1) * np + el_];
+                        tpre[4 * kk + 2] = trot[(size_t)(2 * kk) * np + el_]; tpre[4 * kk + 3] = trot[(size_t)(2 * kk + 1) * np + el_];
+                    }
+                }
             }
+            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS], bl, br, bb, bt;
+            ship_world(shiptab, ca, sa, x, y, swx, swy, bl, br, bb, bt);
+            cx = x + (br - bl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
+            cy = y + (bt - bb) / 2;
+        }
+        // the first step's query needs nothing from role 3: it runs while role 3 integrates
+        lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first, b_count,
+                                         cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
+        for (int k = 0; k < K; ++k) {
+            wait_pose(k); // role 3 has published this step's post-step pose
+            if constexpr (DYN) {
+                if (role == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4 * SSG_N_TRAFFIC; ++i) asm volatile("" : "+v"(tpre[i]));
+                }
+            }
+            SSG_STAMP_K(0);
+            const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
+            const double ncx = pose[4 * EPW + tl], ncy = pose[5 * EPW + tl];
+            const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
+            const int nmap = posem[tl];
+            ack_pose();
+            // collide_ship of this step, one bank hull per lidar role (role 2 is writing the previous step's rows; in a launch's
+            // first step the lidar waves have just finished the first query and would idle until B)
+            reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
+                    bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
+            SSG_STAMP_K(4);
+            if (DYN && role == 1) traffic_collide(tpre, npx, npy, nca, nsa, k);
 
             SSG_STAMP_K(3);
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
@@ -1091,6 +1150,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // the pre-step state: what the last step of the previous launch, or the reset, left in the state columns.
         constexpr int F = 6 + NB;
         double pv[F];
+        double ogp[DYN ? 2 * SSG_MAX_GOALS : 1];
         {
             const int el = el_;
             const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
@@ -1142,7 +1202,21 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                                                                     min(64, c.n_envs - te0), lane);
                 }
             }
+            if constexpr (DYN) {
+                // This step's goal centres (the dyn kernels' output), asked for in one batch while the body role integrates: read
+                // goal by goal in closest_goal, each was a dependent round trip in this wave's tail, the end of the launch.
+#pragma unroll
+                for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+                    const bool listed = g < c.n_goals;
+                    ogp[2 * g] = listed ? goal_at<LDS_BANK, DYN>(c, el_, g, 0) : 0.0;
+                    ogp[2 * g + 1] = listed ? goal_at<LDS_BANK, DYN>(c, el_, g, 1) : 0.0;
+                }
+            }
             wait_pose(k);
+            if constexpr (DYN) {
+#pragma unroll
+                for (int g = 0; g < 2 * SSG_MAX_GOALS; ++g) asm volatile("" : "+v"(ogp[g]));
+            }
             SSG_STAMP_K(0);
             const double x = pose[0 * EPW + tl], y = pose[1 * EPW + tl];
             const double ang = pose[6 * EPW + tl];
@@ -1150,14 +1224,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const int map_id = posem[tl];
             ack_pose();
             const int rec_off = map_id * SSG_MAP_STRIDE;
-    // config 4: collide_ship (game.py:232-241) against the traffic ships, where this step's cpSpaceStep (the dyn kernels, just
-    // before this launch) left them: cpBBIntersects, then "touching counts" SAT over both hulls' edge normals.  Per lane only the
-    // rejects run — no vertex of ship k's hull is further than its hull radius from its body position, so a player whose world
-    // box is further than that from the position cannot touch it; then the exact box test — and the (lane, ship) pairs that pass
-    // go into a pair queue of the tile and are served 12 at a time by the whole wave:
-    // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.  (Rounds
-    // 2-3 ran this test in the dyn kernels: on every wave of the full step's chain, and in extra workgroups for resting envs.
-    // It runs on the OBSERVER wave, which has nothing to do between the pose hand-over and the rendezvous.)
             SSG_STAMP_K(1);
             tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
@@ -1195,7 +1261,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(4);
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
             double nf_gx = 0, nf_gy = 0;
-            if (!SSG_ABL(0)) nearest_goal<LDS_BANK, DYN>(c, DYN ? el_ : rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
+            if constexpr (DYN) nearest_goal_regs(c.n_goals, gd >> 8, x, y, ogp, nf_gx, nf_gy);
+            else if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
             SSG_STAMP_K(5);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
@@ -1214,12 +1281,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             nv[3] = do_reset ? 0.0 : ang;
             nv[4] = do_reset ? rs_gx : nf_gx;
             nv[5] = do_reset ? rs_gy : nf_gy;
-            if constexpr (DYN) { // the newest frame's goal: the next observation's older frame (goals move: kept in two columns)
-                if (live) {
-                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = nv[4];
-                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = nv[5];
-                }
-            }
             {
                 const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(res_k);
 #pragma unroll
@@ -1241,15 +1302,19 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                     // the sticky columns, and the other parity's buffer is free)
                     double *colbuf = reinterpret_cast<double *>((K == 1) ? res_k + lds_res_bytes(NB) : res_k);
                     if (kSplitOk && early) {
-                        write_obs_tile<NB, true, kSplitOk ? F / ObsTile<NB>::CP : 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
-                            return nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
-                        if (__any(do_reset)) { // the history of an env that starts a new episode: -1 over what went out early
+                        // the history of an env that starts a new episode: -1 over what went out early.  BEFORE this step's own
+                        // stores: the early ones were issued a rendezvous ago and the wait below is for nothing, where after the
+                        // new frame's stores it drained them too — a tile's whole write burst, at the moment every tile of the
+                        // grid writes
+                        if (__any(do_reset)) {
                             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the early stores of these addresses have completed
                             if (do_reset && lane < rows_live) {
 #pragma unroll
                                 for (int j = 0; j < F; ++j) st_out(&obase[(unsigned)(lane * 2 * F + j)], -1.0);
                             }
                         }
+                        write_obs_tile<NB, true, kSplitOk ? F / ObsTile<NB>::CP : 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
+                            return nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
                     } else if (hist2)
                         write_obs_tile<NB, true, 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
                             return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
@@ -1259,6 +1324,12 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 }
             }
             SSG_STAMP_K(7);
+            if constexpr (DYN) { // the newest frame's goal: the next observation's older frame (goals move: kept in two columns)
+                if (live) {
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 0) * np + el_] = nv[4];
+                    c.dyn_f64[(size_t)(DC_PREV_GOAL + 1) * np + el_] = nv[5];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < F; ++i) pv[i] = nv[i];
             if (k == K - 1 && K > 1 && live && !SSG_ABL(9)) { // the sticky readings go back to the state columns with the last step
@@ -1289,6 +1360,28 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // (gathered bank: this env's goal centres -> LDS, before barrier 0)
     int act_next = actions_kn[el_]; // step k+1's action is requested a rendezvous ahead of its use
+    // Config 4: the goal circles are dynamic bodies whose centres the dyn kernel left in the env's columns before this launch
+    // (a DYN launch is one step).  All of them are asked for in one batch right after barrier 0 and are there when the
+    // integration is done: read goal by goal where they are used, each was a round trip of its own on the critical path to
+    // rendezvous B.
+    double gpre[DYN ? 2 * SSG_MAX_GOALS : 1];
+    unsigned dflag = 0;
+    unsigned long long dlive = 0ull; // the env's cached arbiters (needed by the classification of a resting env that reached a goal)
+    auto ask_goals = [&]() {
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+            const bool listed = g < c.n_goals;
+            gpre[2 * g] = listed ? goal_at<LDS_BANK, DYN>(c, el_, g, 0) : 0.0;
+            gpre[2 * g + 1] = listed ? goal_at<LDS_BANK, DYN>(c, el_, g, 1) : 0.0;
+        }
+        dflag = c.dyn_flag[el_]; // bit 2 of the flag: the env's other bodies are at rest
+        dlive = c.dyn_live[el_];
+    };
+    auto have_goals = [&]() {
+#pragma unroll
+        for (int g = 0; g < 2 * SSG_MAX_GOALS; ++g) asm volatile("" : "+v"(gpre[g]));
+        asm volatile("" : "+v"(dflag), "+v"(dlive));
+    };
     // (the state is wanted in registers BEFORE barrier 0, under the bank's staging: left to itself the compiler sinks the
     // loads below the barrier and the first step starts a memory round trip late)
     asm volatile("" : "+v"(x), "+v"(y), "+v"(vx), "+v"(vy), "+v"(ang), "+v"(w), "+v"(cum));
@@ -1296,12 +1389,16 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
     __syncthreads();                             // barrier 0: bank + tables + role 0's initial rotation visible
     SSG_STAMP(9);
+    if constexpr (DYN) ask_goals();
     const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi]; // ship vertex i (local)
     const double w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi]; // ship plane normal i (local)
 #ifdef SSG_PRIO
     __builtin_amdgcn_s_setprio(SSG_PRIO);
 #endif
 
+    bool q_need = false; // config 4: this env's entry in the next step's queue (see the classification after the rendezvous)
+    unsigned q_slot = 0, q_arrival = 0;
+    unsigned long long q_key = 0ull;
     for (int k = 0; k < K; ++k) {
 #ifdef SSG_STAMPS_ITER
     if (k < 8) SSG_STAMP(k); // (diagnostic: when does each of a launch's first 8 steps start, and the last one?)
@@ -1375,13 +1472,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     SSG_STAMP_K(1);
     if (lane == 0) __hip_atomic_store(&sync_ready[tile], (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     SSG_STAMP_K(2);
+    if constexpr (DYN) have_goals();
 
     const bool oob_x = (x < 0.0) | (x > c.width);
     const bool oob_y = (y < 0.0) | (y > c.height);
-    unsigned dflag = 0;
-    unsigned long long dlive = 0ull; // config 4: the env's cached arbiters (asked for here: where the classification needs it —
-                                     // a resting env that reached a goal — the load was a dependent round trip after the rendezvous)
-    if constexpr (DYN) { dflag = c.dyn_flag[el_]; dlive = c.dyn_live[el_]; } // bit 2 of the flag: the env's other bodies are at rest
 
     // player <-> goal circles: collide_goal (game.py:243-257).  Contact iff cpPolyShapePointQuery distance of the
     // centre to the ship hull <= radius (negative inside), after the cpBBIntersects reject.
@@ -1407,6 +1501,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 #pragma unroll
             for (int g = 0; g < SSG_MAX_GOALS; ++g)
                 if (g < c.n_goals) near_test(g, hG[(2 * g) * EPW], hG[(2 * g + 1) * EPW]);
+        } else if constexpr (DYN) {
+#pragma unroll
+            for (int g = 0; g < SSG_MAX_GOALS; ++g)
+                if (g < c.n_goals) near_test(g, gpre[2 * g], gpre[2 * g + 1]);
         } else {
             for (int g = 0; g < c.n_goals; ++g) near_test(g, goal_at<LDS_BANK, DYN>(c, goff, g, 0), goal_at<LDS_BANK, DYN>(c, goff, g, 1));
         }
@@ -1419,6 +1517,15 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const int boff = __shfl(goff, src);
             double gx, gy;
             if constexpr (!LDS_BANK && !DYN) { gx = hG[(2 * g) * EPW - lane + src]; gy = hG[(2 * g + 1) * EPW - lane + src]; } // env `src` of this tile
+            else if constexpr (DYN) { // the source lane holds its env's goal centres
+                (void)boff;
+                gx = __shfl(gpre[0], src); gy = __shfl(gpre[1], src);
+#pragma unroll
+                for (int h = 1; h < SSG_MAX_GOALS; ++h) {
+                    const double hx = __shfl(gpre[2 * h], src), hy = __shfl(gpre[2 * h + 1], src);
+                    gx = (g == h) ? hx : gx; gy = (g == h) ? hy : gy;
+                }
+            }
             else { gx = goal_at<LDS_BANK, DYN>(c, boff, g, 0); gy = goal_at<LDS_BANK, DYN>(c, boff, g, 1); }
             // lane = (pair p, ship edge i from vertex i-1 to vertex i)
             const double v1x = bca * w_hx + (-bsa) * w_hy + bx, v1y = bsa * w_hx + bca * w_hy + by;
@@ -1464,7 +1571,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
     if constexpr (DYN) {
-        colliding |= gtraf[(k & 1) * EPW + tl] != 0u; // ... and against the traffic ships (role 2)
+        colliding |= gtraf[(k & 1) * EPW + tl] != 0u; // ... and against the traffic ships (lidar-hi)
         if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
     }
 
@@ -1475,25 +1582,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool done = colliding | done3;
     const bool do_reset = done & auto_reset;
+    if (do_reset) map_id = next_map(c, map_id); // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
 
-    if (live && !SSG_ABL(6)) {
-        // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
-        // single hot address, and integer adds commute, so the totals are bitwise reproducible run to run.
-        // cum is a sum of {1, -1, -0.01} terms, so round(100*cum) is the exact return in hundredths.
-        unsigned long long *slot = reinterpret_cast<unsigned long long *>(c.stats) + 4 * (blockIdx.x % kStatsSlots);
-        if (done) {
-            atomicAdd(slot + 0, (unsigned long long)(long long)llrint(cum * 100.0));
-            atomicAdd(slot + 1, (unsigned long long)steps);
-            atomicAdd(slot + 2, 1ull);
-        }
-        if (goal_reached) atomicAdd(slot + 3, 1ull);
-    }
-    // (reward / done / flags go to HBM from the observer, which holds the same bits)
-    if (do_reset) { // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
-        map_id = next_map(c, map_id);
-        episodes += 1;
-        if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // the new world's goal centres (only these lanes gather)
-    }
     if constexpr (DYN) {
         if (live) {
             // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
@@ -1530,9 +1620,33 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(qm & ((1ull << lane) - 1ull));
             const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
             c.dyn_queue[slot] = el_;
-            c.dyn_qkey[slot] = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+            // The arrival number is a returning atomic: a round trip of several microseconds behind the tile's stores.  It is
+            // asked for first thing after the rendezvous and stored (with the bucket) as this role's LAST instruction.
+            q_slot = slot;
+            q_key = (unsigned long long)bucket << 32;
+            q_arrival = atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
         }
+        q_need = need_full;
     }
+    SSG_STAMP_K(6);
+    if (live && !SSG_ABL(6)) {
+        // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
+        // single hot address, and integer adds commute, so the totals are bitwise reproducible run to run.
+        // cum is a sum of {1, -1, -0.01} terms, so round(100*cum) is the exact return in hundredths.
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(c.stats) + 4 * (blockIdx.x % kStatsSlots);
+        if (done) {
+            atomicAdd(slot + 0, (unsigned long long)(long long)llrint(cum * 100.0));
+            atomicAdd(slot + 1, (unsigned long long)steps);
+            atomicAdd(slot + 2, 1ull);
+        }
+        if (goal_reached) atomicAdd(slot + 3, 1ull);
+    }
+    // (reward / done / flags go to HBM from the observer, which holds the same bits)
+    if (do_reset) {
+        episodes += 1;
+        if constexpr (!LDS_BANK && !DYN) load_hdr_goals(map_id * SSG_MAP_STRIDE); // the new world's goal centres (only these lanes gather)
+    }
+    SSG_STAMP_K(7);
     if (do_reset) {
         x = c.spawn_x; y = c.spawn_y; vx = 0.0; vy = 0.0; ang = 0.0; w = 0.0; cum = 0.0;
         rudder = 0; steps = 0;
@@ -1548,6 +1662,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         st_out(&c.mask[el], (uint8_t)gm);
     }
     SSG_STAMP_K(5);
+    if constexpr (DYN) {
+        if (k < K - 1 && q_need) c.dyn_qkey[q_slot] = q_key | (unsigned long long)q_arrival; // (DYN launches are single steps: never taken)
+    }
     } // k
     if (live) {
         // The last step's outputs (the observer wrote those of the steps before), from the same LDS words the observer
@@ -1570,6 +1687,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if (gd & 32u) ev |= SSG_EV_NO_GOALS_LEFT;
             st_out(&flags_out[el], (uint8_t)ev);
         }
+    }
+    if constexpr (DYN) {
+        asm volatile("" : "+v"(q_arrival)); // (first use of the atomic's result: not before this point)
+        if (q_need) c.dyn_qkey[q_slot] = q_key | (unsigned long long)q_arrival;
     }
     SSG_STAMP(10);
     SSG_STAMP_FLUSH(6);
@@ -1799,6 +1920,7 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
 {
     step_fn_t k = step_fn(c.n_beams, epw, lds, variant_of(c));
     if (!k) return hipErrorInvalidValue;
+    if (variant_of(c) == 2 && K != 1) return hipErrorInvalidValue; // the DYN instantiations run exactly one step per launch
     const int grid = (c.n_envs + epw - 1) / epw;
     hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K, traj);
     return hipGetLastError();
