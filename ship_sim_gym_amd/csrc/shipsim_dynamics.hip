@@ -944,8 +944,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     unsigned long long prof_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, prof_last = 0ull;
 #ifdef SSG_DYN_PROFILE
     unsigned long long type_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, type_t0 = 0ull; // cycles per pair type: gb gg tb gt tt
+    double type_cnt[5] = {0.0, 0.0, 0.0, 0.0, 0.0};                                   // ... and the wave's trips of that type
 #define SSG_TYPE_BEGIN() do { type_t0 = __builtin_amdgcn_s_memtime(); } while (0)
-#define SSG_TYPE_END(t) do { type_acc[t] += __builtin_amdgcn_s_memtime() - type_t0; } while (0)
+#define SSG_TYPE_END(t) do { type_acc[t] += __builtin_amdgcn_s_memtime() - type_t0; type_cnt[t] += 1.0; } while (0)
 #else
 #define SSG_TYPE_BEGIN() do { } while (0)
 #define SSG_TYPE_END(t) do { } while (0)
@@ -1176,6 +1177,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         for (int i = 0; i < 6; ++i) col.f64[(size_t)(DC_ARB + 4 * 45 + i) * np + e] = (double)prof_acc[i]; // unused arbiter rows of pairs 45, 46
     if (d.stop_after == -1)
         for (int i = 0; i < 5; ++i) col.f64[(size_t)(DC_ARB + 4 * 47 + i) * np + e] = (double)type_acc[i]; // ... and of pairs 47, 48
+    if (d.stop_after == -1)
+        for (int i = 0; i < 5; ++i) col.f64[(size_t)(DC_ARB + 210 + i) * np + e] = type_cnt[i]; // (pairs 52, 53: beyond the stamps' rows)
 #endif
     stamp(2);
     if (d.stop_after == 3) return;

@@ -33,6 +33,7 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <type_traits>
 
 #include "shipsim.h"
 #include "shipsim_internal.h"
@@ -238,7 +239,7 @@ __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double
 //                           max_steps, no goals left, bits 8.. = goals still listed after this step
 //                           (-> role 2: reset decision, reward / done / flags outputs, nearest goal; -> the lidar roles:
 //                           reset decision)
-//   gtraf    [2][EPW] u32   config 4: the player touches a traffic ship (collide_ship, by role 2 before the rendezvous)
+//   gtraf    [2][EPW] u32   config 4: the player touches a traffic ship (collide_ship; one word per lidar role, before the rendezvous)
 //   sync     [3][EPW/64] u32  per tile: `ready` = number of poses role 3 has published, `ack` = number of pose reads the
 //                           three consumer waves have completed, `bar` = arrivals at the tile's per-step rendezvous
 //   goal scratch per role-3 wave: (lane, goal) pair queue u16[64*6] + consumed-goal masks u32[64]
@@ -252,7 +253,7 @@ constexpr int kShipTabBytes = 6 * 8 * 8;
 constexpr int kTrafficTabBytes = SSG_N_TRAFFIC * 4 * 8 * 8; // config 4: per traffic ship k, [k][0..3][i] = local vertex x, y, plane normal x, y
 constexpr int kPoseDoubles = 7;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
-constexpr int kTrafficScratchBytes = 64 * SSG_N_TRAFFIC * 2 + 64 * 4; // config 4, per observer wave: (lane, ship) pair queue (u16) + hit words
+constexpr int kTrafficScratchBytes = 64 * SSG_N_TRAFFIC * 2 + 64 * 4; // config 4, per lidar-hi wave: (lane, ship) pair queue (u16) + hit words (lidar-lo: inside its beam pair queue)
 __host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
 {
     return kBeamTabBytes + kShipTabBytes + kTrafficTabBytes + kPoseDoubles * epw * 8 + 8 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * (kGoalScratchBytes + kTrafficScratchBytes);
@@ -955,25 +956,25 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // go into a pair queue of the tile and are served 12 at a time by the whole wave:
     // lane L = 5*p + i takes edge normal i of BOTH hulls of pair p.  Products and sums are the per-env formulation's.  (Rounds
     // 2-3 ran this test in the dyn kernels: on every wave of the full step's chain, and in extra workgroups for resting envs.
-    // It runs on the lidar-hi wave, after its bank hull: that wave is then the last to reach the rendezvous, by ~4 k cycles; on
-    // the OBSERVER wave, idle between the pose hand-over and the rendezvous, the rendezvous came 3 k cycles earlier and the step
-    // 0.6 us later — holding the ships' 12 doubles next to its two frames, that wave spilled 32 registers into its tail, which
-    // is the end of the launch.)
-    auto traffic_collide = [&](const double *tpre, double x, double y, double ca, double sa, int k_) {
-                const int wq = lane / 5, wi = lane - 5 * wq;
-                const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi], w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi];
-                bool hit_traffic = false;
-                double sbl, sbr, sbb, sbt;
-                {
-                    double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
-                    ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
-                }
-        unsigned short *tq = reinterpret_cast<unsigned short *>(traffic_scratch0 + (tl >> 6) * kTrafficScratchBytes);
-        unsigned *tw = reinterpret_cast<unsigned *>(tq + 64 * SSG_N_TRAFFIC);
+    // It runs on the two lidar waves, after their bank hulls — ship 0 on lidar-lo, ships 1 and 2 on lidar-hi.  (All three on
+    // lidar-hi: that wave reached the rendezvous ~4 k cycles after everybody else.  On the OBSERVER wave, idle between the pose
+    // hand-over and the rendezvous: the rendezvous came 3 k cycles earlier and the step 0.6 us later — holding the ships' 12
+    // doubles next to its two frames, that wave spilled 32 registers into its tail, which is the end of the launch.)
+    // Ships [K0, K1) of the env's traffic; `part` = which of the tile's two pair queues and result words (one per lidar role).
+    auto traffic_collide = [&](auto k0_, auto k1_, const double *tpre, double x, double y, double ca, double sa, int part,
+                               unsigned short *tq /* pair queue: 64 x (K1 - K0) */, unsigned *tw /* 64 hit words */) {
+        constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+        const int wq = lane / 5, wi = lane - 5 * wq;
+        const double w_hx = shiptab[0 * 8 + wi], w_hy = shiptab[1 * 8 + wi], w_nx = shiptab[2 * 8 + wi], w_ny = shiptab[3 * 8 + wi];
+        double sbl, sbr, sbb, sbt;
+        {
+            double swx[SSG_SHIP_VERTS], swy[SSG_SHIP_VERTS];
+            ship_world(shiptab, ca, sa, x, y, swx, swy, sbl, sbr, sbb, sbt);
+        }
         tw[lane] = 0u;
         int n_tp = 0;
 #pragma unroll
-        for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
+        for (int kk = K0; kk < K1; ++kk) {
             const double tx = tpre[4 * kk + 0], ty = tpre[4 * kk + 1];
             const double dx = dmax(dmax(sbl - tx, tx - sbr), 0.0), dy = dmax(dmax(sbb - ty, ty - sbt), 0.0);
             bool cand = false;
@@ -1000,9 +1001,9 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const int src = code & 63, kk = code >> 6;
             const double bx = __shfl(x, src), by = __shfl(y, src), bca = __shfl(ca, src), bsa = __shfl(sa, src);
             // the source lane holds its env's ships
-            double tx = __shfl(tpre[0], src), ty = __shfl(tpre[1], src), tca = __shfl(tpre[2], src), tsa = __shfl(tpre[3], src);
+            double tx = __shfl(tpre[4 * K0 + 0], src), ty = __shfl(tpre[4 * K0 + 1], src), tca = __shfl(tpre[4 * K0 + 2], src), tsa = __shfl(tpre[4 * K0 + 3], src);
 #pragma unroll
-            for (int h = 1; h < SSG_N_TRAFFIC; ++h) {
+            for (int h = K0 + 1; h < K1; ++h) {
                 const double a0 = __shfl(tpre[4 * h + 0], src), a1 = __shfl(tpre[4 * h + 1], src);
                 const double a2 = __shfl(tpre[4 * h + 2], src), a3 = __shfl(tpre[4 * h + 3], src);
                 tx = (kk == h) ? a0 : tx; ty = (kk == h) ? a1 : ty; tca = (kk == h) ? a2 : tca; tsa = (kk == h) ? a3 : tsa;
@@ -1040,9 +1041,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             const bool separated = ((ms >> (5 * wq)) & 31ull) != 0ull;
             if (valid & (wi == 0) & !separated) atomicOr(&tw[src], 1u);
         }
-        hit_traffic = tw[lane] != 0u;
-                gtraf[(k_ & 1) * EPW + tl] = hit_traffic ? 1u : 0u;
+        gtraf[part * EPW + tl] = (tw[lane] != 0u) ? 1u : 0u;
     };
+    // (DYN launches are single steps: gtraf's two parities serve as the two lidar roles' result words)
+    auto traffic_hit = [&](int) -> unsigned { return gtraf[tl] | gtraf[EPW + tl]; };
     if (role < 2) {
         // =====================================================================================================
         // ROLES 0 / 1: LiDAR.query on the PRE-step pose (models.py:39-76; game.py:193 runs it before space.step)
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         // the first step's pre-step pose comes from the state columns
         double ca, sa, cx, cy;
         int map_id;
-        double tpre[DYN ? 4 * SSG_N_TRAFFIC : 1];
+        double tpre[DYN ? 4 * SSG_N_TRAFFIC : 1] = {};
         {
             const double x = colX[el_], y = colY[el_], ang = colA[el_];
             map_id = colMap[el_];
@@ -1067,10 +1069,11 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 // the first query: read where they are used, they were two dependent round trips per ship between the bank hull
                 // and the rendezvous.  (Asked for BEFORE barrier 0, with the state, they delayed the barrier for every role: the
                 // whole grid starts at once and the extra megabytes queue up behind the bank's staging.)
-                if (role == 1) {
+                {
                     const double *tcol = c.dyn_f64 + (size_t)DC_TRAFFIC * np, *trot = c.dyn_f64 + (size_t)DC_TROT * np;
 #pragma unroll
                     for (int kk = 0; kk < SSG_N_TRAFFIC; ++kk) {
+                        if ((kk == 0) != (role == 0)) continue; // ship 0: lidar-lo; ships 1, 2: lidar-hi
                         tpre[4 * kk + 0] = tcol[(size_t)(9 * kk) * np + el_]; tpre[4 * kk + 1] = tcol[(size_t)(9 * kk + 1) * np + el_];
                         tpre[4 * kk + 2] = trot[(size_t)(2 * kk) * np + el_]; tpre[4 * kk + 3] = trot[(size_t)(2 * kk + 1) * np + el_];
                     }
@@ -1087,10 +1090,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         for (int k = 0; k < K; ++k) {
             wait_pose(k); // role 3 has published this step's post-step pose
             if constexpr (DYN) {
-                if (role == 1) {
 #pragma unroll
-                    for (int i = 0; i < 4 * SSG_N_TRAFFIC; ++i) asm volatile("" : "+v"(tpre[i]));
-                }
+                for (int i = 0; i < 4 * SSG_N_TRAFFIC; ++i) asm volatile("" : "+v"(tpre[i]));
             }
             SSG_STAMP_K(0);
             const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
@@ -1103,14 +1104,22 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
                     bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
             SSG_STAMP_K(4);
-            if (DYN && role == 1) traffic_collide(tpre, npx, npy, nca, nsa, k);
+            if constexpr (DYN) {
+                // lidar-lo's queue and hit words: its (beam, hull) pair queue, idle between two queries (64 + 128 of its >= 192 half-words)
+                static_assert(lds_queue_bytes(1) >= 64 * 2 + 64 * 4, "lidar-lo's pair queue holds ship 0's pair queue and hit words");
+                unsigned short *tq1 = reinterpret_cast<unsigned short *>(traffic_scratch0 + (tl >> 6) * kTrafficScratchBytes);
+                if (role == 0) traffic_collide(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, tpre, npx, npy, nca, nsa, 0,
+                                               queue, reinterpret_cast<unsigned *>(queue + 64));
+                else traffic_collide(std::integral_constant<int, 1>{}, std::integral_constant<int, SSG_N_TRAFFIC>{}, tpre, npx, npy, nca, nsa, 1,
+                                     tq1, reinterpret_cast<unsigned *>(tq1 + 64 * SSG_N_TRAFFIC));
+            }
 
             SSG_STAMP_K(3);
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
             if (k + 1 < K) {
                 // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
-                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? gtraf[(k & 1) * EPW + tl] : 0u)) != 0u);
+                const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? traffic_hit(k) : 0u)) != 0u);
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
                 map_id = rs ? next_map(c, nmap) : nmap;
@@ -1126,7 +1135,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // A single-step launch: the sticky readings' columns hold exactly the previous frame's values, so "a miss keeps
             // the previous reading" (models.py:68-72) is "a miss stores nothing".  The lidar waves, idle after the step's only
             // rendezvous, store their own beams' hits (or the -1 of a fresh episode) while the observer builds the rows.
-            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 1u) | (DYN ? gtraf[tl] : 0u)) != 0u);
+            const bool rs = auto_reset & ((gres[tl] | (gdone[tl] & 1u) | (DYN ? traffic_hit(0) : 0u)) != 0u);
             const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(tile_base); // parity 0
             for (int kb = 0; kb < b_count; ++kb) {
                 const int i = b_first + kb;
@@ -1236,7 +1245,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             // inside a fused launch.
             // =================================================================================================
             const unsigned gd = gdone[(k & 1) * EPW + tl];
-            const bool colliding = (gres[(k & 1) * EPW + tl] != 0u) | (DYN && gtraf[(k & 1) * EPW + tl] != 0u); // collide_ship: a bank, or traffic
+            const bool colliding = (gres[(k & 1) * EPW + tl] != 0u) | (DYN && traffic_hit(k) != 0u); // collide_ship: a bank, or traffic
             const bool do_reset = auto_reset & (colliding | ((gd & 1u) != 0u));
             // (a launch's last step: role 3, idle by then, writes these after its loop — the observer's tail is what the
             // launch waits for)
@@ -1571,7 +1580,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
     if constexpr (DYN) {
-        colliding |= gtraf[(k & 1) * EPW + tl] != 0u; // ... and against the traffic ships (lidar-hi)
+        colliding |= traffic_hit(k) != 0u; // ... and against the traffic ships (the lidar roles)
         if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
     }
 
@@ -1672,7 +1681,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         const int par = (K - 1) & 1;
         const size_t el = (size_t)el_ + (size_t)(K - 1) * (size_t)traj;
         const unsigned gd = gdone[par * EPW + tl];
-        const bool colliding = (gres[par * EPW + tl] != 0u) | (DYN && gtraf[par * EPW + tl] != 0u);
+        const bool colliding = (gres[par * EPW + tl] != 0u) | (DYN && traffic_hit(par) != 0u);
         const bool goal_reached = (gd & 4u) != 0u;
         double rew = goal_reached ? 1.0 : ((gd & 8u) ? -1.0 : -0.01);
         if ((c.flags & SSG_FLAG_FIX_COLLISION_REWARD) && (colliding & !goal_reached)) rew = -1.0;

@@ -75,7 +75,15 @@ if ty[:, sel].max() > 0:
     for i in range(5):
         v = ty[i][sel]
         print("   %-10s %8.0f %8.0f %8.0f   entered by %.2f of the waves" % (nm[i], np.median(v), np.percentile(v, 90), v.max(), (v > 0).mean()))
+    tc = cols[DC_ARB + 210: DC_ARB + 215, :n].cpu().numpy()
+    trips = tc[:, sel].sum(axis=0)
+    types = (tc[:, sel] > 0).sum(axis=0)
+    print("   narrowphase trips per wave: mean %.2f p90 %.0f max %.0f | pair types per wave: mean %.2f | trips by type (mean): %s" % (
+        trips.mean(), np.percentile(trips, 90), trips.max(), types.mean(), ", ".join("%s %.2f" % (nm[i], tc[i][sel].mean()) for i in range(5))))
+    print("   if every type took ONE trip (a lane per query): trips per wave mean %.2f; cycles per trip by type (mean): %s" % (
+        types.mean(), ", ".join("%s %.0f" % (nm[i], (ty[i][sel].sum() / max(1.0, tc[i][sel].sum()))) for i in range(5))))
     heavy = st[5][sel] >= np.percentile(st[5][sel], 95)
+    print("   slowest 5 %%: trips mean %.2f, types mean %.2f" % (trips[heavy].mean(), types[heavy].mean()))
     print("   slowest 5 %% of the waves: " + ", ".join("%s %.0f" % (nm[i], ty[i][sel][heavy].mean()) for i in range(5)))
 
 # which (age, world) make a wave slow?  Only the envs stepped by the LAST full step (not at rest now) carry stamps of one and
