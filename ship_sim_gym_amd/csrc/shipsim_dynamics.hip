@@ -679,16 +679,23 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
     // this workgroup's four segments of the queue (segment = tile of 64 envs, entries [64*seg, 64*seg + count))
     const unsigned i = blockIdx.x * 256u + (unsigned)t;
     const unsigned seg = i >> 6;
-    const unsigned cnt = ((size_t)seg < (size_t)c.n_pad / 64) ? min(c.dyn_segcnt[seg], 64u) : 0u; // (clamped: garbage counters must not index past a segment)
+    // One batch of loads: the segment's length, this slot's key and entry (whatever they hold beyond the length: never used), two
+    // bucket counters.  (One after the other — the length, then the key, then, for workgroups that hold entries, the counters —
+    // they were three dependent round trips of a kernel that is little else.)
+    const bool seg_ok = (size_t)seg < (size_t)c.n_pad / 64;
+    unsigned cnt_raw = seg_ok ? c.dyn_segcnt[seg] : 0u;
+    unsigned long long k = seg_ok ? c.dyn_qkey[i] : 0ull;
+    int entry = seg_ok ? c.dyn_queue[i] : 0;
+    unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
+    asm volatile("" : "+v"(cnt_raw), "+v"(k), "+v"(entry), "+v"(c0), "+v"(c1));
+    const unsigned cnt = min(cnt_raw, 64u); // (clamped: garbage counters must not index past a segment)
     const bool valid = (unsigned)lane < cnt;
-    const unsigned long long k = valid ? c.dyn_qkey[i] : 0ull;
     const unsigned n_full = (unsigned)__popcll(__ballot(valid));
     if (lane == 0) wave_tot[wv] = n_full;
     __syncthreads();
     const unsigned wsum = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     if (wsum == 0u) return; // no full step queued among this workgroup's 256 envs (workgroup-uniform)
     __syncthreads();
-    const unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
     static_assert(kDynAgeBuckets == 8, "four threads (two buckets each) per map");
     // inside the map (threads 4m .. 4m+3): inclusive scan of the bucket counts, the map's total, its wave-rounded length
     const unsigned two = c0 + c1;
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const Dyn
         // (the entry carries its bucket's map index in bits 25 ..: the full step's waves — one bank record per wave when the bank
         // holds at most 64 — stage their record's planes without first fetching the env's map id, a dependent round trip)
         if (dst < (unsigned)c.n_pad + (unsigned)kDynSortedPad)
-            c.dyn_sorted[dst] = (int32_t)((unsigned)c.dyn_queue[i] | ((((unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)) / (unsigned)kDynAgeBuckets) << kDynSortedMapShift));
+            c.dyn_sorted[dst] = (int32_t)((unsigned)entry | ((((unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)) / (unsigned)kDynAgeBuckets) << kDynSortedMapShift));
     }
 }
 
