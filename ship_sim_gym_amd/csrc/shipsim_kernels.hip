@@ -202,10 +202,13 @@ __device__ __forceinline__ void nearest_goal_regs(int n_goals, unsigned gm, doub
 
 // The bank record an env moves to when ShipGame.reset gives it its next world: the next record of the shared bank, or —
 // map_ring mode — the next record of the env's own ring [base, base + R).
-__device__ __forceinline__ int next_map(const DevCfg &c, int map_id)
+// (`env` = the env's index in this handle: its ring starts at record env * R, reset_kernel.  Not `map_id - map_id % R`: the
+// reciprocal of a run-time divisor is loop-invariant, the compiler kept it live around the step loop and spilled it — a scratch
+// reload, i.e. a wait for every store the wave had in flight, in every step of the observer.)
+__device__ __forceinline__ int next_map(const DevCfg &c, int map_id, int env)
 {
     if (c.map_ring > 0) {
-        const int base = map_id - map_id % c.map_ring;
+        const int base = env * c.map_ring;
         const int nxt = map_id + 1;
         return (nxt - base >= c.map_ring) ? base : nxt;
     }
@@ -1122,7 +1125,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
                 const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? traffic_hit(k) : 0u)) != 0u);
                 ca = rs ? 1.0 : nca; sa = rs ? 0.0 : nsa;
                 cx = rs ? shiptab[0 * 8 + 6] : ncx; cy = rs ? shiptab[1 * 8 + 6] : ncy;
-                map_id = rs ? next_map(c, nmap) : nmap;
+                map_id = rs ? next_map(c, nmap, el_) : nmap;
                 if constexpr (!LDS_BANK) {
                     if (rs) load_hdr_lidar(map_id * SSG_MAP_STRIDE); // only the lanes whose env moved to its next record gather
                 }
@@ -1277,7 +1280,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
             asm volatile("" : "+s"(tile_w), "+s"(tile_e0));
             char *res_k = scratch0 + tile_w * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB);
-            const int map_new = do_reset ? next_map(c, map_id) : map_id;
+            const int map_new = do_reset ? next_map(c, map_id, el_) : map_id;
             double rs_gx = 0.0, rs_gy = 0.0; // the reset frame's goal: only a reset env's lanes fetch it when the bank is gathered
             if (LDS_BANK || do_reset) {
                 const double2 sg = bank_at2<LDS_BANK>(c, map_new * SSG_MAP_STRIDE + SSG_MAP_OFF_SPAWN_GOAL);
@@ -1342,8 +1345,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 #pragma unroll
             for (int i = 0; i < F; ++i) pv[i] = nv[i];
             if (k == K - 1 && K > 1 && live && !SSG_ABL(9)) { // the sticky readings go back to the state columns with the last step
+                int el = el_; // (laundered: the addresses of the head's loads are not kept live — and spilled — around the step loop)
+                asm volatile("" : "+v"(el));
 #pragma unroll
-                for (int i = 0; i < NB; ++i) st_out(&colLid[(size_t)i * np + el_], pv[6 + i]);
+                for (int i = 0; i < NB; ++i) st_out(&colLid[(size_t)i * np + el], pv[6 + i]);
             }
             SSG_STAMP_K(3);
         }
@@ -1591,7 +1596,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 
     const bool done = colliding | done3;
     const bool do_reset = done & auto_reset;
-    if (do_reset) map_id = next_map(c, map_id); // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
+    if (do_reset) map_id = next_map(c, map_id, el_); // VecEnv auto-reset: ShipGame.reset + ShipEnv.reset onto the next bank record
 
     if constexpr (DYN) {
         if (live) {
