@@ -201,7 +201,8 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps);
  * ------------------------------------------------------------------------------------------------- */
 /* Replaces: ShipEnv.reset -> ShipGame.reset (ship_env.py:171-184, game.py:260-277).
  * dev_mask: u8[n_envs], non-zero = reset this env; NULL = all.  dev_map_ids: i32[n_envs] record to install for
- * each reset env; NULL = (env_id_base + e) mod n_maps.  dev_obs: f64[n_envs][history*(6+n_beams)], rows of reset
+ * each reset env; NULL = (env_id_base + e) mod n_maps (map_ring mode: must be NULL — the env moves to the next record of
+ * its own ring; SSG_ERR_BAD_ARG otherwise).  dev_obs: f64[n_envs][history*(6+n_beams)], rows of reset
  * envs are overwritten with the reset observation. */
 int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids, double *dev_obs, void *stream);
 

@@ -660,6 +660,8 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
     rc = flush_remap(h, stream);
     if (rc != SSG_OK) return rc;
     if (h->cfg.map_ring > 0) {
+        if (dev_map_ids) // episode p of env e lives in record e*R + p mod R: there is no other record to put it on
+            return fail(h, SSG_ERR_BAD_ARG, "ssg_reset: dev_map_ids must be NULL in map_ring mode (an env's records are its own ring)");
         if (!h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds before the first ssg_reset");
         if (h->ring_credit < 1) { // a reset starts an episode: make sure every ring still holds an unused world
             rc = ring_refill(h, nullptr, stream);

@@ -166,6 +166,10 @@ def test_ring_bookkeeping_with_one_step_episodes_and_reinit(native):
 
     v.reset_tensor()
     check_current_records("after the first reset")
+    # an env's records are its own ring: a caller-chosen record index is refused, nothing is reset
+    with pytest.raises(Exception, match="map_ring"):
+        v.reset_tensor(map_ids=torch.zeros(n, dtype=torch.int32, device=v.device))
+    check_current_records("after the refused reset")
     acts = v.random_actions(3, 0, 40)
     for k in range(25):
         _, _, done, _ = v.step_tensor(acts[k])
