@@ -114,7 +114,8 @@ typedef struct ssg_config {
     /* config 4 (BASELINE configs[3]) */
     int32_t n_ships;       /* 1 (default), or 4 = the player + ShipGame.add_default_traffic() after every reset
                               (game.py:279-286): goal bodies become dynamic and Chipmunk's contact solver runs for the
-                              traffic ships and goals; every step is then two launches (no fused rollout) */
+                              traffic ships and goals; every step is then three launches — queue sort, cpSpaceStep of the queued envs,
+                              the step kernel — (no fused rollout) */
     int32_t map_ring;      /* 0 (default): envs walk through a shared bank of worlds.  R in 2..64: EVERY EPISODE GETS A BRAND-NEW
                               WORLD, as ShipGame.reset does (game.py:260-277: gen_level + gen_goal_path at every reset): the bank
                               holds n_envs * R records, env e owns records [e*R, e*R + R) as a ring, episode p of env e lives
@@ -275,7 +276,8 @@ int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *d
  * removals and bank changes itself; a caller that WRITES ANY state column of a config-4 handle between two steps — the
  * SSG_F_TRAFFIC / SSG_F_GOAL_BODIES columns, but also the player's own SSG_F_X .. SSG_F_W, SSG_F_GOAL_MASK, SSG_F_STEP_COUNT
  * or SSG_F_MAP_ID (scenario set-up, curriculum placement, tests) — tells it with this call: the queue of the next step is then
- * rebuilt from the columns (a resting env whose player was moved next to a parked ship gets collide_ship's test again).
+ * rebuilt from the columns, and the ships' rotation columns (what collide_ship's player x traffic test in the step kernel turns
+ * their hulls with) are recomputed from the angles.
  * dev_mask: u8[n_envs], non-zero = also clear the env's rest bit and refresh its row-major shadow; NULL = all envs. */
 int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
 

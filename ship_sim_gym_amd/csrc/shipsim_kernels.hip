@@ -870,7 +870,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     int *poser = posem + EPW;                                                                // [EPW]
     unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
     unsigned *gdone = gres + 2 * EPW;                                                        // [2 parities][EPW]
-    unsigned *gtraf = gdone + 2 * EPW;                                                       // [2 parities][EPW] config 4: the player touches a traffic ship (role 2 -> all)
+    unsigned *gtraf = gdone + 2 * EPW;                                                       // [2][EPW] config 4: the player touches a traffic ship (one word per lidar role -> all; DYN launches are single steps)
     unsigned *sync_ready = gtraf + 2 * EPW;                                                  // [EPW/64]
     unsigned *sync_ack = sync_ready + EPW / 64;                                              // [EPW/64]
     unsigned *sync_bar = sync_ack + EPW / 64;                                                // [EPW/64] (+ one pad word each)
