@@ -114,8 +114,8 @@ typedef struct ssg_config {
     /* config 4 (BASELINE configs[3]) */
     int32_t n_ships;       /* 1 (default), or 4 = the player + ShipGame.add_default_traffic() after every reset
                               (game.py:279-286): goal bodies become dynamic and Chipmunk's contact solver runs for the
-                              traffic ships and goals; every step is then three launches — queue sort, cpSpaceStep of the queued envs,
-                              the step kernel — (no fused rollout) */
+                              traffic ships and goals; every step is then two launches — cpSpaceStep of the queued envs, the step
+                              kernel — (no fused rollout) */
     int32_t map_ring;      /* 0 (default): envs walk through a shared bank of worlds.  R in 2..64: EVERY EPISODE GETS A BRAND-NEW
                               WORLD, as ShipGame.reset does (game.py:260-277: gen_level + gen_goal_path at every reset): the bank
                               holds n_envs * R records, env e owns records [e*R, e*R + R) as a ring, episode p of env e lives

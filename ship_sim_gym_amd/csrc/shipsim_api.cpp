@@ -19,7 +19,7 @@ struct ssg_handle {
     int n_pad = 0;
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
-    size_t off_dyn_hash = 0, off_dyn_queue = 0, off_dyn_count = 0, off_dyn_qkey = 0, off_dyn_sorted = 0, off_dyn_row = 0, off_dyn_segcnt = 0;
+    size_t off_dyn_hash = 0, off_dyn_count = 0, off_dyn_row = 0, off_dyn_bucket = 0;
     bool dyn_queue_valid = false; // the step kernel's last launch left the next step's dyn queue (nothing host-side touched the envs since)
     ssg::DynCfg dyn{};
     void *state = nullptr;
@@ -336,12 +336,10 @@ void refresh_dev(ssg_handle *h)
     d.dyn_u32 = dyn ? reinterpret_cast<uint32_t *>(base + h->off_dyn_u32) : nullptr;
     d.dyn_flag = dyn ? reinterpret_cast<uint8_t *>(base + h->off_dyn_flag) : nullptr;
     d.dyn_hash = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_hash) : nullptr;
-    d.dyn_queue = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_queue) : nullptr;
     d.dyn_count = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_count) : nullptr;
-    d.dyn_qkey = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_qkey) : nullptr;
-    d.dyn_sorted = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_sorted) : nullptr;
+    d.dyn_bucket = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_bucket) : nullptr;
+    d.dyn_par = 0; // (the queue is rebuilt from the flags after every refresh: dyn_queue_valid = false below)
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
-    d.dyn_segcnt = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_segcnt) : nullptr;
     {   // the step kernel's reject in front of collide_ship's exact player x traffic test: no vertex of ship k's hull is further than
         // its hull radius from its body position
         auto radius = [](const double *hull) {
@@ -469,8 +467,6 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring must be 0 or in 2..64");
     if (cfg->map_ring != 0 && cfg->history > 2)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring needs history <= 2");
-    if (cfg->n_ships > 1 && cfg->n_envs > ssg::kDynSortedEnvMask) // (a sorted dyn-queue entry keeps 25 bits for the env)
-        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_ships = 4 supports at most 33 554 431 envs per handle");
     if (cfg->n_ships > 1 && (cfg->flags & SSG_FLAG_EXACT_LIDAR))
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: SSG_FLAG_EXACT_LIDAR is not built for n_ships = 4");
     ssg_handle *h = new (std::nothrow) ssg_handle();
@@ -500,13 +496,10 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_u32 = h->off_dyn_live + np * sizeof(unsigned long long);
         h->off_dyn_flag = h->off_dyn_u32 + (size_t)ssg::DU_COUNT * np * sizeof(uint32_t);
         h->off_dyn_hash = h->off_dyn_flag + np;
-        h->off_dyn_queue = h->off_dyn_hash + np * sizeof(unsigned long long);
-        h->off_dyn_count = h->off_dyn_queue + np * sizeof(int32_t);
-        h->off_dyn_qkey = h->off_dyn_count + (((size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
-        h->off_dyn_sorted = h->off_dyn_qkey + np * sizeof(unsigned long long);
-        h->off_dyn_row = (h->off_dyn_sorted + (np + (size_t)ssg::kDynSortedPad) * sizeof(int32_t) + 255) & ~(size_t)255;
-        h->off_dyn_segcnt = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
-        h->nbytes = h->off_dyn_segcnt + ((np / 64 * sizeof(unsigned) + 255) & ~(size_t)255);
+        h->off_dyn_count = h->off_dyn_hash + np * sizeof(unsigned long long);
+        h->off_dyn_row = h->off_dyn_count + ((2 * (size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
+        h->off_dyn_bucket = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
+        h->nbytes = h->off_dyn_bucket + (size_t)ssg::kDynBuckets * np * sizeof(int32_t); // one array of n_pad slots per sort bucket
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -747,16 +740,13 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
             }
             if (dyn) {
                 hipError_t e = hipSuccess;
-                if (!h->dyn_queue_valid) { // the classify pass rebuilds the queue: its bucket counters and length start from zero,
-                                           // the sorted queue holds nothing (-1 everywhere: the sort only writes the entries)
+                if (!h->dyn_queue_valid) { // the classify pass rebuilds the queue: this step's bucket counters start from zero
+                    h->dev.dyn_par = 0;
                     e = hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
-                    if (e == hipSuccess)
-                        e = hipMemsetAsync(h->dev.dyn_sorted, 0xFF, ((size_t)h->dev.n_pad + ssg::kDynSortedPad) * sizeof(int32_t),
-                                           static_cast<hipStream_t>(stream));
                 }
                 if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
                 if (e != hipSuccess) {
-                    h->dyn_queue_valid = false; // (a sorted queue the full step never consumed must not survive: the next call starts over)
+                    h->dyn_queue_valid = false; // (a queue the full step never consumed must not survive: the next call starts over)
                     return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
                 }
             }
@@ -768,7 +758,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 h->dyn_queue_valid = false; // (the next call rebuilds the dyn queue from the flags, counters zeroed)
                 return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
             }
-            if (dyn) h->dyn_queue_valid = true; // the step kernel's body role has queued the envs whose bodies must be stepped next
+            if (dyn) { // the step kernel's body role has queued the envs whose bodies must be stepped next, in the other counter set
+                h->dyn_queue_valid = true;
+                h->dev.dyn_par ^= 1;
+            }
         }
         return SSG_OK;
     }

@@ -17,7 +17,7 @@
 //    (`lds[field*kGrp + lane]`, kGrp = 48 envs per wave): the per-lane gathers of the solver are (nearly) conflict-free.
 //    (A first version kept them in per-lane arrays: 8.7 KB of scratch per lane, 1 GB of HBM traffic per step, 420 us.)
 //  * Shapes are never materialised: a ship's world vertices are its pose applied on the fly to the hull constants
-//    (staged once per workgroup in LDS, broadcast reads).  The bank planes: the sorted queue is map-major and every map's
+//    (staged once per workgroup in LDS, broadcast reads).  The bank planes: the queue is walked map-major and every map's
 //    stretch starts on a wave boundary, so all lanes of a wave sit on ONE bank record, staged once per wave (96 doubles,
 //    broadcast reads) — dyn_step_kernel<true>; banks of more than 64 records and per-env rings of worlds keep the planes in
 //    per-lane columns (dyn_step_kernel<false>).  76 KB of LDS per wave: two waves per CU, each alone on its SIMD, 512 at
@@ -26,12 +26,12 @@
 //    EPA's growing hull has seven LDS entries per lane, scratch beyond (practically never).
 //  * Arbiter records (accumulated impulses, contact hashes, state, age) persist in struct-of-arrays columns but are
 //    read or written only for pairs whose bit is set in the env's 64-bit live mask.
-//  * Which envs are stepped: the ones the step kernel's body role queued at the end of the previous step (segmented queue,
-//    DevCfg::dyn_queue), sorted by (bank record, steps since the reset) so that the lanes of a wave walk the same path
-//    (dyn_sort_kernel), read through a row-major shadow of the body columns (DevCfg::dyn_row).  Envs whose space is at a
-//    fixed point of cpSpaceStep (the rest bit) are not stepped at all.
-// Per step: dyn_sort_kernel, dyn_step_kernel, then the step kernel, which reads this step's goal and traffic positions from
-// the dyn columns (DevCfg::dyn_*) and queues the envs for the next step.
+//  * Which envs are stepped: the ones the step kernel's body role queued at the end of the previous step, each in the array of
+//    its (bank record, steps since the reset) bucket (DevCfg::dyn_bucket) so that the lanes of a wave walk the same path; a wave
+//    finds its entries from the 512 bucket counters alone (no sort pass) and reads the bodies through a row-major shadow of
+//    their columns (DevCfg::dyn_row).  Envs whose space is at a fixed point of cpSpaceStep (the rest bit) are not stepped at all.
+// Per step: dyn_step_kernel, then the step kernel, which reads this step's goal and traffic positions from the dyn columns
+// (DevCfg::dyn_*) and queues the envs for the next step.
 //
 // The canonical pair order, the cold GJK start and the unsolved player arbiters are the named assumptions of the
 // oracle (oracle/ssg_dynamics.c header); this file follows the same ones.
@@ -177,7 +177,7 @@ struct ShipShape {
 // lane's LDS columns right before the narrowphase that needs them (all 48 loads in flight at once): GJK / EPA call
 // support() a dozen times in a dependent chain, and each call straight from L2 was a round trip.
 constexpr int kBankDoubles = 4 * SSG_MAX_HULL;
-// UNI: every lane of the wave sits on the same bank record (dyn_sort_kernel's map-aligned order, banks of <= 64 records): the
+// UNI: every lane of the wave sits on the same bank record (the queue's map-aligned order, banks of <= 64 records): the
 // planes are staged ONCE per wave (field stride 1, broadcast reads) instead of into per-lane columns (field stride kGrp).
 template <bool UNI>
 struct BankShape {
@@ -651,83 +651,10 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         need_full = !rest;
         bucket = dyn_bucket_of(age, map_id);
     }
-    // The queue is segmented by tiles of 64 envs (a wave of this kernel = one tile): no atomics to append.
-    const unsigned long long m = __ballot(need_full);
-    const int lane = threadIdx.x & 63;
-    const int seg = e >> 6; // (n_pad is a multiple of 256: every wave of the grid owns a whole segment)
-    if (lane == 0 && (size_t)seg < (size_t)c.n_pad / 64) c.dyn_segcnt[seg] = (unsigned)__popcll(m);
-    if (need_full) {
-        const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        // arrival number inside the env's sort bucket (order inside a bucket is irrelevant: every env is stepped on its own)
-        c.dyn_queue[slot] = e;
-        c.dyn_qkey[slot] = ((unsigned long long)bucket << 32) | (unsigned long long)atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// dyn_sort_kernel: counting sort of the queue by bucket.  Every
-// workgroup scans the 512 bucket counters itself (2 KB from L2) and scatters its 256 queue entries to base[bucket] + arrival
-// number.  Buckets are map-major (dyn_bucket_of) and a map's eight buckets start on a multiple of kDynGrp slots: no wave of the
-// full step straddles two bank records.  The gaps are not written: the full step leaves -1 behind in every slot it read.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dyn_sort_kernel(const DevCfg c, const DynCfg d)
-{
-    __shared__ unsigned base[kDynBuckets];
-    __shared__ unsigned wave_tot[4];
-    static_assert(kDynBuckets == 512, "two buckets per thread of a 256-thread workgroup");
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    // this workgroup's four segments of the queue (segment = tile of 64 envs, entries [64*seg, 64*seg + count))
-    const unsigned i = blockIdx.x * 256u + (unsigned)t;
-    const unsigned seg = i >> 6;
-    // One batch of loads: the segment's length, this slot's key and entry (whatever they hold beyond the length: never used), two
-    // bucket counters.  (One after the other — the length, then the key, then, for workgroups that hold entries, the counters —
-    // they were three dependent round trips of a kernel that is little else.)
-    const bool seg_ok = (size_t)seg < (size_t)c.n_pad / 64;
-    unsigned cnt_raw = seg_ok ? c.dyn_segcnt[seg] : 0u;
-    unsigned long long k = seg_ok ? c.dyn_qkey[i] : 0ull;
-    int entry = seg_ok ? c.dyn_queue[i] : 0;
-    unsigned c0 = c.dyn_count[kDynBucket0 + (2 * t) * kDynBucketStride], c1 = c.dyn_count[kDynBucket0 + (2 * t + 1) * kDynBucketStride];
-    asm volatile("" : "+v"(cnt_raw), "+v"(k), "+v"(entry), "+v"(c0), "+v"(c1));
-    const unsigned cnt = min(cnt_raw, 64u); // (clamped: garbage counters must not index past a segment)
-    const bool valid = (unsigned)lane < cnt;
-    const unsigned n_full = (unsigned)__popcll(__ballot(valid));
-    if (lane == 0) wave_tot[wv] = n_full;
-    __syncthreads();
-    const unsigned wsum = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    if (wsum == 0u) return; // no full step queued among this workgroup's 256 envs (workgroup-uniform)
-    __syncthreads();
-    static_assert(kDynAgeBuckets == 8, "four threads (two buckets each) per map");
-    // inside the map (threads 4m .. 4m+3): inclusive scan of the bucket counts, the map's total, its wave-rounded length
-    const unsigned two = c0 + c1;
-    unsigned in_map = two;
-    { const unsigned v = __shfl_up(in_map, 1); in_map += ((lane & 3) >= 1) ? v : 0u; }
-    { const unsigned v = __shfl_up(in_map, 2); in_map += ((lane & 3) >= 2) ? v : 0u; }
-    const unsigned n_map = __shfl(in_map, lane | 3);
-    const unsigned r_map = (n_map + (unsigned)(kDynGrp - 1)) / (unsigned)kDynGrp * (unsigned)kDynGrp;
-    // over the maps: inclusive scan of the rounded lengths (each map contributes once, at its last thread)
-    unsigned incl = ((lane & 3) == 3) ? r_map : 0u;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned v = __shfl_up(incl, o);
-        incl += (lane >= o) ? v : 0u;
-    }
-    const unsigned maps_incl = __shfl(incl, lane | 3); // ... up to and including this thread's map
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    unsigned off = 0;
-    for (int w = 0; w < wv; ++w) off += wave_tot[w];
-    const unsigned excl = off + maps_incl - r_map + in_map - two; // the map's first slot + the buckets of the map before this thread's
-    base[2 * t] = excl;
-    base[2 * t + 1] = excl + c0;
-    __syncthreads();
-    // the queue's length including the gaps (zeroed by the step kernel; every workgroup that gets here stores the same number)
-    if (t == 0) c.dyn_count[0] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    if (valid) {
-        const unsigned dst = base[(unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)] + (unsigned)k;
-        // (the entry carries its bucket's map index in bits 25 ..: the full step's waves — one bank record per wave when the bank
-        // holds at most 64 — stage their record's planes without first fetching the env's map id, a dependent round trip)
-        if (dst < (unsigned)c.n_pad + (unsigned)kDynSortedPad)
-            c.dyn_sorted[dst] = (int32_t)((unsigned)entry | ((((unsigned)(k >> 32) & (unsigned)(kDynBuckets - 1)) / (unsigned)kDynAgeBuckets) << kDynSortedMapShift));
+    if (need_full) { // append to the bucket's array (order inside a bucket is irrelevant: every env is stepped on its own)
+        unsigned *cnt = c.dyn_count + (size_t)c.dyn_par * kDynCountWords; // THIS step's counter set (zeroed by the host just before)
+        const unsigned arrival = atomicAdd(cnt + dyn_counter_word(bucket), 1u);
+        c.dyn_bucket[(size_t)bucket * (size_t)c.n_pad + arrival] = e;
     }
 }
 
@@ -744,19 +671,57 @@ template <bool UNI>
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
     const int lane = threadIdx.x;
-    // The queue's length is not read: every slot the sort did not write holds -1 (a gap in front of the next map's stretch, or
-    // past the end: this kernel leaves -1 behind in what it read, ssg_step memsets the array whenever the host rebuilt the
-    // queue) — one memory round trip less at the head of every wave's chain.
     const unsigned long long t_start = __builtin_amdgcn_s_memtime(); // (development aid, see stamp())
-    const unsigned slot = (unsigned)blockIdx.x * (unsigned)kGrp + (unsigned)lane;
-    const bool in_queue = lane < kGrp;
-    const int e_raw = in_queue ? c.dyn_sorted[slot] : -1;
-    const bool queued = (e_raw >= 0) & ((e_raw & kDynSortedEnvMask) < c.n_envs);
-    if (!__any(queued) && blockIdx.x != 0) return; // wave-uniform: nothing queued for this workgroup
-    if (queued) c.dyn_sorted[slot] = -1;           // the next sort writes entries only
-    const int e = queued ? (e_raw & kDynSortedEnvMask) : 0;
-    if (blockIdx.x == 0) // the sort is done with its bucket counters: the next step's classify pass starts from zero
-        for (int i = lane; i < kDynBuckets; i += 64) c.dyn_count[kDynBucket0 + i * kDynBucketStride] = 0u;
+    // This wave's 48 entries, from the bucket counters alone.  Lane m reads the eight age counters of map bucket m; a map's
+    // stretch of the (virtual) queue is its eight buckets in age order, rounded up to a whole wave, and the stretches follow each
+    // other in map order: an inclusive scan of the rounded lengths tells every lane where its map starts, the one lane whose
+    // stretch holds this wave's first slot names the wave's map, and its eight counts place every lane in an age bucket.
+    static_assert(kDynMapBuckets == 64 && kDynAgeBuckets == 8, "one lane per map bucket, eight counters each");
+    const unsigned *cnt_set = c.dyn_count + (size_t)c.dyn_par * kDynCountWords;
+    unsigned ac[kDynAgeBuckets];
+#pragma unroll
+    for (int j = 0; j < kDynAgeBuckets; ++j) ac[j] = cnt_set[dyn_counter_word((unsigned)(kDynAgeBuckets * lane + j))];
+    if (blockIdx.x == 0) { // the OTHER counter set is the step kernel's to fill for the next step: it starts from zero
+        unsigned *other = c.dyn_count + (size_t)(c.dyn_par ^ 1) * kDynCountWords;
+        for (int i = lane; i < kDynBuckets; i += 64) other[dyn_counter_word((unsigned)i)] = 0u;
+    }
+    unsigned n_map = 0;
+#pragma unroll
+    for (int j = 0; j < kDynAgeBuckets; ++j) n_map += min(ac[j], (unsigned)c.n_pad); // (clamped: garbage counters must not index past an array)
+    const unsigned r_map = (n_map + (unsigned)(kGrp - 1)) / (unsigned)kGrp * (unsigned)kGrp;
+    unsigned incl = r_map;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        incl += (lane >= o) ? v : 0u;
+    }
+    const unsigned start = incl - r_map;
+    const unsigned slot0 = (unsigned)blockIdx.x * (unsigned)kGrp; // (a stretch is a multiple of kGrp slots: a wave never straddles two maps)
+    const unsigned long long owner = __ballot((start <= slot0) & (slot0 < incl));
+    if (owner == 0ull) return; // past the end of the queue (block 0 always finds an owner or an empty queue: see below)
+    const int qmap = __ffsll((long long)owner) - 1; // wave-uniform: the map bucket of this wave
+    const unsigned off = slot0 - (unsigned)__builtin_amdgcn_readlane((int)start, qmap) + (unsigned)lane; // this lane's entry inside the map's stretch
+    unsigned base = 0;
+    int qage = 0;
+    unsigned in_bucket = off;
+    bool queued = lane < kGrp;
+    {
+        unsigned total = 0;
+#pragma unroll
+        for (int j = 0; j < kDynAgeBuckets; ++j) {
+            const unsigned aj = min((unsigned)__builtin_amdgcn_readlane((int)ac[j], qmap), (unsigned)c.n_pad);
+            const bool here = (off >= total) & (off < total + aj);
+            qage = here ? j : qage;
+            base = here ? total : base;
+            total += aj;
+        }
+        queued &= off < total;
+        in_bucket = off - base;
+    }
+    if (!__any(queued)) return; // wave-uniform (only the rounding of a map's last wave)
+    const int e_q = queued ? c.dyn_bucket[(size_t)(kDynAgeBuckets * qmap + qage) * (size_t)c.n_pad + in_bucket] : 0;
+    queued &= (e_q >= 0) & (e_q < c.n_envs);
+    const int e = queued ? e_q : 0;
     const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
     const int cbase = kGrp * lane_doubles;
     const int sbank = cbase + kHullDoubles * (1 + SSG_N_TRAFFIC); // UNI: the wave's two banks, plane-major as in the per-lane columns
@@ -772,7 +737,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     double rw[kDynRow];
     {
         // from the env's row of the row-major shadow: 40 16-byte loads over five cache lines of this lane, instead of 75 column
-        // gathers over 75 x 64 lines per wave (the sorted queue scatters a wave's envs over the whole batch)
+        // gathers over 75 x 64 lines per wave (the bucketed queue scatters a wave's envs over the whole batch)
         const double2 *row2 = reinterpret_cast<const double2 *>(c.dyn_row + (size_t)e * kDynRow);
 #pragma unroll
         for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
@@ -780,9 +745,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     stage_hulls(c, d, cbase, lane);
     int map_id = map_col;
     if (UNI) {
-        const unsigned long long qm = __ballot(queued);
-        if (qm == 0ull) return;
-        map_id = __builtin_amdgcn_readlane(e_raw >> kDynSortedMapShift, __ffsll((long long)qm) - 1); // (the sort put it there)
+        if (!__any(queued)) return;
+        map_id = qmap; // (banks of at most 64 records: the wave's map bucket IS its record — known before the entries are)
         const double *rec_u = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
         for (int q = lane; q < 2 * kBankDoubles; q += 64) {
             const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
@@ -1510,20 +1474,19 @@ hipError_t prepare_dyn(const DevCfg &c)
 
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream)
 {
-    // (the classify pass over every env only when the host touched the envs,) the sort, then the full step over the sorted
-    // queue (grid sized for the worst case: every env queued and every map's stretch rounded up to a wave; workgroups past the
-    // queue's end leave at once).  The step kernel that follows empties the queue counter.
+    // (the classify pass over every env only when the host touched the envs,) then the full step over the bucketed queue (grid
+    // sized for the worst case: every env queued and every map's stretch rounded up to a wave; workgroups past the queue's end
+    // leave at once).
     static const int stop_after = [] { const char *sv = getenv("SSG_DYN_STOP"); return sv ? atoi(sv) : 0; }(); // dev aid
     DynCfg dd = d;
     dd.stop_after = stop_after;
     if (classify)
         hipLaunchKernelGGL(dyn_classify_kernel, dim3((unsigned)((c.n_pad + kClassifyThreads - 1) / kClassifyThreads)),
                            dim3(kClassifyThreads), 0, stream, c, dd);
-    hipLaunchKernelGGL(dyn_sort_kernel, dim3((unsigned)(c.n_pad / 256)), dim3(256), 0, stream, c, dd);
-    // one bank record per wave: the sort's buckets tell records apart only when the bank holds at most kDynMapBuckets of them
+    // one bank record per wave: the buckets tell records apart only when the bank holds at most kDynMapBuckets of them
     // (a per-env ring of worlds never does)
     const bool uni = c.map_ring == 0 && c.n_maps <= kDynMapBuckets;
-    const dim3 grid((unsigned)((c.n_pad + kDynSortedPad) / kGrp));
+    const dim3 grid((unsigned)((c.n_pad + kDynPad) / kGrp));
     if (uni) hipLaunchKernelGGL(dyn_step_kernel<true>, grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
     else hipLaunchKernelGGL(dyn_step_kernel<false>, grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
     return hipGetLastError();

@@ -34,18 +34,23 @@ enum {
 enum { DU_META = 0 /* state | age << 3 | count << 5 */, DU_HASH = kDynPairs /* contact hashes, polygon pairs */,
        DU_COUNT = kDynPairs + kPolyPairs };
 
-// The queue of the full dyn step is sorted by (bank record, steps since the reset): after a reset the traffic ships and goal
+// The queue of the full dyn step is BUCKETED by (bank record, steps since the reset): after a reset the traffic ships and goal
 // bodies of an env replay a transient that depends on its world and age only (the player pushes nothing), so envs of one
-// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.  The order is
-// MAP-MAJOR and every map's stretch of the sorted queue starts on a wave boundary (kDynGrp slots; the gaps hold -1): the
-// lanes of a wave of the full step all sit on one bank record, which it then keeps once per wave instead of once per lane.
+// bucket walk the same code path and a wave of bucket-mates does not pay for the union of 64 different ones.  Every bucket has
+// its own array of n_pad slots (DevCfg::dyn_bucket) and its own counter; a producer appends with one returning atomic.  The
+// full step walks the buckets MAP-MAJOR, every map's stretch rounded up to a wave (kDynGrp slots): the lanes of a wave all sit
+// on one bank record, which it then keeps once per wave instead of once per lane — and finds its 48 entries from the 512
+// counters alone (rounds 2-4 ran a counting-sort kernel between the producers and the full step: 5.4 us per step).
 constexpr int kDynAgeBuckets = 8, kDynMapBuckets = 64, kDynBuckets = kDynAgeBuckets * kDynMapBuckets;
 constexpr int kDynGrp = 48;       // envs per wave of the full step (shipsim_dynamics.hip: kGrp)
-constexpr int kDynSortedPad = kDynMapBuckets * kDynGrp; // slots of dyn_sorted beyond n_pad: every map's stretch rounded up to a wave
-constexpr int kDynSortedMapShift = 25, kDynSortedEnvMask = (1 << 25) - 1; // a dyn_sorted entry: env | bucket's map index << 25
-constexpr int kDynBucket0 = 64;   // first bucket counter, in unsigned words after dyn_count[0]
-constexpr int kDynBucketStride = 32; // one counter per 128-byte line: atomics on neighbouring words of ONE line serialise in the L2
-constexpr int kDynCountWords = kDynBucket0 + kDynBuckets * kDynBucketStride;
+constexpr int kDynPad = kDynMapBuckets * kDynGrp; // slots beyond n_pad the full step's grid covers: every map's stretch rounded up to a wave
+// Counters: one per 128-byte line.  (Atomics on neighbouring words of ONE line serialise in the L2.  Measured with the bucketed
+// queue: a map's eight age counters in one line — two 16-byte loads per lane at the head of the full step instead of eight
+// 4-byte ones over 512 lines — made the full step 1.1 us faster and the step kernel, whose returning atomics then meet on 64
+// lines, 1.7 us slower.)
+constexpr int kDynBucketStride = 32;
+constexpr int kDynCountWords = kDynBuckets * kDynBucketStride; // one set; DevCfg::dyn_count holds two (see dyn_par)
+__host__ __device__ __forceinline__ constexpr int dyn_counter_word(unsigned bucket) { return (int)bucket * kDynBucketStride; }
 // sort bucket of an env that is `age` steps into its episode on bank record `map_id`
 __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 {
@@ -94,17 +99,15 @@ struct DevCfg {
                                   // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
     unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
     // The queue of the full dyn step.  Produced for step t+1 by the step kernel's body role at the end of step t (or, after a
-    // host-side reset / bank change / ssg_dyn_invalidate, by dyn_classify_kernel): SEGMENTED, one segment of 64 slots per tile
-    // of 64 envs (entries dyn_queue[64*s + i], i < dyn_segcnt[s]: no atomics to append), each entry with its sort bucket and
-    // arrival number; dyn_sort_kernel turns it into dyn_sorted and counts it.
-    int32_t *dyn_queue;
-    unsigned *dyn_segcnt;         // [n_pad / 64] entries per segment; every producer writes every segment's count
-    unsigned *dyn_count;          // [0] length of dyn_sorted incl. its gaps (dyn_sort_kernel writes, the step kernel zeroes); [kDynBucket0 ..) bucket counts
-    unsigned long long *dyn_qkey; // per queue entry: sort bucket << 32 | arrival number inside the bucket
+    // host-side reset / bank change / ssg_dyn_invalidate, by dyn_classify_kernel): one array of n_pad env indices per sort bucket,
+    // filled in arrival order (a returning atomic on the bucket's counter).  Two counter sets: the full step reads set dyn_par
+    // and zeroes the other one, into which the step kernel that follows counts the next step's entries; the host flips dyn_par
+    // after every step.
+    int32_t *dyn_bucket;          // [kDynBuckets][n_pad]
+    unsigned *dyn_count;          // [2][kDynCountWords]: bucket b's counter at dyn_counter_word(b) of its set
+    int dyn_par;                  // the counter set that holds THIS step's queue
     double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2: the step kernel's reject in front of collide_ship's exact test
     double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS]; // the traffic hulls (local), for that test
-    int32_t *dyn_sorted;          // [n_pad + kDynSortedPad] the queue ordered by bucket (dyn_sort_kernel), -1 in the gaps: what the full dyn
-                                  // step walks (and resets to -1 behind itself)
     double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
 };
 

@@ -1411,8 +1411,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 #endif
 
     bool q_need = false; // config 4: this env's entry in the next step's queue (see the classification after the rendezvous)
-    unsigned q_slot = 0, q_arrival = 0;
-    unsigned long long q_key = 0ull;
+    unsigned q_bucket = 0, q_arrival = 0;
     for (int k = 0; k < K; ++k) {
 #ifdef SSG_STAMPS_ITER
     if (k < 8) SSG_STAMP(k); // (diagnostic: when does each of a launch's first 8 steps start, and the last one?)
@@ -1586,7 +1585,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     bool colliding = gres[(k & 1) * EPW + tl] != 0u; // collide_ship result (role 0; role 2 in a launch's first step)
     if constexpr (DYN) {
         colliding |= traffic_hit(k) != 0u; // ... and against the traffic ships (the lidar roles)
-        if (blockIdx.x == 0 && threadIdx.x == 3 * EPW) *c.dyn_count = 0u; // next step's queue starts empty
     }
 
     // ---- determine_reward (ship_env.py:62-77) ----
@@ -1605,8 +1603,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         }
         // Which envs need the full cpSpaceStep of their other bodies NEXT step (shipsim_dynamics.hip)?  Everything that decides
         // it is in this role's registers now: a reset env (fresh bodies), an env whose bodies are not at rest, one that lost a
-        // goal holding a cached arbiter this step.  The others keep their rest bit.  Queue = one segment per tile:
-        // no atomics to append; the entry carries its sort bucket (steps since the reset, bank record).
+        // goal holding a cached arbiter this step.  The others keep their rest bit.  Queue = one array per sort bucket (steps
+        // since the reset, bank record), appended to with a returning atomic on the bucket's counter.
         bool need_full = false;
         if (live) {
             bool resting = !do_reset & ((dflag & 4u) != 0u);
@@ -1627,18 +1625,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             }
             need_full = !resting;
         }
-        const unsigned long long qm = __ballot(need_full);
-        const int seg = (blockIdx.x * EPW + tl) >> 6; // this tile's segment (wave-uniform)
-        if (lane == 0) c.dyn_segcnt[seg] = (unsigned)__popcll(qm);
         if (need_full) {
-            const unsigned slot = (unsigned)seg * 64u + (unsigned)__popcll(qm & ((1ull << lane) - 1ull));
             const unsigned bucket = dyn_bucket_of(do_reset ? 0 : steps, map_id); // (map_id is already the next episode's record)
-            c.dyn_queue[slot] = el_;
-            // The arrival number is a returning atomic: a round trip of several microseconds behind the tile's stores.  It is
-            // asked for first thing after the rendezvous and stored (with the bucket) as this role's LAST instruction.
-            q_slot = slot;
-            q_key = (unsigned long long)bucket << 32;
-            q_arrival = atomicAdd(c.dyn_count + kDynBucket0 + bucket * kDynBucketStride, 1u);
+            // The slot in the bucket's array is a returning atomic: a round trip of several microseconds behind the tile's stores.
+            // It is asked for first thing after the rendezvous; the entry is stored as this role's LAST instruction.  (The NEXT
+            // step's counter set: the dyn kernel of this step zeroed it.)
+            q_bucket = bucket;
+            q_arrival = atomicAdd(c.dyn_count + (size_t)(c.dyn_par ^ 1) * kDynCountWords + dyn_counter_word(bucket), 1u);
         }
         q_need = need_full;
     }
@@ -1677,7 +1670,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     SSG_STAMP_K(5);
     if constexpr (DYN) {
-        if (k < K - 1 && q_need) c.dyn_qkey[q_slot] = q_key | (unsigned long long)q_arrival; // (DYN launches are single steps: never taken)
+        if (k < K - 1 && q_need && q_arrival < (unsigned)c.n_pad) c.dyn_bucket[(size_t)q_bucket * np + q_arrival] = el_; // (DYN launches are single steps: never taken)
     }
     } // k
     if (live) {
@@ -1704,7 +1697,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     if constexpr (DYN) {
         asm volatile("" : "+v"(q_arrival)); // (first use of the atomic's result: not before this point)
-        if (q_need) c.dyn_qkey[q_slot] = q_key | (unsigned long long)q_arrival;
+        if (q_need && q_arrival < (unsigned)c.n_pad) c.dyn_bucket[(size_t)q_bucket * np + q_arrival] = el_; // (a bucket holds n_pad slots: every env once)
     }
     SSG_STAMP(10);
     SSG_STAMP_FLUSH(6);
