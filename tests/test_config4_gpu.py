@@ -49,7 +49,8 @@ def _compare_dyn(N, vec, ob, just_reset=None, atol=1e-9):
 
 
 # (banks of more than 64 records: the full dyn step's waves no longer sit on ONE record each — its per-lane-planes variant)
-@pytest.mark.parametrize("n,nb,K,n_maps", [(4096, 10, 160, 64), (777, 8, 120, 64), (2048, 10, 100, 96)])
+@pytest.mark.parametrize("n,nb,K,n_maps", [(4096, 10, 160, 64), (777, 8, 120, 64), (2048, 10, 100, 96),
+                                           (3000, 8, 60, 1)])  # one world: after the reset ONE bucket of the dyn queue holds every env
 def test_config4_parity(n, nb, K, n_maps):
     torch, O, N, ShipVecEnv = _mods()
     from helpers import oracle_cfg
