@@ -98,6 +98,19 @@ def traj_bytes_per_step(n, D):
     return n * (8 * D + 8 + 1 + 1)
 
 
+def state_bytes_per_env(nb):
+    """The state columns one launch reads (first step) and writes back (last step): 7 + nb f64, 4 i32, the goal mask."""
+    return 2 * ((7 + nb) * 8 + 4 * 4 + 1)
+
+
+def fused_compulsory_bytes(nb, D, steps_in_launch):
+    """Compulsory HBM bytes per env-step of the FUSED rollout API (ssg_rollout_traj): every step's outputs (obs row, reward,
+    done, flags) and its action, plus the state columns once per launch.  The honest HBM denominator of a kernel that keeps
+    the state in registers across the fused steps (the 675 B of SURVEY 8d charge every step a state read + write and a
+    re-read of the previous frame)."""
+    return traj_bytes_per_step(1, D) + 4 + state_bytes_per_env(nb) / float(steps_in_launch)
+
+
 def steps_per_launch_cfg():
     return max(1, int(os.environ.get("SSG_FUSE", "100")))  # SSG_ROLLOUT_STEPS_PER_LAUNCH (include/shipsim.h)
 
@@ -474,9 +487,18 @@ def main():
             "repeats": R, "repeats_ms": [w * 1e3 for w in walls], "timing": "median of %d repeats of the K-step rollout" % R,
             "roofline": dict({"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS,
-                              "frac_note": "algorithmic 675 B/env-step formula of SURVEY 8d over the live launch time; the bytes the "
-                                           "kernel really moves are in hbm_measured",
-                              "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
+                              "frac_note": "SURVEY 8d's algorithmic bytes per env-step (single-step API with persistent state) over "
+                                           "the live launch time (HIP events); it charges every step a state read + write and a "
+                                           "re-read of the previous frame, which a fused launch keeps in registers, so it can "
+                                           "exceed what the kernel moves: frac_wall is the same formula over the wall time "
+                                           "`value` uses, frac_fused_compulsory the bytes the fused API must move",
+                              # the same formula over the driver-visible wall time (value = envs x steps / wall)
+                              "frac_wall": B * (total_steps / world / wall) / 1e9 / HBM_PEAK_GBPS,
+                              # what the fused API has to move: outputs + action every step, the state once per launch
+                              "fused_compulsory_bytes_per_env_step": (None if c4 else fused_compulsory_bytes(n_beams, vec.states_history, steps_in_launch)),
+                              "frac_fused_compulsory": (None if c4 else fused_compulsory_bytes(n_beams, vec.states_history, steps_in_launch)
+                                                        * env_steps_per_s_kernel / 1e9 / HBM_PEAK_GBPS),
+                              "measured_copy_GBps": copy_gbps,
                               "kernel": ("ssg::dyn_* kernels + ssg::step_kernel<10, 256, true, false, true>"
                                          if c4 else "ssg::step_kernel<8, 256, true, false, false>"),
                               "algorithmic_bytes_per_env_step": B,

@@ -30,6 +30,14 @@ def test_bench_line_carries_the_contract_fields():
         assert k in r, k
     assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["algorithmic_bytes_per_env_step"] == 675 and r["avg_launch_us"] > 0
+    # what binds, without fractions above 1: the 675 B formula over the wall time `value` uses, and the bytes the FUSED API
+    # must move (outputs 234 + action 4 + the state columns once per 20-step launch)
+    for k in ("frac_wall", "fused_compulsory_bytes_per_env_step", "frac_fused_compulsory", "measured_copy_GBps"):
+        assert k in r, k
+    assert "frac_of_measured_copy" not in r
+    assert abs(r["frac_wall"] - 675 * j["value"] / 1e9 / 8000.0) < 1e-9
+    assert abs(r["fused_compulsory_bytes_per_env_step"] - (234 + 4 + 2 * ((7 + 8) * 8 + 17) / 20.0)) < 1e-9
+    assert 0 < r["frac_fused_compulsory"] < 1 and r["frac_wall"] <= r["frac"] * 1.0001
     cb = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

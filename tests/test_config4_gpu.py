@@ -33,10 +33,9 @@ def _oracle_dyn(ob, idx):
 
 
 def _compare_dyn(N, vec, ob, just_reset=None, atol=1e-9):
-    """Traffic / goal body columns against the oracle's bodies.  The body COLUMNS of an auto-reset env lag its reset by two
-    steps (include/shipsim.h, SSG_F_TRAFFIC: in the step after the reset the step kernel reads the new world from the table
-    its N slot published; the dyn step after that continues from the slot into the columns): `just_reset` = the envs that
-    were reset by one of the last two steps are left out."""
+    """Traffic / goal body columns against the oracle's bodies.  The body COLUMNS of an auto-reset env lag its reset by ONE
+    step: the step kernel only flags the env (dyn flag bit 1) and the next dyn step rebuilds its bodies (ShipGame.reset +
+    add_default_traffic) and writes every column.  `just_reset` = the envs reset by the step just taken are left out."""
     idx = np.arange(vec.num_envs)
     keep = np.ones(vec.num_envs, dtype=bool) if just_reset is None else ~just_reset.astype(bool)
     t_g, g_g = _dyn_state(N, vec)
@@ -64,7 +63,6 @@ def test_config4_parity(n, nb, K, n_maps):
     r_done = np.zeros(n, dtype=np.uint8)
     for k in range(K):
         obs, rew, done, flags = vec.step_tensor(acts[k])
-        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
         np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
         np.testing.assert_array_equal(rew.cpu().numpy(), r_rew, err_msg="reward differs at step %d" % k)
@@ -74,7 +72,7 @@ def test_config4_parity(n, nb, K, n_maps):
         n_done += int(r_done.sum())
         n_col += int(((flags.cpu().numpy() & N.EV_COLLIDING) != 0).sum())
         if k in (0, 1, 2, 7, 40, K - 1):
-            _compare_dyn(N, vec, ob, just_reset=r_done | p_done)
+            _compare_dyn(N, vec, ob, just_reset=r_done)
     assert n_done > n // 4 and n_col > 0
     assert max_err <= 1e-9
     vec.close()
@@ -100,7 +98,6 @@ def test_config4_rollout_matches_oracle_every_step(n, nb, K, n_maps):
     worst, n_done, n_goal = 0.0, 0, 0
     r_done = np.zeros(n, dtype=np.uint8)
     for k in range(K):
-        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
         np.testing.assert_array_equal(g_done[k], r_done, err_msg="done differs at rollout step %d" % k)
         np.testing.assert_array_equal(g_rew[k], r_rew, err_msg="reward differs at rollout step %d" % k)
@@ -109,7 +106,7 @@ def test_config4_rollout_matches_oracle_every_step(n, nb, K, n_maps):
         worst = max(worst, err)
         n_done += int(r_done.sum()); n_goal += int((r_rew == 1.0).sum())
     assert worst <= 1e-9 and n_done > n // 4 and n_goal > 0
-    _compare_dyn(N, vec, ob, just_reset=r_done | p_done)
+    _compare_dyn(N, vec, ob, just_reset=r_done)
     # the same steps, one launch sequence per step
     b = ShipVecEnv(n, n_beams=nb, n_maps=n_maps, n_ships=4)
     b.reset_tensor()
@@ -117,7 +114,7 @@ def test_config4_rollout_matches_oracle_every_step(n, nb, K, n_maps):
         o, r, d, f = b.step_tensor(acts[k])
         assert torch.equal(o, torch.from_numpy(g_obs[k]).to(o.device)), "step %d" % k
         assert torch.equal(d, torch.from_numpy(g_done[k]).to(d.device)) and torch.equal(f, torch.from_numpy(g_flags[k]).to(f.device))
-    keep = torch.from_numpy(~(r_done | p_done).astype(bool)).to(b.device)
+    keep = torch.from_numpy(~r_done.astype(bool)).to(b.device)
     assert torch.equal(b.field(N.F_TRAFFIC)[:, keep], vec.field(N.F_TRAFFIC)[:, keep])
     assert torch.equal(b.field(N.F_X), vec.field(N.F_X)) and torch.equal(b.field(N.F_GOAL_MASK), vec.field(N.F_GOAL_MASK))
     vec.close(); b.close()
@@ -168,12 +165,11 @@ def test_config4_solver_scenarios():
     for k in range(K):
         a = torch.from_numpy(acts[k]).to(vec.device)
         obs, rew, done, flags = vec.step_tensor(a)
-        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts[k], auto_reset=True)
         np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
         np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
         assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
-        _compare_dyn(N, vec, ob, just_reset=r_done | p_done, atol=1e-8)
+        _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
         n_col += int(((flags.cpu().numpy() & N.EV_COLLIDING) != 0)[3::4].sum())
         struck |= np.abs(_dyn_state(N, vec)[0][:, 2, 3:]).max(axis=1) > 0      # ship 3 acquired a real velocity
     assert n_col >= n // 8                                # the player did run into the parked ships
@@ -232,11 +228,10 @@ def test_config4_rest_bit_and_poke_at_rest():
     r_done = np.zeros(n, dtype=np.uint8)
     for k in range(25):
         obs, rew, done, flags = vec.step_tensor(ones)
-        p_done = r_done
         r_obs, r_rew, r_done = ob.step(np.ones(n, dtype=np.int32))
         np.testing.assert_array_equal(done.cpu().numpy(), r_done)
         assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
-        _compare_dyn(N, vec, ob, just_reset=r_done | p_done, atol=1e-8)
+        _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
     t, _ = _dyn_state(N, vec)
     assert (np.abs(t[idx, 2, 0] - 400.0) > 1e-3).mean() > 0.9     # ship 3 was really pushed in the poked envs
     vec.close()
@@ -311,13 +306,12 @@ def test_config4_curriculum_maps():
     r_done = np.zeros(n, dtype=np.uint8)
     for k in range(12, 130):
         obs, rew, done, flags = vec.step_tensor(acts[k])
-        p_done = r_done
         r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
         np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
         np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
         assert float(np.max(np.abs(obs.cpu().numpy() - r_obs))) <= 1e-9
         if k % 10 == 0:
-            _compare_dyn(N, vec, ob, just_reset=r_done | p_done, atol=1e-8)
+            _compare_dyn(N, vec, ob, just_reset=r_done, atol=1e-8)
             moved3 |= bool((_dyn_state(N, vec)[0][:, 0, 0] > 170.0).any())
     assert moved3                                                 # ship 1 is pushed out of a left bank wider than lesson 0's 150
     vec.close()
