@@ -39,3 +39,37 @@ def run_pair(O, N, vec, K, seed=12345, check_every=1, atol=1e-5):
             max_err = max(max_err, err)
             n_done += int(r_done.sum())
     return max_err, n_done
+
+
+class OracleSample:
+    """The oracle on a random SAMPLE of a large batch's envs (BASELINE sizes: 65 536 .. 1 048 576 envs).  Envs are independent
+    and everything an env sees is keyed by its GLOBAL id — bank record (env_id_base + e) mod n_maps, Philox action stream — so
+    the oracle world of env e stepped with column e of the batch's action tensor must reproduce row e of every output, whatever
+    the batch size: reward / done bit-exact, observations within `atol`, every step."""
+
+    def __init__(self, O, vec, m=2048, seed=0):
+        n = vec.num_envs
+        rng = np.random.RandomState(seed)
+        self.idx = np.sort(rng.choice(n, size=min(m, n), replace=False))
+        # (the first and the last env, a wave boundary and a workgroup boundary are always in)
+        self.idx = np.unique(np.concatenate([self.idx, [0, n - 1, min(n - 1, 63), min(n - 1, 64), min(n - 1, 255), min(n - 1, 256)]]))
+        self.ob = O.Batch(len(self.idx), oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals,
+                          map_ids=(vec.env_id_base + self.idx) % vec.n_maps)
+        self.worst, self.n_done, self.steps = 0.0, 0, 0
+        import torch
+        self.tidx = torch.as_tensor(self.idx, device=vec.device)
+
+    def reset(self, obs_gpu):
+        np.testing.assert_array_equal(obs_gpu[self.tidx].cpu().numpy(), self.ob.reset())
+
+    def step(self, acts_k, obs, rew, done, atol=1e-5, n_threads=8):
+        """acts_k: this step's [n] action row (device tensor); obs / rew / done: the batch's outputs of the step."""
+        a = acts_k[self.tidx].cpu().numpy()
+        r_obs, r_rew, r_done = self.ob.step(a, auto_reset=True, n_threads=n_threads)
+        np.testing.assert_array_equal(done[self.tidx].cpu().numpy(), r_done, err_msg="sampled envs: done differs at step %d" % self.steps)
+        np.testing.assert_array_equal(rew[self.tidx].cpu().numpy(), r_rew, err_msg="sampled envs: reward differs at step %d" % self.steps)
+        err = float(np.max(np.abs(obs[self.tidx].cpu().numpy() - r_obs)))
+        assert err <= atol, "sampled envs: obs differ by %g at step %d" % (err, self.steps)
+        self.worst = max(self.worst, err)
+        self.n_done += int(r_done.sum())
+        self.steps += 1

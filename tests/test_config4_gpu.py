@@ -178,14 +178,28 @@ def test_config4_solver_scenarios():
 
 
 def test_config4_full_size_properties():
-    """65 536 envs x 4 ships: properties that need no oracle at this size."""
+    """BASELINE configs[3] at full size (65 536 envs x 4 ships, 10 beams): ~2 050 randomly chosen envs against the oracle at
+    every step (reward / done exact, observations 1e-5; bodies at the end), plus properties of the whole batch."""
     torch, O, N, ShipVecEnv = _mods()
+    from helpers import OracleSample
     n = 65536
     vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
-    vec.reset_tensor()
-    acts = vec.random_actions(99, 0, 50)
-    for k in range(50):
+    smp = OracleSample(O, vec, 2048, seed=4)
+    smp.reset(vec.reset_tensor())
+    acts = vec.random_actions(99, 0, 80)
+    for k in range(80):
         obs, rew, done, flags = vec.step_tensor(acts[k])
+        smp.step(acts[k], obs, rew, done, atol=1e-5)
+    assert smp.n_done > 500 and smp.worst <= 1e-9
+    # the sampled envs' bodies (traffic ships, goal circles) where the oracle's are; envs reset by the last step excluded
+    t_all, g_all = _dyn_state(N, vec)
+    t_o, g_o = _oracle_dyn(smp.ob, np.arange(len(smp.idx)))
+    keep = ~smp.ob.done.astype(bool)
+    np.testing.assert_allclose(t_all[smp.idx][keep], t_o[keep], atol=1e-8, rtol=0)
+    mask = vec.field(N.F_GOAL_MASK).cpu().numpy()[smp.idx]
+    for g in range(5):
+        alive = (mask >> g & 1).astype(bool) & keep
+        np.testing.assert_allclose(g_all[smp.idx][alive, g], g_o[alive, g], atol=1e-8, rtol=0)
     assert torch.isfinite(obs).all()
     t, g = _dyn_state(N, vec)
     assert np.isfinite(t).all() and np.isfinite(g).all()

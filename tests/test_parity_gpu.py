@@ -6,7 +6,7 @@ The oracle itself is "parity unpinned" at the pymunk boundary (oracle/ssg_oracle
 import numpy as np
 import pytest
 
-from helpers import oracle_cfg, run_pair
+from helpers import OracleSample, oracle_cfg, run_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -344,17 +344,20 @@ def test_full_size_properties(torch_cuda, native):
     assert st["episodes"] == ep_done and ep_done > n // 2
 
 
-def test_full_size_fused_trajectory_properties(torch_cuda, native):
+def test_full_size_fused_trajectory_properties(torch_cuda, oracle, native):
     """The benchmark's own launch shape — BASELINE configs[2] at full size, 100 fused steps per launch, trajectory outputs —
     through size-independent properties of EVERY step: history chaining between consecutive slots, reset rows, the three
-    reward values, flag / reward consistency, lidar ranges; and slot by slot equal to a second handle that gathers its bank
-    from L2 instead of staging it in LDS (an independent instantiation of the kernel)."""
+    reward values, flag / reward consistency, lidar ranges; slot by slot equal to a second handle that gathers its bank
+    from L2 instead of staging it in LDS (an independent instantiation of the kernel); and, for ~2 050 randomly chosen envs
+    of the 65 536, every step of the trajectory against the ORACLE (reward / done exact, observations within 1e-5)."""
     torch = torch_cuda
     n, K = 65536, 200
     vec = _vec(n, n_maps=64, n_beams=8)
     ref = _vec(n, n_maps=64, n_beams=8, bank_in_global=True)
     F = vec.n_states
+    smp = OracleSample(oracle, vec, 2048, seed=65536)
     obs0 = vec.reset_tensor().clone(); ref.reset_tensor()
+    smp.reset(obs0)
     acts = vec.random_actions(2025, 0, K)
     to, tr, td, tf = vec.rollout_tensor(acts, trajectory=True)
     ro, rr, rd, rf = ref.rollout_tensor(acts, trajectory=True)
@@ -362,6 +365,7 @@ def test_full_size_fused_trajectory_properties(torch_cuda, native):
     prev = obs0
     for k in range(K):
         obs, rew, done, flags = to[k], tr[k], td[k], tf[k]
+        smp.step(acts[k], obs, rew, done, atol=ATOL)
         cont = done == 0
         assert torch.equal(obs[cont][:, :F], prev[cont][:, F:]), k        # oldest-first history (ship_env.py:113,181)
         rs = ~cont
@@ -376,6 +380,9 @@ def test_full_size_fused_trajectory_properties(torch_cuda, native):
     st = vec.stats()
     assert st["episodes"] == int(td.sum()) and st["episodes"] > n // 2
     assert torch.equal(to[K - 1][:, F], vec.field(native.F_X)) and torch.equal(to[K - 1][:, F + 1], vec.field(native.F_Y))
+    assert smp.n_done > 1000 and smp.worst <= 1e-9
+    print("configs[2] at 65 536 envs: %d sampled envs x %d fused steps vs the oracle, %d episode ends, max |obs - oracle| = %.3e"
+          % (len(smp.idx), K, smp.n_done, smp.worst))
 
 
 def test_trajectory_rewards_add_up_to_the_in_kernel_episode_statistics(torch_cuda, native):
@@ -622,17 +629,72 @@ def test_edge_configurations(torch_cuda, oracle, native):
     assert hit > 20
 
 
-def test_million_envs_smoke(torch_cuda, native):
-    """BASELINE configs[4] size on ONE device (1 048 576 envs, 10 beams): runs, stays finite, statistics add up."""
+def test_million_envs_smoke(torch_cuda, oracle, native):
+    """BASELINE configs[4] size on ONE device (1 048 576 envs, 10 beams): runs, stays finite, statistics add up, and ~2 050
+    randomly chosen envs of the million agree with the oracle at every step."""
     torch = torch_cuda
     v = _vec(1 << 20, n_maps=64, n_beams=10)
-    v.reset_tensor()
-    acts = v.random_actions(1, 0, 30)
+    smp = OracleSample(oracle, v, 2048, seed=1 << 20)
+    smp.reset(v.reset_tensor())
+    acts = v.random_actions(1, 0, 60)
     eps = 0
-    for k in range(30):
+    for k in range(60):
         obs, rew, done, flags = v.step_tensor(acts[k])
+        smp.step(acts[k], obs, rew, done, atol=ATOL)
         eps += int(done.sum())
     assert bool(torch.isfinite(obs).all()) and v.stats()["episodes"] == eps and eps > 1000
+    assert smp.n_done > 100 and smp.worst <= 1e-9
+    v.close()
+
+
+@pytest.mark.parametrize("rank", [0, 5, 7])
+def test_configs4_rank_share_against_the_oracle(torch_cuda, oracle, native, rank):
+    """BASELINE configs[4] as a rank of the 8-GPU job sees it: 131 072 envs, 10 beams, global env ids
+    [rank * 131 072, (rank + 1) * 131 072) — fused trajectory rollout (two launches), every step of ~2 050 sampled envs against
+    oracle worlds built from their GLOBAL ids (bank record and Philox stream)."""
+    torch = torch_cuda
+    n, K = 131072, 120
+    v = _vec(n, n_maps=64, n_beams=10, env_id_base=rank * n)
+    smp = OracleSample(oracle, v, 2048, seed=rank)
+    smp.reset(v.reset_tensor())
+    acts = v.random_actions(12345, 0, K)
+    np.testing.assert_array_equal(acts[:, smp.tidx[:8]].cpu().numpy(),
+                                  np.stack([oracle.fill_actions(12345, 0, K, rank * n + int(e), 1)[:, 0] for e in smp.idx[:8]], axis=1))
+    to, tr, td, tf = v.rollout_tensor(acts, trajectory=True)
+    for k in range(K):
+        smp.step(acts[k], to[k], tr[k], td[k], atol=ATOL)
+    assert smp.n_done > 500 and smp.worst <= 1e-9
+    v.close()
+
+
+@pytest.mark.parametrize("n_ships", [1, 4])
+def test_reference_random_rollout_configuration(torch_cuda, oracle, native, n_ships):
+    """train/random.py:4-7 — the reference's own random-action rollout: GameConfig.SPEED = 1 (dt = 0.1, damping 0.4^0.1 per
+    step), default bounds and EnvConfig: small steps, long episodes that mostly end on MAX_STEPS.  Single steps and a fused
+    trajectory rollout against the oracle, with and without add_default_traffic."""
+    torch = torch_cuda
+    from ship_sim_gym_amd.config import EnvConfig, GameConfig
+
+    class G(GameConfig):
+        SPEED = 1
+
+    v = _vec(700, game_config=G, env_config=EnvConfig, n_maps=16, n_ships=n_ships)
+    assert abs(v.cfg.dt - 0.1) < 1e-15 and v.cfg.max_steps == 1000
+    err, n_done = run_pair(oracle, native, v, K=1100, seed=4242, check_every=1)
+    assert err <= (1e-9 if n_ships == 1 else 1e-8)
+    st = v.stats()
+    assert n_done >= 700 and st["episodes"] == n_done          # every env ran into MAX_STEPS at step 1000 (or ended earlier)
+    v.close()
+    # the same stream as one fused trajectory rollout (1-ship: 100-step launches; 4 ships: per-step launch sequences)
+    w = _vec(700, game_config=G, env_config=EnvConfig, n_maps=16, n_ships=n_ships)
+    smp = OracleSample(oracle, w, 700, seed=1)
+    smp.reset(w.reset_tensor())
+    acts = w.random_actions(4242, 0, 1050)
+    to, tr, td, tf = w.rollout_tensor(acts, trajectory=True)
+    for k in range(1050):
+        smp.step(acts[k], to[k], tr[k], td[k], atol=ATOL, n_threads=8)
+    assert int((tf[999] & native.EV_MAX_STEPS != 0).sum()) > 350   # step 1000: MAX_STEPS ends the episodes still running
+    w.close()
 
 
 def test_trainer_glue_runs_end_to_end(torch_cuda, native):
