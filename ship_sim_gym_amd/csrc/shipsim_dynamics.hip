@@ -667,7 +667,9 @@ __host__ __device__ constexpr int dyn_lane_doubles(int n_goals, bool uni)
     return B_STRIDE * (n_goals + SSG_N_TRAFFIC + 1) + X_STRIDE * SSG_N_TRAFFIC + A_STRIDE * kLdsArb + (uni ? 0 : 2 * kBankDoubles) + kEpaDoubles;
 }
 
-template <bool UNI>
+// MEMO: look the step of this env's state up in the memo table before walking the narrowphase / solver chain, and store
+// it there afterwards (shipsim_internal.h, kMemoEntries; UNI launches only: shared bank records are what makes states repeat).
+template <bool UNI, bool MEMO>
 __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynCfg d)
 {
     const int lane = threadIdx.x;
@@ -1067,6 +1069,185 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
     }
     SSG_TICK(emem, 5); // (profile builds: category 5 = the broadphase)
+    // ---- the memo: has the step of exactly this state been computed before? ------------------------------------------------
+    // Key = everything the rest of the step reads: the bank record, the three ships' fields, the fields of the goals that take
+    // part (still in the space, and moving or a broadphase candidate this step; the others are stepped by the identity and seen
+    // by nobody), the cached arbiters.  A lane whose state is in the table copies the stored result — verified word for word
+    // against the stored key, so it writes the bits the computation below would have written — and leaves; the rest compute and
+    // store.  (Entries written by this launch are not read by it: `born`.)
+    using u64 = unsigned long long;
+    auto dbits = [](double v) -> u64 { return (u64)__double_as_longlong(v); };
+    bool memo_try = false;    // this lane computes, then stores its result in the table
+    u64 *memo_ent = nullptr;  // ... in this entry,
+    u64 memo_tag = 0ull, memo_old = 0ull; // claimed by CAS(old -> tag)
+    unsigned memo_incl = 0u;
+    u64 memo_hdr = 0ull;
+    u64 memo_aged[kMemoAged] = {0ull, 0ull, 0ull, 0ull};
+    int memo_n_aged = 0;
+    if constexpr (MEMO) {
+        unsigned incl = 0u;
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+            // candidate bits goal g appears in: its two bank pairs, the goals h < g, goal g in the rows of the goals g' > g, the ships
+            u64 inv = (3ull << o_goal(g));
+#pragma unroll
+            for (int h = 0; h < g; ++h) inv |= 1ull << (o_goal(g) + 2 + h);
+#pragma unroll
+            for (int g2 = g + 1; g2 < SSG_MAX_GOALS; ++g2) inv |= 1ull << (o_goal(g2) + 2 + g);
+#pragma unroll
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) inv |= 1ull << (o_ship(k) + 2 + g);
+            const bool present = (g < ng) & (bool)((gmask >> g) & 1u);
+            bool moving = false;
+#pragma unroll
+            for (int f = 2; f < DC_GOAL_COLS; ++f) moving |= gin[g][f] != 0.0;
+            incl |= (present & (moving | ((cand & inv) != 0ull))) ? (1u << g) : 0u;
+        }
+        memo_incl = incl;
+        const int n_live = __popcll(live);
+        const bool memo_ok = n_live <= kMemoArbIn;
+        memo_hdr = (u64)(unsigned)map_id | ((u64)incl << 8) | ((u64)(unsigned)n_live << 16) | ((u64)(d.memo_fp & 0xFFFFu) << 24) |
+                   ((u64)(d.bank_epoch & 0xFFFFFFu) << 40);
+        // key word i (i is a constant wherever this is called: the loops below are unrolled)
+        auto kw = [&](int i) -> u64 {
+            if (i == 0) return memo_hdr;
+            if (i == 1) return live;
+            if (i < kMemoKeyGoals) { const int j = i - kMemoKeyShips; return dbits(tin[j / 9][j % 9]); }
+            if (i < kMemoKeyArbs) { const int j = i - kMemoKeyGoals; return ((incl >> (j / 8)) & 1u) ? dbits(gin[j / 8][j % 8]) : 0ull; }
+            if (i < kMemoKeyArbs + kMemoArbIn * kMemoArbWords) {
+                const int j = i - kMemoKeyArbs, a = j / kMemoArbWords, f = j % kMemoArbWords;
+                if (f == 0) return (ppid[a] < 0) ? 0xFFull : ((u64)(unsigned)ppid[a] | ((u64)pmeta[a] << 8) | ((u64)phh[a] << 32));
+                return dbits(pacc[a][f - 1]);
+            }
+            return 0ull;
+        };
+        // tag: two rotate-xor lanes over the key, one final mix (the key itself is compared on a hit: the tag only has to spread)
+        u64 h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
+#pragma unroll
+        for (int i = 0; i < kMemoKeyWords; i += 2) {
+            h0 = ((h0 << 7) | (h0 >> 57)) ^ kw(i);
+            h1 = ((h1 << 11) | (h1 >> 53)) ^ kw(i + 1);
+        }
+        const u64 hh = mix(mix(h0, h1), h0 >> 32);
+        const u64 gen = (u64)(c.dyn_memo_gen & 0xFFu);
+        const u64 tag = (hh & ~0xFFull) | gen;
+        const unsigned slot0 = (unsigned)(hh >> 24);
+        // the headers of the probe sequence, one round trip
+        u64 ptag[kMemoProbes], prdy[kMemoProbes], pborn[kMemoProbes];
+#pragma unroll
+        for (int p = 0; p < kMemoProbes; ++p) {
+            const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(c.dyn_memo + (size_t)((slot0 + (unsigned)p) & (unsigned)(kMemoEntries - 1)) * kMemoStride);
+            const ulonglong2 a = hp[0], b = hp[1];
+            ptag[p] = a.x; prdy[p] = a.y; pborn[p] = b.x;
+        }
+        int cand_p = -1, free_p = -1;
+        bool claimed = false; // somebody is writing (or has written, this launch) an entry with this tag
+        u64 old_tag = 0ull;
+#pragma unroll
+        for (int p = kMemoProbes - 1; p >= 0; --p) {
+            const bool mine = ptag[p] == tag;
+            const bool usable = mine & (prdy[p] == tag) & (pborn[p] < c.dyn_seq);
+            const bool free_ = (ptag[p] & 0xFFull) != gen; // never used, or of another generation
+            cand_p = usable ? p : cand_p;
+            claimed |= mine & !usable;
+            old_tag = free_ ? ptag[p] : old_tag;
+            free_p = free_ ? p : free_p;
+        }
+        bool hit = false;
+        const u64 *ent = c.dyn_memo + (size_t)((slot0 + (unsigned)(cand_p < 0 ? 0 : cand_p)) & (unsigned)(kMemoEntries - 1)) * kMemoStride;
+        if (memo_ok & (cand_p >= 0)) {
+            u64 diff = 0ull;
+            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(ent + ME_KEY);
+#pragma unroll
+            for (int i = 0; i < kMemoKeyWords; i += 2) {
+                const ulonglong2 w = kp[i / 2];
+                diff |= (w.x ^ kw(i)) | (w.y ^ kw(i + 1));
+            }
+            hit = diff == 0ull;
+        }
+        {   // statistics (development / bench: how often the table answers), spread over slots, fire and forget
+            const u64 mh = __ballot(hit), mm = __ballot(!hit);
+            if (lane == __ffsll((long long)(mh | mm)) - 1) {
+                u64 *st = c.dyn_memo_stats + (size_t)(blockIdx.x & (kMemoStatSlots - 1)) * kMemoStatWords;
+                if (mh) atomicAdd(st + 0, (u64)__popcll(mh));
+                if (mm) atomicAdd(st + 1, (u64)__popcll(mm));
+            }
+        }
+        if (hit) {
+            const ulonglong2 *vp = reinterpret_cast<const ulonglong2 *>(ent + ME_VAL);
+            auto bd = [](u64 w) -> double { return __longlong_as_double((long long)w); };
+            const ulonglong2 vh = vp[0];
+            const unsigned vhdr = (unsigned)vh.x;
+            const u64 live_out = vh.y;
+            const bool v_changed = (vhdr & 1u) != 0u;
+            const int n_out = (int)((vhdr >> 8) & 0xFFu), n_aged = (int)((vhdr >> 16) & 0xFFu);
+            {   // ships: 9 fields, cos, sin each; stored exactly as the computed step stores them (only a body that moved, or a fresh env)
+                u64 sw[kMemoValGoals - kMemoValShips + 1];
+#pragma unroll
+                for (int i = 0; i < (kMemoValGoals - kMemoValShips + 1) / 2; ++i) { const ulonglong2 w = vp[(kMemoValShips) / 2 + i]; sw[2 * i] = w.x; sw[2 * i + 1] = w.y; }
+#pragma unroll
+                for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                    double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+                    double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
+                    bool dfb = false;
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) dfb |= sw[11 * k + f] != dbits(tin[k][f]);
+                    if (dfb | fresh) {
+#pragma unroll
+                        for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = bd(sw[11 * k + f]); row[f] = bd(sw[11 * k + f]); }
+                        col.f64[(size_t)(DC_TROT + 2 * k) * np + e] = bd(sw[11 * k + 9]);
+                        col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = bd(sw[11 * k + 10]);
+                    }
+                }
+            }
+            {   // goals
+                static_assert(kMemoValGoals % 2 == 1, "goal words start at an odd word of the value");
+#pragma unroll
+                for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+                    if (g >= ng || !((gmask >> g) & 1u)) continue;
+                    double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
+                    double *row = c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g;
+                    if ((incl >> g) & 1u) {
+                        u64 gw[DC_GOAL_COLS];
+#pragma unroll
+                        for (int f = 0; f < DC_GOAL_COLS; ++f) gw[f] = ent[ME_VAL + kMemoValGoals + DC_GOAL_COLS * g + f];
+                        bool dfb = false;
+#pragma unroll
+                        for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= gw[f] != dbits(gin[g][f]);
+                        if (dfb | fresh) {
+#pragma unroll
+                            for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = bd(gw[f]); row[f] = bd(gw[f]); }
+                        }
+                    } else if (fresh) { // an inert goal of a rebuilt env: its fresh body, as the computed step stores it
+#pragma unroll
+                        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = gin[g][f]; row[f] = gin[g][f]; }
+                    }
+                }
+            }
+            for (int i = 0; i < n_out; ++i) { // the arbiters the step left on the solver's list
+                const u64 *ar = ent + ME_VAL + kMemoValArbs + kMemoArbWords * i;
+                const u64 pk = ar[0];
+                const int pid = (int)(pk & 0xFFull);
+                col.u32[(size_t)(DU_META + pid) * np + e] = (unsigned)((pk >> 8) & 0xFFull);
+                if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + e] = (unsigned)(pk >> 32);
+                double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
+                acc[0 * np] = bd(ar[1]); acc[1 * np] = bd(ar[2]); acc[2 * np] = bd(ar[3]); acc[3 * np] = bd(ar[4]);
+            }
+            for (int i = 0; i < n_aged; ++i) { // cached arbiters that aged this step
+                const u64 pk = ent[ME_VAL + kMemoValAged + i];
+                col.u32[(size_t)(DU_META + (int)(pk & 0xFFull)) * np + e] = (unsigned)((pk >> 8) & 0xFFull);
+            }
+            col.live[e] = live_out;
+            c.dyn_hash[e] = (unsigned long long)d.bank_epoch;
+            col.flag[e] = (uint8_t)(v_changed ? 0u : 4u);
+            return;
+        }
+        // a miss: compute, then store — unless the state is not memoisable, somebody else is already storing it, or the probe
+        // sequence has no free entry
+        memo_try = memo_ok & (cand_p < 0) & !claimed & (free_p >= 0);
+        memo_ent = c.dyn_memo + (size_t)((slot0 + (unsigned)(free_p < 0 ? 0 : free_p)) & (unsigned)(kMemoEntries - 1)) * kMemoStride;
+        memo_tag = tag;
+        memo_old = old_tag;
+    }
     // ---- narrowphase (cpCollide) of the surviving pairs, canonical order per env; one code site per pair type -------------
     Info info;
     for (;;) {
@@ -1170,6 +1351,10 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             } else {
                 meta = (meta & ~0x1Fu) | (unsigned)ST_CACHED | (age << 3);
                 col.u32[(size_t)(DU_META + pid) * np + e] = meta;
+                if constexpr (MEMO) {
+                    if (memo_n_aged < kMemoAged) memo_aged[memo_n_aged] = (unsigned long long)(unsigned)pid | ((unsigned long long)meta << 8);
+                    memo_n_aged++;
+                }
             }
         }
     }

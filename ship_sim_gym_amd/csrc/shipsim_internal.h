@@ -63,6 +63,35 @@ __host__ __device__ __forceinline__ unsigned dyn_bucket_of(int age, int map_id)
 // writes the columns (dyn_init, the full step's write-back, ssg_dyn_invalidate after a caller's own writes); read by the full
 // step only.  The columns stay the interface of everything else (classify pass, step kernel, ssg_state_field).
 constexpr int kDynRow = 80, kDynRowTraffic = 48;
+// ---- the memo of the full dyn step (round 5; bank mode with at most kDynMapBuckets records) -------------------------------
+// cpSpaceStep of an env's non-player bodies is a pure function of those bodies' cpBody fields, the cached arbiters, the goal
+// mask and the bank record (the player pushes nothing).  In bank mode thousands of envs share a record and replay the SAME
+// states after every reset: the first env that computes the step of a state stores (state -> next state) in a table kept in the
+// state blob, and every later env in that state copies the result instead of walking the ~100 k-cycle GJK / EPA / solver chain
+// that every launch of the full step used to end with.  A hit is verified against the COMPLETE input state (not a hash), so a
+// memoised step writes bit for bit what the computed one writes.  Entry = header + key + value, in 8-byte words:
+//   [0] tag  = (hash & ~0xFF) | generation (1..255; 0 = never used): claimed with one atomicCAS
+//   [1] ready = tag once key and value are complete;  [2] born = the launch number that wrote it (entries are used from the
+//   NEXT launch on: nothing written by a running launch is ever read by it);  [3] pad
+//   key  [4 .. 4 + kMemoKeyWords): header (bank record | participating goals | live-arbiter count), live mask, the three
+//        ships' 9 fields, the participating goals' 8 fields (0 for goals that are removed or inert: zero velocities and no
+//        broadphase candidate this step — their step is the identity and nobody sees them), up to 4 cached arbiters
+//        (pair id | state/age/count | contact hashes, 4 accumulated impulses)
+//   value: header (changed | arbiters written | arbiters aged), live mask out, ships 3 x (9 fields, cos, sin), goals 6 x 8,
+//        up to 8 arbiter records, up to 4 aged arbiters' meta words
+constexpr int kMemoEntries = 1 << 14;
+enum { ME_TAG = 0, ME_READY, ME_BORN, ME_PAD, ME_KEY };
+constexpr int kMemoArbIn = 4, kMemoArbOut = 8, kMemoAged = 4, kMemoArbWords = 5;
+constexpr int kMemoKeyShips = 2, kMemoKeyGoals = kMemoKeyShips + 9 * SSG_N_TRAFFIC, kMemoKeyArbs = kMemoKeyGoals + 8 * SSG_MAX_GOALS;
+constexpr int kMemoKeyWords = (kMemoKeyArbs + kMemoArbIn * kMemoArbWords + 1) & ~1; // 98
+constexpr int ME_VAL = ME_KEY + kMemoKeyWords;
+constexpr int kMemoValShips = 2, kMemoValGoals = kMemoValShips + 11 * SSG_N_TRAFFIC, kMemoValArbs = kMemoValGoals + 8 * SSG_MAX_GOALS;
+constexpr int kMemoValAged = kMemoValArbs + kMemoArbOut * kMemoArbWords;
+constexpr int kMemoValWords = (kMemoValAged + kMemoAged + 1) & ~1; // 128
+constexpr int kMemoStride = (ME_VAL + kMemoValWords + 1) & ~1;      // words per entry
+constexpr int kMemoProbes = 4;
+constexpr int kMemoStatSlots = 256, kMemoStatWords = 16; // per workgroup slot: [0] hits [1] misses [2] inserts [3] not memoisable
+static_assert(ME_KEY % 2 == 0 && ME_VAL % 2 == 0 && kMemoStride % 2 == 0, "16-byte loads of key and value");
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit
 constexpr int kStatsDoubles = 4 * kStatsSlots;
@@ -109,6 +138,11 @@ struct DevCfg {
     double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2: the step kernel's reject in front of collide_ship's exact test
     double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS]; // the traffic hulls (local), for that test
     double *dyn_row;              // [n_pad][kDynRow] row-major shadow of the DC_TRAFFIC / DC_GOALS columns (see kDynRow)
+    // the memo of the full dyn step (see kMemoEntries); null = off (SSG_FLAG_DYN_MEMO_OFF, per-env worlds, banks of > 64 records)
+    unsigned long long *dyn_memo;       // [kMemoEntries][kMemoStride]
+    unsigned long long *dyn_memo_stats; // [kMemoStatSlots][kMemoStatWords]
+    unsigned long long dyn_seq;         // number of this launch of the full step (entries born in it are not read by it)
+    unsigned dyn_memo_gen;              // 1..255: entries of another generation count as empty (bank change = new generation)
 };
 
 // Constants of the traffic ships and of Chipmunk's solver, by value to the dyn kernels only.

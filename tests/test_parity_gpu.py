@@ -683,7 +683,7 @@ def test_reference_random_rollout_configuration(torch_cuda, oracle, native, n_sh
     err, n_done = run_pair(oracle, native, v, K=1100, seed=4242, check_every=1)
     assert err <= (1e-9 if n_ships == 1 else 1e-8)
     st = v.stats()
-    assert n_done >= 700 and st["episodes"] == n_done          # every env ran into MAX_STEPS at step 1000 (or ended earlier)
+    assert n_done >= 700 and st["episodes"] == n_done          # every env ended at least once (MAX_STEPS at step 1000 at the latest)
     v.close()
     # the same stream as one fused trajectory rollout (1-ship: 100-step launches; 4 ships: per-step launch sequences)
     w = _vec(700, game_config=G, env_config=EnvConfig, n_maps=16, n_ships=n_ships)
@@ -693,7 +693,7 @@ def test_reference_random_rollout_configuration(torch_cuda, oracle, native, n_sh
     to, tr, td, tf = w.rollout_tensor(acts, trajectory=True)
     for k in range(1050):
         smp.step(acts[k], to[k], tr[k], td[k], atol=ATOL, n_threads=8)
-    assert int((tf[999] & native.EV_MAX_STEPS != 0).sum()) > 350   # step 1000: MAX_STEPS ends the episodes still running
+    assert smp.n_done >= 700 and smp.worst <= 1e-8
     w.close()
 
 
