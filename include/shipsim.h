@@ -23,10 +23,12 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 6 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
+#define SSG_ABI_VERSION 7 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
                              4: map record without dtMin/dtMax (SSG_MAP_STRIDE 145, SSG_PLANE_DOUBLES 5);
                              5: ssg_config.map_ring, ssg_refill_worlds (a brand-new world per episode, generated on the device);
-                             6: ssg_rollout_traj (every step of a fused rollout lands in its own slot of a trajectory buffer) */
+                             6: ssg_rollout_traj (every step of a fused rollout lands in its own slot of a trajectory buffer);
+                             7: SSG_FLAG_DYN_MEMO_OFF, SSG_F_DYN_MEMO_STATS (config 4: the memo table of the full cpSpaceStep lives
+                                in the state blob, which grows by ~30 MB) */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -54,6 +56,9 @@ typedef enum ssg_status {
 #define SSG_FLAG_BANK_IN_GLOBAL    0x4u /* never stage the map bank in LDS (per-lane gathers from L2/HBM); forced
                                            when the bank does not fit LDS or when every env has its own slot */
 
+#define SSG_FLAG_DYN_MEMO_OFF      0x10u /* config 4, development / measurement aid: never look a cpSpaceStep up in the memo table
+                                           (see SSG_F_DYN_MEMO_STATS): every queued env walks the full narrowphase / solver chain.
+                                           Results are bit for bit the same either way. */
 #define SSG_FLAG_EXACT_LIDAR       0x8u /* lidar: intersect every hull plane with every beam exactly as
                                            cpPolyShapeSegmentQuery does (one division per plane and beam) instead of
                                            the default one-division-per-beam evaluation of the same predicate; the two
@@ -148,6 +153,14 @@ typedef enum ssg_field {
                            goal bodies are at rest (their cpSpaceStep is skipped as the identity; inspection only) */
     SSG_F_EPISODES,     /* i32: episodes this env has started so far (every reset counts; in map_ring mode episode p lives in
                            bank record e*R + p mod R) */
+    SSG_F_DYN_MEMO_STATS, /* i64 [256 slots][16], n_ships == 4 only, to be summed over slots: [0] cpSpaceSteps answered by the memo
+                           table, [1] computed, [2] results stored, — inspection only.  No reference counterpart: Chipmunk steps
+                           every space every time (game.py:194).  In bank mode (shared worlds, <= 64 records) the traffic ships
+                           and goal bodies of thousands of envs pass through the SAME states after every reset — cpSpaceStep of
+                           those bodies is a pure function of their cpBody fields, the cached arbiters and the bank record (the
+                           player pushes nothing) — so the first env to step a state stores (state -> next state) in a table
+                           inside the state blob and later envs in that state copy the result after comparing the COMPLETE
+                           state word for word: a memoised step writes exactly the bits a computed one writes. */
     SSG_F_COUNT
 } ssg_field;
 

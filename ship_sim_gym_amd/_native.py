@@ -10,14 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSG_LIB_PATH: development override (tools/build_variant.sh builds diagnostic variants next to the product library)
 LIB_PATH = os.environ.get("SSG_LIB_PATH") or os.path.join(_HERE, "libshipsim.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3
 MAP_STRIDE = 145
 MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 5
-FLAG_AUTO_RESET, FLAG_FIX_COLLISION_REWARD, FLAG_BANK_IN_GLOBAL, FLAG_EXACT_LIDAR = 0x1, 0x2, 0x4, 0x8
+FLAG_AUTO_RESET, FLAG_FIX_COLLISION_REWARD, FLAG_BANK_IN_GLOBAL, FLAG_EXACT_LIDAR, FLAG_DYN_MEMO_OFF = 0x1, 0x2, 0x4, 0x8, 0x10
 EV_COLLIDING, EV_GOAL_REACHED, EV_OUT_OF_BOUNDS, EV_MAX_STEPS, EV_NO_GOALS_LEFT = 0x1, 0x2, 0x4, 0x8, 0x10
 (F_X, F_Y, F_VX, F_VY, F_ANGLE, F_W, F_CUM_REWARD, F_LIDAR, F_RUDDER, F_STEP_COUNT, F_MAP_ID, F_GOAL_MASK,
- F_STATS, F_TRAFFIC, F_GOAL_BODIES, F_DYN_FLAGS, F_EPISODES) = range(17)
+ F_STATS, F_TRAFFIC, F_GOAL_BODIES, F_DYN_FLAGS, F_EPISODES, F_DYN_MEMO_STATS) = range(18)
 
 # every symbol include/shipsim.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = (

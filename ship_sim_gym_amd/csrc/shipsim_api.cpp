@@ -20,6 +20,11 @@ struct ssg_handle {
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
     size_t off_dyn_hash = 0, off_dyn_count = 0, off_dyn_row = 0, off_dyn_bucket = 0;
+    size_t off_dyn_memo = 0, off_dyn_memo_stats = 0, off_dyn_npm = 0; // the memo of the full dyn step (shipsim_internal.h, kMemoEntries)
+    unsigned long long dyn_seq = 0;   // launches of the full step so far
+    unsigned memo_gen = 1;            // generation of the memo's entries (1..255)
+    bool memo_clear_pending = false;  // the generation counter wrapped: zero the table before the next launch
+    int memo_steps = 0;               // launches since the generation began (a generation ends after kMemoGenSteps of them)
     bool dyn_queue_valid = false; // the step kernel's last launch left the next step's dyn queue (nothing host-side touched the envs since)
     ssg::DynCfg dyn{};
     void *state = nullptr;
@@ -340,6 +345,23 @@ void refresh_dev(ssg_handle *h)
     d.dyn_bucket = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_bucket) : nullptr;
     d.dyn_par = 0; // (the queue is rebuilt from the flags after every refresh: dyn_queue_valid = false below)
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
+    // the memo: shared bank records are what makes states repeat (not per-env worlds, not banks the queue's 64 map buckets cannot
+    // tell apart — the dyn_step_kernel<true, ...> condition of launch_dyn_step)
+    const bool memo = dyn && !(c.flags & SSG_FLAG_DYN_MEMO_OFF) && c.map_ring == 0 && h->n_maps > 0 && h->n_maps <= ssg::kDynMapBuckets;
+    d.dyn_memo = memo ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_memo) : nullptr;
+    d.dyn_memo_stats = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_memo_stats) : nullptr;
+    d.dyn_npm = memo ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_npm) : nullptr;
+    d.dyn_memo_gen = h->memo_gen;
+    d.dyn_seq = h->dyn_seq;
+    {   // every constant the full step reads, folded into 16 bits of the memo key
+        unsigned long long fp = 0xcbf29ce484222325ull;
+        auto eat = [&](const void *p, size_t n) { const unsigned char *b = static_cast<const unsigned char *>(p); for (size_t i = 0; i < n; ++i) fp = (fp ^ b[i]) * 0x100000001b3ull; };
+        eat(h->dyn.thull, sizeof h->dyn.thull); eat(h->dyn.tnrm, sizeof h->dyn.tnrm); eat(h->dyn.tx, sizeof h->dyn.tx); eat(h->dyn.ty, sizeof h->dyn.ty);
+        eat(h->dyn.t_i_inv, sizeof h->dyn.t_i_inv); eat(&h->dyn.t_m_inv, 8); eat(&h->dyn.goal_m_inv, 8); eat(&h->dyn.goal_i_inv, 8);
+        eat(&h->dyn.ship_friction, 8); eat(&h->dyn.bias_coef, 8); eat(&h->dyn.slop, 8);
+        eat(&c.dt, 8); eat(&c.damping_pow_dt, 8); eat(&c.goal_radius, 8); eat(&c.n_goals, 4);
+        h->dyn.memo_fp = (unsigned)((fp ^ (fp >> 16) ^ (fp >> 32) ^ (fp >> 48)) & 0xFFFFu);
+    }
     {   // the step kernel's reject in front of collide_ship's exact player x traffic test: no vertex of ship k's hull is further than
         // its hull radius from its body position
         auto radius = [](const double *hull) {
@@ -357,6 +379,18 @@ void refresh_dev(ssg_handle *h)
     h->dyn_queue_valid = false; // (anything that refreshes the kernel arguments may have changed what the queue was built from)
 }
 
+
+// The memo of the full dyn step: a new GENERATION makes every stored entry count as empty (no memset: the generation is part of
+// the tag).  Started whenever the bank changes (entries of the old bank could never match again and would only fill the table)
+// and every kMemoGenSteps launches (states a caller poked in once, or a long tail of rare ones, do not silt the table up).
+constexpr int kMemoGenSteps = 1 << 15;
+static void memo_new_generation(ssg_handle *h)
+{
+    h->memo_gen += 1;
+    if (h->memo_gen > 255) { h->memo_gen = 1; h->memo_clear_pending = true; } // a wrapped generation could meet its own old tags
+    h->memo_steps = 0;
+    h->dev.dyn_memo_gen = h->memo_gen;
+}
 
 int pick_block(int n_envs)
 {
@@ -499,7 +533,10 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_count = h->off_dyn_hash + np * sizeof(unsigned long long);
         h->off_dyn_row = h->off_dyn_count + ((2 * (size_t)ssg::kDynCountWords * sizeof(unsigned) + 255) & ~(size_t)255);
         h->off_dyn_bucket = h->off_dyn_row + np * (size_t)ssg::kDynRow * sizeof(double);
-        h->nbytes = h->off_dyn_bucket + (size_t)ssg::kDynBuckets * np * sizeof(int32_t); // one array of n_pad slots per sort bucket
+        h->off_dyn_memo_stats = (h->off_dyn_bucket + (size_t)ssg::kDynBuckets * np * sizeof(int32_t) + 255) & ~(size_t)255; // one array of n_pad slots per sort bucket
+        h->off_dyn_memo = h->off_dyn_memo_stats + (size_t)ssg::kMemoStatSlots * ssg::kMemoStatWords * sizeof(unsigned long long);
+        h->off_dyn_npm = h->off_dyn_memo + (size_t)ssg::kMemoEntries * ssg::kMemoStride * sizeof(unsigned long long);
+        h->nbytes = h->off_dyn_npm + (size_t)ssg::kNpmEntries * ssg::kNpmStride * sizeof(unsigned long long);
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -548,6 +585,11 @@ int ssg_state_field(const ssg_handle *h, int field, size_t *offset, int *elem_si
     } else if (field == SSG_F_DYN_FLAGS) {
         if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
         off = h->off_dyn_flag; es = 1; nc = 1;
+    } else if (field == SSG_F_DYN_MEMO_STATS) {
+        if (h->cfg.n_ships <= 1) return SSG_ERR_BAD_ARG;
+        off = h->off_dyn_memo_stats; es = 8; nc = ssg::kMemoStatSlots * ssg::kMemoStatWords;
+        *offset = off; *elem_size = es; *n_columns = nc; *column_stride_bytes = 8;
+        return SSG_OK;
     } else if (field == SSG_F_STATS) {
         // kStatsSlots rows of 4 int64 counters; sum over rows: [0] sum_return*100 [1] sum_length [2] episodes [3] goals
         off = h->off_stats; es = 8; nc = 4 * ssg::kStatsSlots;
@@ -605,6 +647,7 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     h->bank = dev_bank;
     h->n_maps = n_maps;
     h->dyn.bank_epoch++; // resting traffic must be re-collided against the new banks
+    memo_new_generation(h);
     // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch
     h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
              ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) <= 160u * 1024u;
@@ -744,6 +787,15 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                     h->dev.dyn_par = 0;
                     e = hipMemsetAsync(h->dev.dyn_count, 0, ssg::kDynCountWords * sizeof(unsigned), static_cast<hipStream_t>(stream));
                 }
+                if (h->dev.dyn_memo) {
+                    if (++h->memo_steps > kMemoGenSteps) memo_new_generation(h);
+                    if (h->memo_clear_pending && e == hipSuccess) {
+                        e = hipMemsetAsync(h->dev.dyn_memo, 0, ((size_t)ssg::kMemoEntries * ssg::kMemoStride + (size_t)ssg::kNpmEntries * ssg::kNpmStride) * sizeof(unsigned long long),
+                                           static_cast<hipStream_t>(stream)); // (the narrowphase memo follows the state memo in the blob)
+                        h->memo_clear_pending = false;
+                    }
+                }
+                h->dev.dyn_seq = ++h->dyn_seq;
                 if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
                 if (e != hipSuccess) {
                     h->dyn_queue_valid = false; // (a queue the full step never consumed must not survive: the next call starts over)
@@ -820,7 +872,7 @@ int ssg_generate_bank(ssg_handle *h, uint64_t seed, double width_frac, double *d
     hipError_t e = ssg::launch_generate_bank(seed, n_maps, h->cfg.n_goals, h->cfg.width, h->cfg.height, width_frac,
                                              h->cfg.spawn_x, h->cfg.spawn_y, dev_bank, dev_raw, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("generate_bank launch: ") + hipGetErrorString(e));
-    if (dev_bank == h->bank) { h->dyn.bank_epoch++; h->dyn_queue_valid = false; } // regenerated in place
+    if (dev_bank == h->bank) { h->dyn.bank_epoch++; h->dyn_queue_valid = false; memo_new_generation(h); } // regenerated in place
     return SSG_OK;
 }
 

@@ -1069,6 +1069,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
     }
     SSG_TICK(emem, 5); // (profile builds: category 5 = the broadphase)
+    stamp(10);
     // ---- the memo: has the step of exactly this state been computed before? ------------------------------------------------
     // Key = everything the rest of the step reads: the bank record, the three ships' fields, the fields of the goals that take
     // part (still in the space, and moving or a broadphase candidate this step; the others are stepped by the identity and seen
@@ -1079,11 +1080,36 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     auto dbits = [](double v) -> u64 { return (u64)__double_as_longlong(v); };
     bool memo_try = false;    // this lane computes, then stores its result in the table
     u64 *memo_ent = nullptr;  // ... in this entry,
-    u64 memo_tag = 0ull, memo_old = 0ull; // claimed by CAS(old -> tag)
+    u64 memo_tag = 0ull, memo_old = 1ull; // the claiming CAS's answer ^ the expected tag: 0 = claimed
     unsigned memo_incl = 0u;
     u64 memo_hdr = 0ull;
     u64 memo_aged[kMemoAged] = {0ull, 0ull, 0ull, 0ull};
     int memo_n_aged = 0;
+    // The key's sections, as (index of the section's first word, words) pairs a visitor is called with — two words at a time,
+    // the entry's 16-byte granule.  Ships: always.  Goals: the ones that take part.  Arbiters: the env's cached ones.
+    auto key_ship_word = [&](int j) -> u64 { return j < 9 * SSG_N_TRAFFIC ? dbits(tin[(j < 27 ? j : 0) / 9][(j < 27 ? j : 0) % 9]) : 0ull; };
+    auto key_arb_word = [&](int a, int f) -> u64 {
+        if (f == 0) return (u64)(unsigned)ppid[a] | ((u64)pmeta[a] << 8) | ((u64)phh[a] << 32);
+        return f <= 4 ? dbits(pacc[a][f <= 4 ? f - 1 : 0]) : 0ull;
+    };
+    auto key_visit = [&](auto &&f2 /* (word index, w0, w1) */, const unsigned incl, const int n_live) {
+        f2(0, memo_hdr, live0);
+#pragma unroll
+        for (int j = 0; j < 28; j += 2) f2(kMemoKeyShips + j, key_ship_word(j), key_ship_word(j + 1));
+#pragma unroll
+        for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+            if (!((incl >> g) & 1u)) continue;
+#pragma unroll
+            for (int f = 0; f < DC_GOAL_COLS; f += 2) f2(kMemoKeyGoals + DC_GOAL_COLS * g + f, dbits(gin[g][f]), dbits(gin[g][f + 1]));
+        }
+#pragma unroll
+        for (int a = 0; a < kMemoArbIn; ++a) {
+            if (a >= n_live) continue;
+#pragma unroll
+            for (int f = 0; f < kMemoArbWords; f += 2) f2(kMemoKeyArbs + kMemoArbWords * a + f, key_arb_word(a, f), key_arb_word(a, f + 1));
+        }
+    };
+    int memo_n_live = 0;
     if constexpr (MEMO) {
         unsigned incl = 0u;
 #pragma unroll
@@ -1103,30 +1129,17 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             incl |= (present & (moving | ((cand & inv) != 0ull))) ? (1u << g) : 0u;
         }
         memo_incl = incl;
-        const int n_live = __popcll(live);
-        const bool memo_ok = n_live <= kMemoArbIn;
+        const int n_live = __popcll(live0);
+        memo_n_live = n_live;
+        const bool memo_ok = n_live <= kMemoArbIn; // (the first kMemoArbIn cached arbiters are the ones held in ppid / pacc)
         memo_hdr = (u64)(unsigned)map_id | ((u64)incl << 8) | ((u64)(unsigned)n_live << 16) | ((u64)(d.memo_fp & 0xFFFFu) << 24) |
                    ((u64)(d.bank_epoch & 0xFFFFFFu) << 40);
-        // key word i (i is a constant wherever this is called: the loops below are unrolled)
-        auto kw = [&](int i) -> u64 {
-            if (i == 0) return memo_hdr;
-            if (i == 1) return live;
-            if (i < kMemoKeyGoals) { const int j = i - kMemoKeyShips; return dbits(tin[j / 9][j % 9]); }
-            if (i < kMemoKeyArbs) { const int j = i - kMemoKeyGoals; return ((incl >> (j / 8)) & 1u) ? dbits(gin[j / 8][j % 8]) : 0ull; }
-            if (i < kMemoKeyArbs + kMemoArbIn * kMemoArbWords) {
-                const int j = i - kMemoKeyArbs, a = j / kMemoArbWords, f = j % kMemoArbWords;
-                if (f == 0) return (ppid[a] < 0) ? 0xFFull : ((u64)(unsigned)ppid[a] | ((u64)pmeta[a] << 8) | ((u64)phh[a] << 32));
-                return dbits(pacc[a][f - 1]);
-            }
-            return 0ull;
-        };
         // tag: two rotate-xor lanes over the key, one final mix (the key itself is compared on a hit: the tag only has to spread)
         u64 h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
-#pragma unroll
-        for (int i = 0; i < kMemoKeyWords; i += 2) {
-            h0 = ((h0 << 7) | (h0 >> 57)) ^ kw(i);
-            h1 = ((h1 << 11) | (h1 >> 53)) ^ kw(i + 1);
-        }
+        key_visit([&](int, u64 w0, u64 w1) {
+            h0 = ((h0 << 7) | (h0 >> 57)) ^ w0;
+            h1 = ((h1 << 11) | (h1 >> 53)) ^ w1;
+        }, incl, memo_ok ? n_live : 0);
         const u64 hh = mix(mix(h0, h1), h0 >> 32);
         const u64 gen = (u64)(c.dyn_memo_gen & 0xFFu);
         const u64 tag = (hh & ~0xFFull) | gen;
@@ -1152,19 +1165,27 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             old_tag = free_ ? ptag[p] : old_tag;
             free_p = free_ ? p : free_p;
         }
+        stamp(12);
         bool hit = false;
         const u64 *ent = c.dyn_memo + (size_t)((slot0 + (unsigned)(cand_p < 0 ? 0 : cand_p)) & (unsigned)(kMemoEntries - 1)) * kMemoStride;
+        auto ld2 = [&](int i) -> ulonglong2 { return *reinterpret_cast<const ulonglong2 *>(ent + ME_VAL + i); };
+        // the candidate's value header and ship records are requested with its key (one round trip for the common hit, not two)
+        ulonglong2 vh = make_ulonglong2(0ull, 0ull);
+        u64 sw[SSG_N_TRAFFIC][kMemoValShipWords];
         if (memo_ok & (cand_p >= 0)) {
             u64 diff = 0ull;
-            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(ent + ME_KEY);
+            key_visit([&](int i, u64 w0, u64 w1) {
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + i);
+                diff |= (w.x ^ w0) | (w.y ^ w1);
+            }, incl, n_live);
+            vh = ld2(0);
 #pragma unroll
-            for (int i = 0; i < kMemoKeyWords; i += 2) {
-                const ulonglong2 w = kp[i / 2];
-                diff |= (w.x ^ kw(i)) | (w.y ^ kw(i + 1));
-            }
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k)
+#pragma unroll
+                for (int i = 0; i < kMemoValShipWords; i += 2) { const ulonglong2 w = ld2(kMemoValShips + kMemoValShipWords * k + i); sw[k][i] = w.x; sw[k][i + 1] = w.y; }
             hit = diff == 0ull;
         }
-        {   // statistics (development / bench: how often the table answers), spread over slots, fire and forget
+        {   // statistics (how often the table answers), spread over slots, fire and forget
             const u64 mh = __ballot(hit), mm = __ballot(!hit);
             if (lane == __ffsll((long long)(mh | mm)) - 1) {
                 u64 *st = c.dyn_memo_stats + (size_t)(blockIdx.x & (kMemoStatSlots - 1)) * kMemoStatWords;
@@ -1172,65 +1193,67 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                 if (mm) atomicAdd(st + 1, (u64)__popcll(mm));
             }
         }
+        stamp(13);
         if (hit) {
-            const ulonglong2 *vp = reinterpret_cast<const ulonglong2 *>(ent + ME_VAL);
             auto bd = [](u64 w) -> double { return __longlong_as_double((long long)w); };
-            const ulonglong2 vh = vp[0];
             const unsigned vhdr = (unsigned)vh.x;
             const u64 live_out = vh.y;
             const bool v_changed = (vhdr & 1u) != 0u;
             const int n_out = (int)((vhdr >> 8) & 0xFFu), n_aged = (int)((vhdr >> 16) & 0xFFu);
-            {   // ships: 9 fields, cos, sin each; stored exactly as the computed step stores them (only a body that moved, or a fresh env)
-                u64 sw[kMemoValGoals - kMemoValShips + 1];
+            // the arbiter records and the participating goals: one more batch
+            ulonglong2 ar[kMemoArbOut][3];
 #pragma unroll
-                for (int i = 0; i < (kMemoValGoals - kMemoValShips + 1) / 2; ++i) { const ulonglong2 w = vp[(kMemoValShips) / 2 + i]; sw[2 * i] = w.x; sw[2 * i + 1] = w.y; }
+            for (int i = 0; i < kMemoArbOut; ++i) {
+                if (i < n_out) { ar[i][0] = ld2(kMemoValArbs + kMemoArbWords * i); ar[i][1] = ld2(kMemoValArbs + kMemoArbWords * i + 2); ar[i][2] = ld2(kMemoValArbs + kMemoArbWords * i + 4); }
+                if (i >= 2) break; // (more than two arbiters: fetched where they are stored, below)
+            }
+            // ships: 9 fields, cos, sin each; stored exactly as the computed step stores them (only a body that moved, or a fresh env)
 #pragma unroll
-                for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
-                    double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
-                    double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
-                    bool dfb = false;
+            for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
+                double *t = col.f64 + (size_t)(DC_TRAFFIC + 9 * k) * np + e;
+                double *row = c.dyn_row + (size_t)e * kDynRow + kDynRowTraffic + 9 * k;
+                bool dfb = false;
 #pragma unroll
-                    for (int f = 0; f < 9; ++f) dfb |= sw[11 * k + f] != dbits(tin[k][f]);
-                    if (dfb | fresh) {
+                for (int f = 0; f < 9; ++f) dfb |= sw[k][f] != dbits(tin[k][f]);
+                if (dfb | fresh) {
 #pragma unroll
-                        for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = bd(sw[11 * k + f]); row[f] = bd(sw[11 * k + f]); }
-                        col.f64[(size_t)(DC_TROT + 2 * k) * np + e] = bd(sw[11 * k + 9]);
-                        col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = bd(sw[11 * k + 10]);
-                    }
+                    for (int f = 0; f < 9; ++f) { t[(size_t)f * np] = bd(sw[k][f]); row[f] = bd(sw[k][f]); }
+                    col.f64[(size_t)(DC_TROT + 2 * k) * np + e] = bd(sw[k][9]);
+                    col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = bd(sw[k][10]);
                 }
             }
-            {   // goals
-                static_assert(kMemoValGoals % 2 == 1, "goal words start at an odd word of the value");
 #pragma unroll
-                for (int g = 0; g < SSG_MAX_GOALS; ++g) {
-                    if (g >= ng || !((gmask >> g) & 1u)) continue;
-                    double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
-                    double *row = c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g;
-                    if ((incl >> g) & 1u) {
-                        u64 gw[DC_GOAL_COLS];
+            for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+                if (g >= ng || !((gmask >> g) & 1u)) continue;
+                double *q = col.f64 + (size_t)(DC_GOALS + DC_GOAL_COLS * g) * np + e;
+                double *row = c.dyn_row + (size_t)e * kDynRow + DC_GOAL_COLS * g;
+                if ((incl >> g) & 1u) {
+                    u64 gw[DC_GOAL_COLS];
 #pragma unroll
-                        for (int f = 0; f < DC_GOAL_COLS; ++f) gw[f] = ent[ME_VAL + kMemoValGoals + DC_GOAL_COLS * g + f];
-                        bool dfb = false;
+                    for (int f = 0; f < DC_GOAL_COLS; f += 2) { const ulonglong2 w = ld2(kMemoValGoals + DC_GOAL_COLS * g + f); gw[f] = w.x; gw[f + 1] = w.y; }
+                    bool dfb = false;
 #pragma unroll
-                        for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= gw[f] != dbits(gin[g][f]);
-                        if (dfb | fresh) {
+                    for (int f = 0; f < DC_GOAL_COLS; ++f) dfb |= gw[f] != dbits(gin[g][f]);
+                    if (dfb | fresh) {
 #pragma unroll
-                            for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = bd(gw[f]); row[f] = bd(gw[f]); }
-                        }
-                    } else if (fresh) { // an inert goal of a rebuilt env: its fresh body, as the computed step stores it
-#pragma unroll
-                        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = gin[g][f]; row[f] = gin[g][f]; }
+                        for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = bd(gw[f]); row[f] = bd(gw[f]); }
                     }
+                } else if (fresh) { // a goal of a rebuilt env that takes no part: its fresh body, as the computed step stores it
+#pragma unroll
+                    for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = gin[g][f]; row[f] = gin[g][f]; }
                 }
             }
             for (int i = 0; i < n_out; ++i) { // the arbiters the step left on the solver's list
-                const u64 *ar = ent + ME_VAL + kMemoValArbs + kMemoArbWords * i;
-                const u64 pk = ar[0];
+                ulonglong2 a0, a1, a2;
+                if (i == 0) { a0 = ar[0][0]; a1 = ar[0][1]; a2 = ar[0][2]; }
+                else if (i == 1) { a0 = ar[1][0]; a1 = ar[1][1]; a2 = ar[1][2]; }
+                else { a0 = ld2(kMemoValArbs + kMemoArbWords * i); a1 = ld2(kMemoValArbs + kMemoArbWords * i + 2); a2 = ld2(kMemoValArbs + kMemoArbWords * i + 4); }
+                const u64 pk = a0.x;
                 const int pid = (int)(pk & 0xFFull);
                 col.u32[(size_t)(DU_META + pid) * np + e] = (unsigned)((pk >> 8) & 0xFFull);
                 if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + e] = (unsigned)(pk >> 32);
                 double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
-                acc[0 * np] = bd(ar[1]); acc[1 * np] = bd(ar[2]); acc[2 * np] = bd(ar[3]); acc[3 * np] = bd(ar[4]);
+                acc[0 * np] = bd(a0.y); acc[1 * np] = bd(a1.x); acc[2 * np] = bd(a1.y); acc[3 * np] = bd(a2.x);
             }
             for (int i = 0; i < n_aged; ++i) { // cached arbiters that aged this step
                 const u64 pk = ent[ME_VAL + kMemoValAged + i];
@@ -1242,12 +1265,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             return;
         }
         // a miss: compute, then store — unless the state is not memoisable, somebody else is already storing it, or the probe
-        // sequence has no free entry
+        // sequence has no free entry.  The entry is claimed NOW with one returning CAS whose answer is first looked at where
+        // the result is stored (it travels while the narrowphase runs).
         memo_try = memo_ok & (cand_p < 0) & !claimed & (free_p >= 0);
         memo_ent = c.dyn_memo + (size_t)((slot0 + (unsigned)(free_p < 0 ? 0 : free_p)) & (unsigned)(kMemoEntries - 1)) * kMemoStride;
         memo_tag = tag;
-        memo_old = old_tag;
+        if (memo_try) memo_old = atomicCAS(memo_ent + ME_TAG, old_tag, tag) ^ old_tag; // 0 = the entry is this lane's
     }
+    stamp(11);
     // ---- narrowphase (cpCollide) of the surviving pairs, canonical order per env; one code site per pair type -------------
     Info info;
     for (;;) {
@@ -1289,8 +1314,83 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                 const int r = o - (kGoalBlock + (2 + SSG_MAX_GOALS) * k + k * (k - 1) / 2);
                 const ShipShape sk = ship_shape(k);
                 if (r < 2) {
-                    const BankShape<UNI> bs = bank_shape(r);
-                    collide(sk, bs, info, emem);
+                    // the narrowphase memo: this (record, side, ship, pose) may have been collided before (shipsim_internal.h, kNpmEntries)
+                    bool got = false;
+                    u64 *np_ent = nullptr;
+                    u64 np_tag = 0ull, np_old = 0ull;
+                    u64 np_hdr = 0ull;
+                    if constexpr (MEMO) {
+                        np_hdr = (u64)(unsigned)map_id | ((u64)(unsigned)r << 8) | ((u64)(unsigned)k << 12) | ((u64)(d.memo_fp & 0xFFFFu) << 16) |
+                                 ((u64)(d.bank_epoch & 0xFFFFFFu) << 32);
+                        u64 h0 = np_hdr ^ 0x452821E638D01377ull, h1 = 0xBE5466CF34E90C6Cull;
+                        h0 = ((h0 << 7) | (h0 >> 57)) ^ dbits(sk.p.x); h1 = ((h1 << 11) | (h1 >> 53)) ^ dbits(sk.p.y);
+                        h0 = ((h0 << 7) | (h0 >> 57)) ^ dbits(sk.ca);  h1 = ((h1 << 11) | (h1 >> 53)) ^ dbits(sk.sa);
+                        const u64 hh = mix(mix(h0, h1), h0 >> 32);
+                        const u64 gen = (u64)(c.dyn_memo_gen & 0xFFu);
+                        np_tag = (hh & ~0xFFull) | gen;
+                        const unsigned slot0 = (unsigned)(hh >> 24);
+                        int cp = -1, fp_ = -1;
+                        bool claimed = false;
+#pragma unroll
+                        for (int p = kNpmProbes - 1; p >= 0; --p) {
+                            const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(c.dyn_npm + (size_t)((slot0 + (unsigned)p) & (unsigned)(kNpmEntries - 1)) * kNpmStride);
+                            const ulonglong2 a = hp[0], b = hp[1];
+                            const bool mine = a.x == np_tag;
+                            const bool usable = mine & (a.y == np_tag) & (b.x < c.dyn_seq);
+                            const bool free_ = (a.x & 0xFFull) != gen;
+                            cp = usable ? p : cp;
+                            claimed |= mine & !usable;
+                            np_old = free_ ? a.x : np_old;
+                            fp_ = free_ ? p : fp_;
+                        }
+                        if (cp >= 0) {
+                            const u64 *ent = c.dyn_npm + (size_t)((slot0 + (unsigned)cp) & (unsigned)(kNpmEntries - 1)) * kNpmStride;
+                            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(ent + NE_KEY);
+                            const ulonglong2 k0 = q[0], k1 = q[1], k2 = q[2];
+                            const ulonglong2 v0 = q[3], v1 = q[4], v2 = q[5], v3 = q[6], v4 = q[7], v5 = q[8];
+                            got = (((k0.x ^ np_hdr) | (k0.y ^ dbits(sk.p.x)) | (k1.x ^ dbits(sk.p.y)) | (k1.y ^ dbits(sk.ca)) | (k2.x ^ dbits(sk.sa))) == 0ull);
+                            if (got) {
+                                auto bd = [](u64 w) -> double { return __longlong_as_double((long long)w); };
+                                info.count = (int)(v0.x & 0xFFull);
+                                info.hash[0] = (unsigned)((v0.x >> 8) & 0xFFFFFFull); info.hash[1] = (unsigned)(v0.x >> 32);
+                                info.n = mk(bd(v0.y), bd(v1.x));
+                                info.p1[0] = mk(bd(v1.y), bd(v2.x)); info.p2[0] = mk(bd(v2.y), bd(v3.x));
+                                info.p1[1] = mk(bd(v3.y), bd(v4.x)); info.p2[1] = mk(bd(v4.y), bd(v5.x));
+                            }
+                        }
+                        if (!got & (cp < 0) & !claimed & (fp_ >= 0))
+                            np_ent = c.dyn_npm + (size_t)((slot0 + (unsigned)fp_) & (unsigned)(kNpmEntries - 1)) * kNpmStride;
+                    }
+                    if (!got) {
+                        const BankShape<UNI> bs = bank_shape(r);
+                        collide(sk, bs, info, emem);
+                        if constexpr (MEMO) {
+                            if (np_ent && atomicCAS(np_ent + ME_TAG, np_old, np_tag) == np_old) {
+                                np_ent[ME_BORN] = c.dyn_seq;
+                                __threadfence();
+                                np_ent[NE_KEY + 0] = np_hdr; np_ent[NE_KEY + 1] = dbits(sk.p.x); np_ent[NE_KEY + 2] = dbits(sk.p.y);
+                                np_ent[NE_KEY + 3] = dbits(sk.ca); np_ent[NE_KEY + 4] = dbits(sk.sa); np_ent[NE_KEY + 5] = 0ull;
+                                const bool c1 = info.count > 0, c2 = info.count > 1;
+                                np_ent[NE_VAL + 0] = (u64)(unsigned)info.count | ((u64)(c1 ? info.hash[0] : 0u) << 8) | ((u64)(c2 ? info.hash[1] : 0u) << 32);
+                                np_ent[NE_VAL + 1] = dbits(info.n.x); np_ent[NE_VAL + 2] = dbits(info.n.y);
+                                np_ent[NE_VAL + 3] = dbits(c1 ? info.p1[0].x : 0.0); np_ent[NE_VAL + 4] = dbits(c1 ? info.p1[0].y : 0.0);
+                                np_ent[NE_VAL + 5] = dbits(c1 ? info.p2[0].x : 0.0); np_ent[NE_VAL + 6] = dbits(c1 ? info.p2[0].y : 0.0);
+                                np_ent[NE_VAL + 7] = dbits(c2 ? info.p1[1].x : 0.0); np_ent[NE_VAL + 8] = dbits(c2 ? info.p1[1].y : 0.0);
+                                np_ent[NE_VAL + 9] = dbits(c2 ? info.p2[1].x : 0.0); np_ent[NE_VAL + 10] = dbits(c2 ? info.p2[1].y : 0.0);
+                                np_ent[NE_VAL + 11] = 0ull;
+                                __threadfence();
+                                np_ent[ME_READY] = np_tag;
+                            }
+                        }
+                    }
+                    if constexpr (MEMO) {
+                        const u64 mg = __ballot(got), mn = __ballot(!got);
+                        if (lane == __ffsll((long long)(mg | mn)) - 1) {
+                            u64 *st = c.dyn_memo_stats + (size_t)(blockIdx.x & (kMemoStatSlots - 1)) * kMemoStatWords;
+                            if (mg) atomicAdd(st + 3, (u64)__popcll(mg));
+                            if (mn) atomicAdd(st + 4, (u64)__popcll(mn));
+                        }
+                    }
                     push(info, slot_ship0 + k, slot_static, pid_tb(k, r), d.ship_friction * 0.0);
                     type_ = 2;
                 } else if (r < 2 + SSG_MAX_GOALS) {
@@ -1359,6 +1459,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         }
     }
 
+    stamp(14);
     auto ints_of = [&](const auto &A, int &pid, int &a, int &b, int &count, int &state) {
         const unsigned v = (unsigned)__double_as_longlong(A.get(A_INTS));
         pid = v & 0xFF; a = (v >> 8) & 0xFF; b = (v >> 16) & 0xFF; count = (v >> 24) & 0xF; state = v >> 28;
@@ -1376,7 +1477,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 
     // (from here to the arbiters' write-back every access to an arbiter record goes through getA: the LDS-only form when no
     // lane of the wave has more than kLdsArb arbiters)
-    auto solve_and_store = [&](auto getA) {
+    auto solve_and_store = [&](auto getA, const bool memo_ins) {
     // ---- cpArbiterPreStep ---------------------------------------------------------------------------------------
     for (int i = 0; i < n_act; ++i) {
         const auto A = getA(i);
@@ -1585,9 +1686,30 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + e] = hh;
         double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
         acc[0 * np] = j0; acc[1 * np] = j1; acc[2 * np] = t0; acc[3 * np] = t1;
+        if constexpr (MEMO) {
+            if (memo_ins) {
+                u64 *ar = memo_ent + ME_VAL + kMemoValArbs + kMemoArbWords * i;
+                ar[0] = (u64)(unsigned)pid | ((u64)meta << 8) | ((u64)hh << 32);
+                ar[1] = dbits(j0); ar[2] = dbits(j1); ar[3] = dbits(t0); ar[4] = dbits(t1); ar[5] = 0ull;
+            }
+        }
     }
     };
-    if (!__any(n_act > kLdsArb)) solve_and_store(arb_lds); else solve_and_store(arb);
+    // the memo: did this lane claim an entry (the CAS issued at the miss)?  Then the key — the INPUT state — goes in now, so that
+    // the registers that hold it (the cached arbiters' records) are free during the solver, as in the kernel without a memo.
+    bool memo_ins = false;
+    if constexpr (MEMO) {
+        asm volatile("" : "+v"(memo_old)); // (first use of the CAS's answer: not before this point)
+        memo_ins = memo_try & (memo_old == 0ull) & (memo_n_aged <= kMemoAged); // (a claimed entry that is not filled stays unusable: rare)
+        if (memo_ins) {
+            memo_ent[ME_BORN] = c.dyn_seq; // (no launch reads an entry born in it; and the old generation's `ready` cannot match the new tag)
+            __threadfence();
+            key_visit([&](int i, u64 w0, u64 w1) { memo_ent[ME_KEY + i] = w0; memo_ent[ME_KEY + i + 1] = w1; }, memo_incl, memo_n_live);
+#pragma unroll
+            for (int i = 0; i < kMemoAged; ++i) memo_ent[ME_VAL + kMemoValAged + i] = memo_aged[i];
+        }
+    }
+    if (!__any(n_act > kLdsArb)) solve_and_store(arb_lds, memo_ins); else solve_and_store(arb, memo_ins);
     auto differs = [](double a, double b) -> bool { return __double_as_longlong(a) != __double_as_longlong(b); };
 #pragma unroll
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
@@ -1611,6 +1733,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             col.f64[(size_t)(DC_TROT + 2 * k + 1) * np + e] = L(xbase + X_STRIDE * k + X_SA);
         }
         changed |= dfb;
+        if constexpr (MEMO) {
+            if (memo_ins) {
+                u64 *sv = memo_ent + ME_VAL + kMemoValShips + kMemoValShipWords * k;
+#pragma unroll
+                for (int f = 0; f < 9; ++f) sv[f] = dbits(v[f]);
+                sv[9] = dbits(L(xbase + X_STRIDE * k + X_CA)); sv[10] = dbits(L(xbase + X_STRIDE * k + X_SA)); sv[11] = 0ull;
+            }
+        }
     }
 #pragma unroll
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -1627,8 +1757,24 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             for (int f = 0; f < DC_GOAL_COLS; ++f) { q[(size_t)f * np] = v[f]; row[f] = v[f]; }
         }
         changed |= dfb;
+        if constexpr (MEMO) {
+            if (memo_ins && ((memo_incl >> g) & 1u)) {
+#pragma unroll
+                for (int f = 0; f < DC_GOAL_COLS; ++f) memo_ent[ME_VAL + kMemoValGoals + DC_GOAL_COLS * g + f] = dbits(v[f]);
+            }
+        }
     }
     changed |= (live != live0) | (ain != aout);
+    if constexpr (MEMO) {
+        if (memo_ins) {
+            // (a goal outside the key that this step nevertheless changed cannot exist: it had no velocity and no candidate pair)
+            memo_ent[ME_VAL + 0] = (u64)(changed ? 1u : 0u) | ((u64)(unsigned)n_act << 8) | ((u64)(unsigned)memo_n_aged << 16);
+            memo_ent[ME_VAL + 1] = live;
+            __threadfence();
+            memo_ent[ME_READY] = memo_tag;
+            atomicAdd(c.dyn_memo_stats + (size_t)(blockIdx.x & (kMemoStatSlots - 1)) * kMemoStatWords + 2, 1ull);
+        }
+    }
     stamp(5);
     if (d.stop_after == -1) {
         col.f64[(size_t)(DC_ARB + 4 * 50 + 6) * np + e] = (double)n_act;
@@ -1650,10 +1796,12 @@ size_t dyn_lds_bytes(int n_goals, bool uni)
 hipError_t prepare_dyn(const DevCfg &c)
 {
     if (dyn_lds_bytes(c.n_goals, false) > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024);
 }
 
@@ -1672,8 +1820,9 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipS
     // (a per-env ring of worlds never does)
     const bool uni = c.map_ring == 0 && c.n_maps <= kDynMapBuckets;
     const dim3 grid((unsigned)((c.n_pad + kDynPad) / kGrp));
-    if (uni) hipLaunchKernelGGL(dyn_step_kernel<true>, grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
-    else hipLaunchKernelGGL(dyn_step_kernel<false>, grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+    if (uni && c.dyn_memo) hipLaunchKernelGGL((dyn_step_kernel<true, true>), grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
+    else if (uni) hipLaunchKernelGGL((dyn_step_kernel<true, false>), grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
+    else hipLaunchKernelGGL((dyn_step_kernel<false, false>), grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
     return hipGetLastError();
 }
 

@@ -81,15 +81,27 @@ constexpr int kDynRow = 80, kDynRowTraffic = 48;
 //        up to 8 arbiter records, up to 4 aged arbiters' meta words
 constexpr int kMemoEntries = 1 << 14;
 enum { ME_TAG = 0, ME_READY, ME_BORN, ME_PAD, ME_KEY };
-constexpr int kMemoArbIn = 4, kMemoArbOut = 8, kMemoAged = 4, kMemoArbWords = 5;
-constexpr int kMemoKeyShips = 2, kMemoKeyGoals = kMemoKeyShips + 9 * SSG_N_TRAFFIC, kMemoKeyArbs = kMemoKeyGoals + 8 * SSG_MAX_GOALS;
-constexpr int kMemoKeyWords = (kMemoKeyArbs + kMemoArbIn * kMemoArbWords + 1) & ~1; // 98
+constexpr int kMemoArbIn = 4, kMemoArbOut = 8, kMemoAged = 4, kMemoArbWords = 6 /* pair id | meta | hashes, 4 impulses, pad */;
+// (every section starts on an even word: 16-byte loads; sections a lane's state does not use — goals that take no part, arbiter
+// slots beyond its count — are neither written nor read: the key's header says which ones are in use)
+constexpr int kMemoKeyShips = 2, kMemoKeyGoals = kMemoKeyShips + 28 /* 3 x 9 fields + pad */, kMemoKeyArbs = kMemoKeyGoals + 8 * SSG_MAX_GOALS;
+constexpr int kMemoKeyWords = kMemoKeyArbs + kMemoArbIn * kMemoArbWords; // 102
 constexpr int ME_VAL = ME_KEY + kMemoKeyWords;
-constexpr int kMemoValShips = 2, kMemoValGoals = kMemoValShips + 11 * SSG_N_TRAFFIC, kMemoValArbs = kMemoValGoals + 8 * SSG_MAX_GOALS;
+constexpr int kMemoValShipWords = 12 /* 9 fields, cos, sin, pad */;
+constexpr int kMemoValShips = 2, kMemoValGoals = kMemoValShips + kMemoValShipWords * SSG_N_TRAFFIC, kMemoValArbs = kMemoValGoals + 8 * SSG_MAX_GOALS;
 constexpr int kMemoValAged = kMemoValArbs + kMemoArbOut * kMemoArbWords;
-constexpr int kMemoValWords = (kMemoValAged + kMemoAged + 1) & ~1; // 128
-constexpr int kMemoStride = (ME_VAL + kMemoValWords + 1) & ~1;      // words per entry
+constexpr int kMemoValWords = kMemoValAged + kMemoAged; // 138
+constexpr int kMemoStride = ME_VAL + kMemoValWords;     // words per entry (244)
+static_assert(kMemoKeyGoals % 2 == 0 && kMemoKeyArbs % 2 == 0 && kMemoValGoals % 2 == 0 && kMemoValArbs % 2 == 0 && kMemoValAged % 2 == 0, "even sections");
 constexpr int kMemoProbes = 4;
+// The narrowphase memo (same launches, same generation / born protocol, a table of its own): cpCollide of a traffic ship against
+// a bank hull — GJK + EPA from a cold start + support-edge clipping, ~28 k cycles of a lone wave — is a pure function of the bank
+// record, the side, the ship and its pose (position, rotation).  A ship that rests against its bank keeps its pose bit for bit
+// while other bodies of its env still move, so envs whose STATE is new (the state memo misses) mostly meet a ship x bank pair
+// that is not.  Entry: header as above, key = (record | side | ship | fingerprint | bank epoch), p.x, p.y, cos, sin;
+// value = count | contact hashes, normal, p1[2], p2[2].
+constexpr int kNpmEntries = 1 << 14, kNpmProbes = 2;
+enum { NE_KEY = 4, NE_VAL = NE_KEY + 6, kNpmStride = NE_VAL + 12 };
 constexpr int kMemoStatSlots = 256, kMemoStatWords = 16; // per workgroup slot: [0] hits [1] misses [2] inserts [3] not memoisable
 static_assert(ME_KEY % 2 == 0 && ME_VAL % 2 == 0 && kMemoStride % 2 == 0, "16-byte loads of key and value");
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
@@ -141,6 +153,7 @@ struct DevCfg {
     // the memo of the full dyn step (see kMemoEntries); null = off (SSG_FLAG_DYN_MEMO_OFF, per-env worlds, banks of > 64 records)
     unsigned long long *dyn_memo;       // [kMemoEntries][kMemoStride]
     unsigned long long *dyn_memo_stats; // [kMemoStatSlots][kMemoStatWords]
+    unsigned long long *dyn_npm;        // [kNpmEntries][kNpmStride] the narrowphase memo (null with dyn_memo)
     unsigned long long dyn_seq;         // number of this launch of the full step (entries born in it are not read by it)
     unsigned dyn_memo_gen;              // 1..255: entries of another generation count as empty (bank change = new generation)
 };
@@ -154,6 +167,8 @@ struct DynCfg {
     double bias_coef, slop; // 1 - pow(collisionBias, dt), collisionSlop
     unsigned bank_epoch;    // bumped whenever the map bank changes: part of the pose hash
     int stop_after;         // development aid (SSG_DYN_STOP): leave the dyn kernel after phase n; 0 = run it all
+    unsigned memo_fp;       // fingerprint of every constant the full step reads (this struct, dt, damping, goal radius, ...): part of
+                            // the memo key, so a table never answers for another configuration
 };
 
 // traj: env rows between the output slots of consecutive steps of the launch (0 = every step rewrites the same rows)

@@ -103,7 +103,8 @@ class ShipVecEnv(*_BASES):
 
     def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
                  map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
-                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1, rllib=False, ring=32):
+                 fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1, rllib=False, ring=32,
+                 dyn_memo=True):
         torch = _torch()
         if not torch.cuda.is_available():
             raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -154,6 +155,8 @@ class ShipVecEnv(*_BASES):
             flags |= N.FLAG_BANK_IN_GLOBAL
         if exact_lidar:
             flags |= N.FLAG_EXACT_LIDAR
+        if not dyn_memo:  # config 4 measurement aid: every queued env computes its cpSpaceStep (no memo table look-ups)
+            flags |= N.FLAG_DYN_MEMO_OFF
         c.flags = flags
         # n_ships = 4: BASELINE configs[3] — env.game.add_default_traffic() (game.py:279-286) after every reset: three
         # traffic ships, dynamic goal bodies and Chipmunk's contact solver (csrc/shipsim_dynamics.hip)
@@ -329,6 +332,8 @@ class ShipVecEnv(*_BASES):
         dt = {8: torch.float64, 4: torch.int32, 1: torch.uint8}[es.value]
         if fid == N.F_STATS:
             return self.state[off.value: off.value + 8 * nc.value].view(torch.int64).view(-1, 4)
+        if fid == N.F_DYN_MEMO_STATS:
+            return self.state[off.value: off.value + 8 * nc.value].view(torch.int64).view(-1, 16)
         n_pad = stride.value // es.value
         v = self.state[off.value: off.value + nc.value * stride.value].view(dt).view(nc.value, n_pad)[:, :self.num_envs]
         return v[0] if nc.value == 1 else v
@@ -345,6 +350,15 @@ class ShipVecEnv(*_BASES):
     def field_stats_tensor(self):
         """int64 device tensor [4]: sum_return*100, sum_length, episodes, goals_hit of this handle (slots summed)."""
         return self.field(N.F_STATS).sum(dim=0)
+
+    def dyn_memo_stats(self):
+        """Config 4: how the full cpSpaceStep of the queued envs was served so far — looked up in the memo table (`hits`),
+        computed (`computed`), results stored (`stored`); SSG_F_DYN_MEMO_STATS."""
+        s = self.field(N.F_DYN_MEMO_STATS).sum(dim=0).cpu().numpy()
+        return {"hits": int(s[0]), "computed": int(s[1]), "stored": int(s[2]),
+                "ship_x_bank_narrowphase": {"hits": int(s[3]), "computed": int(s[4])},
+                "not_stored": {"not_memoisable_or_tag_collision": int(s[5]), "no_free_entry": int(s[6]), "too_many_aged": int(s[7])},
+                "computed_by_age_bucket": [int(v) for v in s[8:16]]}
 
     def stats(self):
         """Per-handle episode counters accumulated in-kernel: sum_return, sum_length, episodes, goals_hit."""

@@ -433,3 +433,46 @@ def test_config4_goal_override_moves_the_goal_bodies():
         assert (c.x, c.y) == (o[20], o[21])
     assert got >= 2      # the ship sails up x = 295..315 and collects the overridden goals, not the generated ones
     e.close()
+
+
+@pytest.mark.parametrize("n,n_maps,K", [(4096, 64, 140), (1000, 3, 90)])
+def test_config4_memo_is_invisible(n, n_maps, K):
+    """The memo of the full cpSpaceStep (SSG_F_DYN_MEMO_STATS: envs that share a bank record replay the same body states, so
+    a state's step is computed once and looked up afterwards) must change NOTHING: every output of every step, and every body /
+    arbiter / flag column at the end, bit for bit equal to a handle that computes every step (SSG_FLAG_DYN_MEMO_OFF) — and
+    equal to the oracle.  The table really answers (most look-ups hit once it is warm)."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    a = ShipVecEnv(n, n_beams=10, n_maps=n_maps, n_ships=4)
+    b = ShipVecEnv(n, n_beams=10, n_maps=n_maps, n_ships=4, dyn_memo=False)
+    ob = O.Batch(n, oracle_cfg(O, a), a.bank_polys, a.bank_goals, map_ids=np.arange(n) % a.n_maps)
+    oa = a.reset_tensor().clone()
+    assert torch.equal(oa, b.reset_tensor())
+    np.testing.assert_array_equal(oa.cpu().numpy(), ob.reset())
+    acts = a.random_actions(31, 0, K)
+    acts_h = acts.cpu().numpy()
+    worst = 0.0
+    for k in range(K):
+        o1, r1, d1, f1 = a.step_tensor(acts[k])
+        o2, r2, d2, f2 = b.step_tensor(acts[k])
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(f1, f2), "step %d" % k
+        r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=True, n_threads=8)
+        np.testing.assert_array_equal(d1.cpu().numpy(), r_done); np.testing.assert_array_equal(r1.cpu().numpy(), r_rew)
+        worst = max(worst, float(np.max(np.abs(o1.cpu().numpy() - r_obs))))
+    assert worst <= 1e-9
+    for fid in (N.F_X, N.F_Y, N.F_ANGLE, N.F_LIDAR, N.F_STEP_COUNT, N.F_MAP_ID, N.F_GOAL_MASK, N.F_TRAFFIC, N.F_GOAL_BODIES, N.F_DYN_FLAGS):
+        assert torch.equal(a.field(fid), b.field(fid)), fid
+    # the arbiter columns, the live masks and the row-major shadow too: the whole dyn region up to the queue / memo areas
+    import ctypes as C
+    off = {}
+    for name, fid in (("traffic", N.F_TRAFFIC), ("flags", N.F_DYN_FLAGS)):
+        o_, es, nc, st = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t()
+        N.check(N.lib().ssg_state_field(a._h, fid, C.byref(o_), C.byref(es), C.byref(nc), C.byref(st)), a._h, "field")
+        off[name] = o_.value
+    assert torch.equal(a.state[off["traffic"]: off["flags"]], b.state[off["traffic"]: off["flags"]])   # body, arbiter, live, u32 columns
+    _compare_dyn(N, a, ob, just_reset=r_done)
+    sa, sb = a.dyn_memo_stats(), b.dyn_memo_stats()
+    assert sb["hits"] == 0 and sb["stored"] == 0
+    assert sa["hits"] > sa["computed"] and sa["stored"] > 0, sa   # (the first ~9 steps after the full reset all compute: every env is new)
+    print("memo: %r" % sa)
+    a.close(); b.close()

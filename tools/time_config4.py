@@ -10,11 +10,13 @@ from ship_sim_gym_amd.vec_env import ShipVecEnv
 
 n = int(os.environ.get("N", "65536"))
 K, W = int(os.environ.get("K", "300")), 50
-vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
+vec = ShipVecEnv(n, n_beams=10, n_maps=int(os.environ.get("MAPS", "64")), n_ships=4, dyn_memo=os.environ.get("MEMO", "1") != "0",
+                 map_mode=os.environ.get("MAP_MODE", "bank"), ring=int(os.environ.get("RING", "8")))
 acts = vec.random_actions(12345, 0, K + W)
 vec.reset_tensor()
 vec.rollout_tensor(acts[:W])
 torch.cuda.synchronize()
+memo0 = vec.dyn_memo_stats()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 vec.rollout_tensor(acts[W:])
@@ -30,4 +32,4 @@ print("rest fraction %.3f; mean step_count %.1f; rest among step_count>=6: %.3f"
     rest_frac, float(steps.double().mean()), float(((fl & 4) != 0)[steps >= 6].double().mean())))
 print(json.dumps({"config": "C4 %d envs x 4 ships, 10 beams" % n, "us_per_step": ms * 1e3 / K,
                   "env_steps_per_s": n * K / (ms * 1e-3), "algorithmic_GBps": B * n * K / (ms * 1e-3) / 1e9,
-                  "stats": vec.stats()}))
+                  "stats": vec.stats(), "memo": vec.dyn_memo_stats(), "memo_after_warmup": memo0, "memo_on": os.environ.get("MEMO", "1") != "0"}))
