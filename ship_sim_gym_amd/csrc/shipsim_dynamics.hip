@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     auto dbits = [](double v) -> u64 { return (u64)__double_as_longlong(v); };
     bool memo_try = false;    // this lane computes, then stores its result in the table
     u64 *memo_ent = nullptr;  // ... in this entry,
-    u64 memo_tag = 0ull, memo_old = 1ull; // the claiming CAS's answer ^ the expected tag: 0 = claimed
+    u64 memo_old = 1ull; // the claiming CAS's answer ^ the expected tag: 0 = claimed
     unsigned memo_incl = 0u;
     u64 memo_hdr = 0ull;
     u64 memo_aged[kMemoAged] = {0ull, 0ull, 0ull, 0ull};
@@ -1145,12 +1145,11 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const u64 tag = (hh & ~0xFFull) | gen;
         const unsigned slot0 = (unsigned)(hh >> 24);
         // the headers of the probe sequence, one round trip
-        u64 ptag[kMemoProbes], prdy[kMemoProbes], pborn[kMemoProbes];
+        u64 ptag[kMemoProbes], prdy[kMemoProbes];
 #pragma unroll
         for (int p = 0; p < kMemoProbes; ++p) {
-            const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(c.dyn_memo + (size_t)((slot0 + (unsigned)p) & (unsigned)(kMemoEntries - 1)) * kMemoStride);
-            const ulonglong2 a = hp[0], b = hp[1];
-            ptag[p] = a.x; prdy[p] = a.y; pborn[p] = b.x;
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(c.dyn_memo + (size_t)((slot0 + (unsigned)p) & (unsigned)(kMemoEntries - 1)) * kMemoStride);
+            ptag[p] = a.x; prdy[p] = a.y;
         }
         int cand_p = -1, free_p = -1;
         bool claimed = false; // somebody is writing (or has written, this launch) an entry with this tag
@@ -1158,7 +1157,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
         for (int p = kMemoProbes - 1; p >= 0; --p) {
             const bool mine = ptag[p] == tag;
-            const bool usable = mine & (prdy[p] == tag) & (pborn[p] < c.dyn_seq);
+            // `ready` = (launch that completed the entry) << 8 | generation, stored last: usable = completed by an EARLIER launch of
+            // this generation (whatever this launch writes is not read by it, so no fence orders an entry's stores)
+            const bool usable = mine & ((prdy[p] & 0xFFull) == gen) & ((prdy[p] >> 8) < c.dyn_seq);
             const bool free_ = (ptag[p] & 0xFFull) != gen; // never used, or of another generation
             cand_p = usable ? p : cand_p;
             claimed |= mine & !usable;
@@ -1174,10 +1175,43 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         u64 sw[SSG_N_TRAFFIC][kMemoValShipWords];
         if (memo_ok & (cand_p >= 0)) {
             u64 diff = 0ull;
+            // (header, ships and the first two arbiter slots unconditionally — slots past the env's count hold whatever an older
+            // entry left and are masked out — so that the whole comparison of the common case is one batch of loads; goals that
+            // take part and further arbiters, lane by lane)
             key_visit([&](int i, u64 w0, u64 w1) {
                 const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + i);
                 diff |= (w.x ^ w0) | (w.y ^ w1);
-            }, incl, n_live);
+            }, 0u, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                u64 da = 0ull;
+#pragma unroll
+                for (int f = 0; f < kMemoArbWords; f += 2) {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyArbs + kMemoArbWords * a + f);
+                    da |= (w.x ^ key_arb_word(a, f)) | (w.y ^ key_arb_word(a, f + 1));
+                }
+                diff |= (a < n_live) ? da : 0ull;
+            }
+            if ((incl != 0u) | (n_live > 2)) {
+#pragma unroll
+                for (int g = 0; g < SSG_MAX_GOALS; ++g) {
+                    if (!((incl >> g) & 1u)) continue;
+#pragma unroll
+                    for (int f = 0; f < DC_GOAL_COLS; f += 2) {
+                        const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyGoals + DC_GOAL_COLS * g + f);
+                        diff |= (w.x ^ dbits(gin[g][f])) | (w.y ^ dbits(gin[g][f + 1]));
+                    }
+                }
+#pragma unroll
+                for (int a = 2; a < kMemoArbIn; ++a) {
+                    if (a >= n_live) continue;
+#pragma unroll
+                    for (int f = 0; f < kMemoArbWords; f += 2) {
+                        const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyArbs + kMemoArbWords * a + f);
+                        diff |= (w.x ^ key_arb_word(a, f)) | (w.y ^ key_arb_word(a, f + 1));
+                    }
+                }
+            }
             vh = ld2(0);
 #pragma unroll
             for (int k = 0; k < SSG_N_TRAFFIC; ++k)
@@ -1269,7 +1303,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         // the result is stored (it travels while the narrowphase runs).
         memo_try = memo_ok & (cand_p < 0) & !claimed & (free_p >= 0);
         memo_ent = c.dyn_memo + (size_t)((slot0 + (unsigned)(free_p < 0 ? 0 : free_p)) & (unsigned)(kMemoEntries - 1)) * kMemoStride;
-        memo_tag = tag;
         if (memo_try) memo_old = atomicCAS(memo_ent + ME_TAG, old_tag, tag) ^ old_tag; // 0 = the entry is this lane's
     }
     stamp(11);
@@ -1319,6 +1352,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                     u64 *np_ent = nullptr;
                     u64 np_tag = 0ull, np_old = 0ull;
                     u64 np_hdr = 0ull;
+                    const u64 gen_np = (u64)(c.dyn_memo_gen & 0xFFu);
                     if constexpr (MEMO) {
                         np_hdr = (u64)(unsigned)map_id | ((u64)(unsigned)r << 8) | ((u64)(unsigned)k << 12) | ((u64)(d.memo_fp & 0xFFFFu) << 16) |
                                  ((u64)(d.bank_epoch & 0xFFFFFFu) << 32);
@@ -1333,10 +1367,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                         bool claimed = false;
 #pragma unroll
                         for (int p = kNpmProbes - 1; p >= 0; --p) {
-                            const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(c.dyn_npm + (size_t)((slot0 + (unsigned)p) & (unsigned)(kNpmEntries - 1)) * kNpmStride);
-                            const ulonglong2 a = hp[0], b = hp[1];
+                            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(c.dyn_npm + (size_t)((slot0 + (unsigned)p) & (unsigned)(kNpmEntries - 1)) * kNpmStride);
                             const bool mine = a.x == np_tag;
-                            const bool usable = mine & (a.y == np_tag) & (b.x < c.dyn_seq);
+                            const bool usable = mine & ((a.y & 0xFFull) == gen) & ((a.y >> 8) < c.dyn_seq);
                             const bool free_ = (a.x & 0xFFull) != gen;
                             cp = usable ? p : cp;
                             claimed |= mine & !usable;
@@ -1366,8 +1399,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                         collide(sk, bs, info, emem);
                         if constexpr (MEMO) {
                             if (np_ent && atomicCAS(np_ent + ME_TAG, np_old, np_tag) == np_old) {
-                                np_ent[ME_BORN] = c.dyn_seq;
-                                __threadfence();
                                 np_ent[NE_KEY + 0] = np_hdr; np_ent[NE_KEY + 1] = dbits(sk.p.x); np_ent[NE_KEY + 2] = dbits(sk.p.y);
                                 np_ent[NE_KEY + 3] = dbits(sk.ca); np_ent[NE_KEY + 4] = dbits(sk.sa); np_ent[NE_KEY + 5] = 0ull;
                                 const bool c1 = info.count > 0, c2 = info.count > 1;
@@ -1378,8 +1409,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                                 np_ent[NE_VAL + 7] = dbits(c2 ? info.p1[1].x : 0.0); np_ent[NE_VAL + 8] = dbits(c2 ? info.p1[1].y : 0.0);
                                 np_ent[NE_VAL + 9] = dbits(c2 ? info.p2[1].x : 0.0); np_ent[NE_VAL + 10] = dbits(c2 ? info.p2[1].y : 0.0);
                                 np_ent[NE_VAL + 11] = 0ull;
-                                __threadfence();
-                                np_ent[ME_READY] = np_tag;
+                                np_ent[ME_READY] = (c.dyn_seq << 8) | gen_np;
                             }
                         }
                     }
@@ -1702,8 +1732,6 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         asm volatile("" : "+v"(memo_old)); // (first use of the CAS's answer: not before this point)
         memo_ins = memo_try & (memo_old == 0ull) & (memo_n_aged <= kMemoAged); // (a claimed entry that is not filled stays unusable: rare)
         if (memo_ins) {
-            memo_ent[ME_BORN] = c.dyn_seq; // (no launch reads an entry born in it; and the old generation's `ready` cannot match the new tag)
-            __threadfence();
             key_visit([&](int i, u64 w0, u64 w1) { memo_ent[ME_KEY + i] = w0; memo_ent[ME_KEY + i + 1] = w1; }, memo_incl, memo_n_live);
 #pragma unroll
             for (int i = 0; i < kMemoAged; ++i) memo_ent[ME_VAL + kMemoValAged + i] = memo_aged[i];
@@ -1770,8 +1798,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             // (a goal outside the key that this step nevertheless changed cannot exist: it had no velocity and no candidate pair)
             memo_ent[ME_VAL + 0] = (u64)(changed ? 1u : 0u) | ((u64)(unsigned)n_act << 8) | ((u64)(unsigned)memo_n_aged << 16);
             memo_ent[ME_VAL + 1] = live;
-            __threadfence();
-            memo_ent[ME_READY] = memo_tag;
+            memo_ent[ME_READY] = (c.dyn_seq << 8) | (u64)(c.dyn_memo_gen & 0xFFu); // (the entry's last store)
             atomicAdd(c.dyn_memo_stats + (size_t)(blockIdx.x & (kMemoStatSlots - 1)) * kMemoStatWords + 2, 1ull);
         }
     }
