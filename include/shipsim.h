@@ -150,7 +150,8 @@ typedef enum ssg_field {
                            v_bias.y, w, w_bias (add_goal's dynamic circle bodies, game.py:77-95) */
     SSG_F_DYN_FLAGS,    /* u8, n_ships == 4 only: bit 0 unused (rounds 2-3: the player touches a traffic ship; the step kernel
                            now runs that test itself), bit 1 = bodies to be rebuilt after an in-kernel auto-reset, bit 2 = the traffic ships and
-                           goal bodies are at rest (their cpSpaceStep is skipped as the identity; inspection only) */
+                           goal bodies are at rest (their cpSpaceStep is skipped as the identity; inspection only), bit 3 = the env
+                           has an entry in the queue of the next full cpSpaceStep */
     SSG_F_EPISODES,     /* i32: episodes this env has started so far (every reset counts; in map_ring mode episode p lives in
                            bank record e*R + p mod R) */
     SSG_F_DYN_MEMO_STATS, /* i64 [256 slots][16], n_ships == 4 only, to be summed over slots: [0] cpSpaceSteps answered by the memo
@@ -300,6 +301,12 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
  * player marker is always drawn.  Debugging / video aid (`metadata['render.modes']` lists 'rgb_array',
  * ship_env.py:18); not a hot path. */
 int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream);
+
+/* Inspection aid (config 4; no reference counterpart): launches of the full cpSpaceStep so far, and how many of them had to
+ * rebuild their queue from the per-env flags first (a pass over every env: after a full ssg_reset, a bank change,
+ * ssg_dyn_invalidate, a second masked ssg_reset between two steps; NOT after one masked ssg_reset between two steps, whose envs
+ * join the queue the step kernel left). */
+int ssg_debug_dyn_counters(const ssg_handle *h, uint64_t *full_steps, uint64_t *queue_rebuilds);
 
 /* Inspection aid (no reference counterpart): how ssg_set_map_bank laid the step kernel out for this handle — envs per workgroup (256, 128 or 64: halved
  * until the staged bank fits the CU's 160 KiB of LDS beside the exchange and lidar buffers), whether the bank is staged in LDS

@@ -20,7 +20,9 @@ struct ssg_handle {
     size_t off_stats = 0, off_f64 = 0, off_i32 = 0, off_mask = 0, off_obs2 = 0, off_obsH = 0, nbytes = 0;
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
     size_t off_dyn_hash = 0, off_dyn_count = 0, off_dyn_row = 0, off_dyn_bucket = 0;
-    size_t off_dyn_memo = 0, off_dyn_memo_stats = 0, off_dyn_npm = 0; // the memo of the full dyn step (shipsim_internal.h, kMemoEntries)
+    size_t off_dyn_memo = 0, off_dyn_memo_stats = 0, off_dyn_npm = 0, off_dyn_qmap = 0;
+    unsigned long long n_classify = 0; // launches of the classify pass (the queue of the full step rebuilt from the per-env flags)
+    int masked_resets_since_step = 0; // masked ssg_reset calls that joined the live dyn queue since the last step (at most one may) // the memo of the full dyn step (shipsim_internal.h, kMemoEntries)
     unsigned long long dyn_seq = 0;   // launches of the full step so far
     unsigned memo_gen = 1;            // generation of the memo's entries (1..255)
     bool memo_clear_pending = false;  // the generation counter wrapped: zero the table before the next launch
@@ -343,6 +345,7 @@ void refresh_dev(ssg_handle *h)
     d.dyn_hash = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_hash) : nullptr;
     d.dyn_count = dyn ? reinterpret_cast<unsigned *>(base + h->off_dyn_count) : nullptr;
     d.dyn_bucket = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_bucket) : nullptr;
+    d.dyn_qmap = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_qmap) : nullptr;
     d.dyn_par = 0; // (the queue is rebuilt from the flags after every refresh: dyn_queue_valid = false below)
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
     // the memo: shared bank records are what makes states repeat (not per-env worlds, not banks the queue's 64 map buckets cannot
@@ -536,7 +539,8 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
         h->off_dyn_memo_stats = (h->off_dyn_bucket + (size_t)ssg::kDynBuckets * np * sizeof(int32_t) + 255) & ~(size_t)255; // one array of n_pad slots per sort bucket
         h->off_dyn_memo = h->off_dyn_memo_stats + (size_t)ssg::kMemoStatSlots * ssg::kMemoStatWords * sizeof(unsigned long long);
         h->off_dyn_npm = h->off_dyn_memo + (size_t)ssg::kMemoEntries * ssg::kMemoStride * sizeof(unsigned long long);
-        h->nbytes = h->off_dyn_npm + (size_t)ssg::kNpmEntries * ssg::kNpmStride * sizeof(unsigned long long);
+        h->off_dyn_qmap = h->off_dyn_npm + (size_t)ssg::kNpmEntries * ssg::kNpmStride * sizeof(unsigned long long);
+        h->nbytes = h->off_dyn_qmap + np * sizeof(int32_t);
         const int rc = set_traffic(h);
         if (rc != SSG_OK) { delete h; return fail(nullptr, rc, "ssg_create: traffic ship geometry"); }
     }
@@ -705,10 +709,16 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
         }
         h->ring_credit -= 1;
     }
-    h->dyn_queue_valid = false;
+    // Config 4: a MASKED reset between two steps joins the queue the step kernel left for the next full cpSpaceStep (the RLlib flow
+    // resets its done envs this way after every step; rebuilding the queue from the per-env flags instead — memset + the classify
+    // pass over every env — cost the next step 12-19 us).  One such reset per step: every env then has at most one entry per sort
+    // bucket, which is what a bucket's n_pad slots hold; a second one, a full reset, or a queue that is not there rebuild it.
+    const bool append = h->cfg.n_ships > 1 && dev_mask && h->dyn_queue_valid && h->masked_resets_since_step == 0;
+    if (append) h->masked_resets_since_step = 1;
+    else h->dyn_queue_valid = false;
     hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
     if (e == hipSuccess && h->cfg.n_ships > 1) // add_default_traffic + fresh goal bodies for the reset envs
-        e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, static_cast<hipStream_t>(stream));
+        e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, append, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("reset launch: ") + hipGetErrorString(e));
     return SSG_OK;
 }
@@ -796,6 +806,7 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                     }
                 }
                 h->dev.dyn_seq = ++h->dyn_seq;
+                if (!h->dyn_queue_valid) h->n_classify++;
                 if (e == hipSuccess) e = ssg::launch_dyn_step(h->dev, h->dyn, !h->dyn_queue_valid, static_cast<hipStream_t>(stream));
                 if (e != hipSuccess) {
                     h->dyn_queue_valid = false; // (a queue the full step never consumed must not survive: the next call starts over)
@@ -812,6 +823,7 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
             }
             if (dyn) { // the step kernel's body role has queued the envs whose bodies must be stepped next, in the other counter set
                 h->dyn_queue_valid = true;
+                h->masked_resets_since_step = 0;
                 h->dev.dyn_par ^= 1;
             }
         }
@@ -913,6 +925,14 @@ int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev
         return fail(h, SSG_ERR_BAD_ARG, "ssg_render: bad argument");
     hipError_t e = ssg::launch_render(h->dev, h->dyn, env_index, width, height, dev_rgb, flags, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("render launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
+int ssg_debug_dyn_counters(const ssg_handle *h, uint64_t *full_steps, uint64_t *queue_rebuilds)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    if (full_steps) *full_steps = h->dyn_seq;
+    if (queue_rebuilds) *queue_rebuilds = h->n_classify;
     return SSG_OK;
 }
 

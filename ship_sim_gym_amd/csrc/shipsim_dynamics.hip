@@ -556,7 +556,9 @@ struct ArbLds {
 
 } // namespace
 
-__global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *__restrict__ mask)
+// append: the queue of the next full step is valid (the step kernel produced it) and stays so — the envs reset here join it
+// (masked ssg_reset between two steps: the RLlib flow resets its done envs this way after every step, ship_env.py:171-184 per env).
+__global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *__restrict__ mask, const int append)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs) return;
@@ -564,10 +566,23 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
     const int m = c.i32cols[(size_t)ICOL_MAP * col.np + e]; // written by reset_kernel just before (same stream)
     const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
+    const unsigned old_flag = col.flag[e];
+    const int old_map = c.dyn_qmap[e];
     dyn_init(c, d, col, e, rec);
     col.f64[(size_t)(DC_PREV_GOAL + 0) * col.np + e] = rec[SSG_MAP_OFF_SPAWN_GOAL]; // the reset frame's goal
     col.f64[(size_t)(DC_PREV_GOAL + 1) * col.np + e] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
-    col.flag[e] = 0;
+    if (!append) { col.flag[e] = 0; return; }
+    // A fresh space is stepped in full.  If the env already has an entry in the queue (flag bit 3, set by whoever queued it) under
+    // the record it is reset onto, that entry serves (the age only picks the sort bucket); an entry under ANOTHER record is stale
+    // — the full step drops entries whose record is not the env's — and a new one is appended.
+    const bool queued_here = ((old_flag & 8u) != 0u) & (old_map == m);
+    col.flag[e] = 8u;
+    if (!queued_here) {
+        const unsigned bucket = dyn_bucket_of(0, m);
+        const unsigned arrival = atomicAdd(c.dyn_count + (size_t)c.dyn_par * kDynCountWords + dyn_counter_word(bucket), 1u);
+        if (arrival < (unsigned)c.n_pad) c.dyn_bucket[(size_t)bucket * col.np + arrival] = e;
+        c.dyn_qmap[e] = m;
+    }
 }
 
 // 64-bit mixing for the "did this step change anything" test of the full step (inputs vs outputs, no re-reads).
@@ -647,9 +662,10 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         // gets its bodies rebuilt by the full step.)
         const bool rest = ((flag & 6u) == 4u) && (hash0 == (unsigned long long)d.bank_epoch) &&
                           (drop_removed_goal_arbiters(live0, gmask, ng) == live0);
-        if (rest) col.flag[e] = 4u;
+        col.flag[e] = rest ? 4u : (uint8_t)((flag & 6u) | 8u); // bit 3: the env has an entry in the queue of the coming full step
         need_full = !rest;
         bucket = dyn_bucket_of(age, map_id);
+        if (need_full) c.dyn_qmap[e] = map_id;
     }
     if (need_full) { // append to the bucket's array (order inside a bucket is irrelevant: every env is stepped on its own)
         unsigned *cnt = c.dyn_count + (size_t)c.dyn_par * kDynCountWords; // THIS step's counter set (zeroed by the host just before)
@@ -759,6 +775,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
     for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
     if (!UNI) map_id = map_col;
+    // an entry queued under another record than the env now sits on is stale: a masked ssg_reset moved the env after it was
+    // queued (and queued it again under its new record); entries under the env's record are all equivalent
+    if (UNI) queued &= (map_col & (kDynMapBuckets - 1)) == qmap;
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); one wave per workgroup: the LDS writes above are visible to its lanes
     __builtin_amdgcn_wave_barrier();
     if (!queued) return;
@@ -1877,10 +1896,10 @@ hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream)
+hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, bool append, hipStream_t stream)
 {
     const int block = 256;
-    hipLaunchKernelGGL(dyn_reset_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), 0, stream, c, d, mask);
+    hipLaunchKernelGGL(dyn_reset_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), 0, stream, c, d, mask, append ? 1 : 0);
     return hipGetLastError();
 }
 

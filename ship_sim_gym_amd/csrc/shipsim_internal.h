@@ -138,6 +138,7 @@ struct DevCfg {
     uint8_t *dyn_flag;            // (bit 0 unused: the step kernel runs collide_ship against the traffic ships itself)
                                   // bit 1: env was auto-reset by the step kernel (step -> dyn kernel)
                                   // bit 2: the env's non-player bodies are at rest (see dyn_classify_kernel)
+                                  // bit 3: the env has an entry in the queue of the next full step (cleared by that step)
     unsigned long long *dyn_hash; // bank generation (DynCfg::bank_epoch) the rest bit was established for
     // The queue of the full dyn step.  Produced for step t+1 by the step kernel's body role at the end of step t (or, after a
     // host-side reset / bank change / ssg_dyn_invalidate, by dyn_classify_kernel): one array of n_pad env indices per sort bucket,
@@ -146,6 +147,7 @@ struct DevCfg {
     // after every step.
     int32_t *dyn_bucket;          // [kDynBuckets][n_pad]
     unsigned *dyn_count;          // [2][kDynCountWords]: bucket b's counter at dyn_counter_word(b) of its set
+    int32_t *dyn_qmap;            // [n_pad] the bank record an env's queue entry was queued under (valid while flag bit 3 is set)
     int dyn_par;                  // the counter set that holds THIS step's queue
     double dyn_reach2[SSG_N_TRAFFIC]; // (traffic ship k's hull radius + margin)^2: the step kernel's reject in front of collide_ship's exact test
     double thull[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS], tnrm[SSG_N_TRAFFIC][2 * SSG_SHIP_VERTS]; // the traffic hulls (local), for that test
@@ -182,7 +184,7 @@ hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream);
 hipError_t prepare_dyn(const DevCfg &c);
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream);
-hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, hipStream_t stream);
+hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, bool append, hipStream_t stream);
 hipError_t launch_render(const DevCfg &c, const DynCfg &d, int e, int width, int height, uint8_t *rgb, unsigned flags,
                          hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);

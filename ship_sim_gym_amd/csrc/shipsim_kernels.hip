@@ -1599,7 +1599,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     if constexpr (DYN) {
         if (live) {
             // bit 1 tells the dyn kernels to rebuild this env's traffic / goal bodies; bit 2 (bodies at rest) is theirs
-            c.dyn_flag[el_] = (uint8_t)(do_reset ? 2u : (dflag & 4u));
+            // (bit 3, set below: the env has an entry in the queue of the next full step)
         }
         // Which envs need the full cpSpaceStep of their other bodies NEXT step (shipsim_dynamics.hip)?  Everything that decides
         // it is in this role's registers now: a reset env (fresh bodies), an env whose bodies are not at rest, one that lost a
@@ -1634,6 +1634,10 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             q_arrival = atomicAdd(c.dyn_count + (size_t)(c.dyn_par ^ 1) * kDynCountWords + dyn_counter_word(bucket), 1u);
         }
         q_need = need_full;
+        if (live) {
+            c.dyn_flag[el_] = (uint8_t)((do_reset ? 2u : (dflag & 4u)) | (need_full ? 8u : 0u));
+            if (need_full) c.dyn_qmap[el_] = map_id; // the record the entry is queued under (a later masked ssg_reset may move the env)
+        }
     }
     SSG_STAMP_K(6);
     if (live && !SSG_ABL(6)) {

@@ -351,6 +351,12 @@ class ShipVecEnv(*_BASES):
         """int64 device tensor [4]: sum_return*100, sum_length, episodes, goals_hit of this handle (slots summed)."""
         return self.field(N.F_STATS).sum(dim=0)
 
+    def dyn_counters(self):
+        """Config 4: (launches of the full cpSpaceStep, how many of them rebuilt their queue from the per-env flags first)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        N.check(N.lib().ssg_debug_dyn_counters(self._h, C.byref(a), C.byref(b)), self._h, "ssg_debug_dyn_counters")
+        return int(a.value), int(b.value)
+
     def dyn_memo_stats(self):
         """Config 4: how the full cpSpaceStep of the queued envs was served so far — looked up in the memo table (`hits`),
         computed (`computed`), results stored (`stored`); SSG_F_DYN_MEMO_STATS."""

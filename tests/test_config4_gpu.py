@@ -476,3 +476,47 @@ def test_config4_memo_is_invisible(n, n_maps, K):
     assert sa["hits"] > sa["computed"] and sa["stored"] > 0, sa   # (the first ~9 steps after the full reset all compute: every env is new)
     print("memo: %r" % sa)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,n_maps,memo", [(2048, 16, True), (1500, 96, True), (1024, 1, False)])
+def test_config4_masked_reset_joins_the_queue(n, n_maps, memo):
+    """The RLlib flow (train/rllib/ppo.py:21-44 over ShipEnv.reset, ship_env.py:171-184): no in-kernel auto-reset, the caller
+    resets the done envs with ONE masked ssg_reset after every step.  Those envs join the queue the step kernel left for the
+    next full cpSpaceStep (no rebuild of the queue from the per-env flags: ssg_debug_dyn_counters), and every step — terminal
+    observations, reset observations, rewards, done flags, the bodies — matches the oracle stepped the same way.  A SECOND
+    masked reset between two steps (every tenth step here) falls back to the rebuild and stays exact."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    K = 120
+    vec = ShipVecEnv(n, n_beams=10, n_maps=n_maps, n_ships=4, auto_reset=False, dyn_memo=memo)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    acts = vec.random_actions(555, 0, K)
+    acts_h = acts.cpu().numpy()
+    n_done, worst, doubles = 0, 0.0, 0
+
+    def masked_reset(done_t, done_h):
+        ids = vec.field(N.F_MAP_ID).clone()
+        ids = torch.where(done_t != 0, (ids + 1) % vec.n_maps, ids).to(torch.int32).contiguous()
+        o2 = vec.reset_tensor(mask=done_t.clone(), map_ids=ids)
+        r2 = ob.auto_reset_done()
+        np.testing.assert_array_equal(o2.cpu().numpy()[done_h != 0], r2[done_h != 0])
+
+    for k in range(K):
+        obs, rew, done, flags = vec.step_tensor(acts[k])
+        r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=False, n_threads=8)
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done, err_msg="done differs at step %d" % k)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
+        worst = max(worst, float(np.max(np.abs(obs.cpu().numpy() - r_obs))))       # terminal observations of the done envs
+        if r_done.any():
+            masked_reset(done, r_done)
+            n_done += int(r_done.sum())
+            if k % 10 == 3:                                                        # ... and once more: onto the record after that
+                masked_reset(done, r_done)
+                doubles += 1
+        if k in (1, 5, 40, K - 1):
+            _compare_dyn(N, vec, ob)                                               # (a masked reset rebuilds the bodies at once)
+    assert worst <= 1e-9 and n_done > n // 2 and doubles >= 3
+    steps, rebuilds = vec.dyn_counters()
+    assert steps == K and rebuilds == 1 + doubles, (steps, rebuilds, doubles)      # the first step, and the steps after a double reset
+    vec.close()
