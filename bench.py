@@ -191,10 +191,11 @@ def event_time_rollout(vec, acts, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32):
+def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_memo=True, kernel_split=False):
     """Informational timing of another BASELINE config on this GPU (outside the headline's timed region)."""
     from ship_sim_gym_amd.vec_env import ShipVecEnv
-    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships, ring=ring)
+    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships, ring=ring,
+                     dyn_memo=dyn_memo)
     acts = vec.random_actions(12345, 0, K + W)
     vec.reset_tensor()
     vec.rollout_tensor(acts[:W])
@@ -202,12 +203,57 @@ def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32):
     B = algorithmic_bytes(n_ships, n_beams, 2)
     us = ms * 1e3 / K
     sps = n * K / (ms * 1e-3)
+    out = {"envs": n, "outputs": "trajectory [K,N,...]", "n_beams": n_beams, "n_ships": n_ships, "map_mode": map_mode, "steps": K, "us_per_step": us, "env_steps_per_s": sps,
+           "algorithmic_bytes_per_env_step": B, "achieved_GBps": sps * B / 1e9, "frac": sps * B / 1e9 / HBM_PEAK_GBPS}
+    if n_ships > 1:
+        out["dyn_memo"] = bool(dyn_memo and map_mode == "bank")
+        if out["dyn_memo"]:
+            st = vec.dyn_memo_stats()
+            out["memo_lookups"] = {k: st[k] for k in ("hits", "computed", "stored")}
+    if kernel_split and n_ships > 1:
+        # the two launches of a config-4 step, by HIP events around each (a separate short run: the events and the wait at the end
+        # of the call are not part of the figure above)
+        vec.kernel_times(True)
+        vec.rollout_tensor(acts[W: W + min(K, 100)])
+        d_us, s_us, cnt = vec.kernel_times(False)
+        out["kernel_split_us"] = {"dyn_step_kernel": d_us, "step_kernel_DYN": s_us, "steps": cnt,
+                                  "method": "HIP events around each of the two launches of a step, separate %d-step run" % cnt}
     vec.close()
     del acts
     import torch
     torch.cuda.empty_cache()
-    return {"envs": n, "outputs": "trajectory [K,N,...]", "n_beams": n_beams, "n_ships": n_ships, "map_mode": map_mode, "steps": K, "us_per_step": us, "env_steps_per_s": sps,
-            "algorithmic_bytes_per_env_step": B, "achieved_GBps": sps * B / 1e9, "frac": sps * B / 1e9 / HBM_PEAK_GBPS}
+    return out
+
+
+def c4_policy_in_the_loop(dev, n, host_reset, ks=300):
+    """Config 4 stepped one ssg_step at a time (what a trainer does), us per step (median of 5 x `ks` back-to-back steps):
+    host_reset = False: VecEnv semantics, done envs are reset inside the step kernel; host_reset = True: the RLlib flow on the
+    device — no in-kernel auto-reset, ONE masked ssg_reset(mask = done) after every step (its envs join the queue of the next
+    full cpSpaceStep), no host synchronisation in the loop."""
+    import torch
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=10, n_ships=4, auto_reset=not host_reset)
+    a1 = vec.random_actions(4242, 0, ks)
+    rows = [a1[k] for k in range(ks)]
+    vec.reset_tensor()
+    reps = []
+    for r in range(6):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for a in rows:
+            obs, rew, done, flags = vec.step_tensor(a)
+            if host_reset:
+                vec.reset_tensor(mask=done)   # (default record of each env; the mask is the done tensor the step just wrote)
+        e1.record()
+        torch.cuda.synchronize()
+        if r > 0:
+            reps.append(e0.elapsed_time(e1) * 1e3 / ks)
+    steps, rebuilds = vec.dyn_counters()
+    vec.close()
+    torch.cuda.empty_cache()
+    return {"envs": n, "us_per_step": sorted(reps)[len(reps) // 2], "repeats_us": reps, "launch": "one ssg_step per step" + (" + one masked ssg_reset" if host_reset else ""),
+            "full_cpSpaceSteps": steps, "queue_rebuilds": rebuilds}
 
 
 def free_port():
@@ -532,7 +578,19 @@ def main():
         if world == 1 and not args.no_other_configs and not c4:
             try:
                 other["c2_4096_envs_10_beams"] = side_config(dev, 4096, 10, 1, 1000, 200)
-                other["c4_65536_envs_x4_ships_10_beams"] = side_config(dev, 65536, 10, 4, 200, 200)
+                # BASELINE configs[3].  Bank mode (the benchmark workload of SURVEY 8d: envs share the 64 records): cpSpaceStep of the
+                # traffic ships / goal bodies is MEMOISED (SSG_F_DYN_MEMO_STATS) — labelled, and next to it the same run with every
+                # step computed, and with a brand-new world per episode (no env shares a world: nothing to memoise)
+                other["c4_65536_envs_x4_ships_10_beams"] = side_config(dev, 65536, 10, 4, 200, 200, kernel_split=True)
+                other["c4_65536_envs_x4_ships_10_beams"]["note"] = ("bank mode: envs on one bank record replay the same body states, "
+                                                                    "so a state's cpSpaceStep is computed once and looked up afterwards "
+                                                                    "(verified word for word); c4_memo_off / c4_fresh_world_per_episode "
+                                                                    "are the figures without that sharing")
+                other["c4_memo_off"] = side_config(dev, 65536, 10, 4, 200, 200, dyn_memo=False, kernel_split=True)
+                other["c4_fresh_world_per_episode"] = side_config(dev, 65536, 10, 4, 60, 30, map_mode="fresh_device", ring=8)
+                other["c4_fresh_world_per_episode"]["ring"] = 8
+                other["c4_single_step_auto_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=False)
+                other["c4_host_masked_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=True)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
                 # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 48 worlds per env: launches
                 # of up to 47 fused steps between refills)

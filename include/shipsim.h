@@ -292,7 +292,11 @@ int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *d
  * or SSG_F_MAP_ID (scenario set-up, curriculum placement, tests) — tells it with this call: the queue of the next step is then
  * rebuilt from the columns, and the ships' rotation columns (what collide_ship's player x traffic test in the step kernel turns
  * their hulls with) are recomputed from the angles.
- * dev_mask: u8[n_envs], non-zero = also clear the env's rest bit and refresh its row-major shadow; NULL = all envs. */
+ * dev_mask: u8[n_envs], non-zero = also clear the env's rest bit and refresh its row-major shadow; NULL = all envs.  (The rotation
+ * columns are recomputed for every env whatever the mask says.)
+ * The caller-owned state blob also holds the queue of the next full cpSpaceStep, whose live counter set is named by the HANDLE:
+ * a blob that is copied, restored in place or bound to another handle between two steps must be followed by ssg_bind_state or
+ * ssg_dyn_invalidate(h, NULL, ...) — both make the next step rebuild the queue from the per-env flags. */
 int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
 
 /* Replaces: ShipGame.render + ShipGame.get_screen (game.py:133-138,197-229) for ONE env: an RGB frame of `width` x
@@ -301,6 +305,12 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
  * player marker is always drawn.  Debugging / video aid (`metadata['render.modes']` lists 'rgb_array',
  * ship_env.py:18); not a hot path. */
 int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev_rgb, uint32_t flags, void *stream);
+
+/* Measurement aid (config 4; no reference counterpart): with enable != 0, every following ssg_step / ssg_rollout* call brackets the
+ * two launches of each step — the full cpSpaceStep of the queued envs, the step kernel — with HIP events on the caller's stream and
+ * waits for its own work at the end of the call.  Returns the averages (microseconds per step) and the number of steps accumulated
+ * since the previous call, then starts over.  How bench.py splits a config-4 step into its two kernels. */
+int ssg_debug_kernel_times(ssg_handle *h, int enable, double *dyn_step_us, double *step_kernel_us, uint64_t *steps);
 
 /* Inspection aid (config 4; no reference counterpart): launches of the full cpSpaceStep so far, and how many of them had to
  * rebuild their queue from the per-env flags first (a pass over every env: after a full ssg_reset, a bank change,

@@ -25,7 +25,7 @@ EXPORTS = (
     "ssg_config_set_ship", "ssg_state_nbytes", "ssg_state_field", "ssg_bind_state", "ssg_set_map_bank", "ssg_reset",
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
-    "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_rollout_traj", "ssg_debug_dyn_counters",
+    "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_rollout_traj", "ssg_debug_dyn_counters", "ssg_debug_kernel_times",
 )
 
 
@@ -83,6 +83,7 @@ def lib():
     L.ssg_bind_state.argtypes = [vp, vp]
     L.ssg_init_state.argtypes = [vp, vp]
     L.ssg_debug_launch_geometry.argtypes = [vp, ip, ip, szp]
+    L.ssg_debug_kernel_times.argtypes = [vp, C.c_int, dp, dp, C.POINTER(C.c_uint64)]
     L.ssg_debug_dyn_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ssg_refill_worlds.argtypes = [vp, C.c_uint64, C.c_double, vp, vp]
     L.ssg_set_map_bank.argtypes = [vp, vp, C.c_int]

@@ -21,6 +21,9 @@ struct ssg_handle {
     size_t off_dyn_f64 = 0, off_dyn_live = 0, off_dyn_u32 = 0, off_dyn_flag = 0; // config 4 only
     size_t off_dyn_hash = 0, off_dyn_count = 0, off_dyn_row = 0, off_dyn_bucket = 0;
     size_t off_dyn_memo = 0, off_dyn_memo_stats = 0, off_dyn_npm = 0, off_dyn_qmap = 0;
+    bool time_kernels = false;        // ssg_debug_kernel_times: HIP events around the two launches of every config-4 step
+    double t_dyn_ms = 0.0, t_step_ms = 0.0;
+    unsigned long long t_steps = 0;
     unsigned long long n_classify = 0; // launches of the classify pass (the queue of the full step rebuilt from the per-env flags)
     int masked_resets_since_step = 0; // masked ssg_reset calls that joined the live dyn queue since the last step (at most one may) // the memo of the full dyn step (shipsim_internal.h, kMemoEntries)
     unsigned long long dyn_seq = 0;   // launches of the full step so far
@@ -645,7 +648,7 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     // the CU's LDS beside the lidar scratch; if even 64 does not fit, gather records from L2/HBM instead.
     h->block = pick_block(h->cfg.n_envs);
     if (!(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL))
-        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) > 160u * 1024u) h->block /= 2;
+        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps, h->cfg.n_ships > 1) > 160u * 1024u) h->block /= 2;
     if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64; // the config-4 step kernel is built for 64 and 256
     if (h->bank && n_maps < h->n_maps) h->remap_pending = true; // stale record indices >= n_maps must not survive
     h->bank = dev_bank;
@@ -654,12 +657,12 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     memo_new_generation(h);
     // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch
     h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
-             ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps) <= 160u * 1024u;
+             ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps, h->cfg.n_ships > 1) <= 160u * 1024u;
     if (!h->lds) { // gathered bank: the record heads live in LDS columns beside the lidar buffers — they must fit too
-        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, false, n_maps) > 160u * 1024u) h->block /= 2;
+        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, false, n_maps, h->cfg.n_ships > 1) > 160u * 1024u) h->block /= 2;
         if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64;
     }
-    h->lds_bytes = ssg::step_lds_bytes(h->cfg.n_beams, h->block, h->lds, n_maps);
+    h->lds_bytes = ssg::step_lds_bytes(h->cfg.n_beams, h->block, h->lds, n_maps, h->cfg.n_ships > 1);
     h->prepared = false;
     refresh_dev(h);
     return SSG_OK;
@@ -716,9 +719,11 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
     const bool append = h->cfg.n_ships > 1 && dev_mask && h->dyn_queue_valid && h->masked_resets_since_step == 0;
     if (append) h->masked_resets_since_step = 1;
     else h->dyn_queue_valid = false;
-    hipError_t e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
-    if (e == hipSuccess && h->cfg.n_ships > 1) // add_default_traffic + fresh goal bodies for the reset envs
-        e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, append, static_cast<hipStream_t>(stream));
+    hipError_t e;
+    if (h->cfg.n_ships > 1) // the player, then add_default_traffic + fresh goal bodies of the reset envs: one launch
+        e = ssg::launch_dyn_reset(h->dev, h->dyn, dev_mask, dev_map_ids, dev_obs, append, static_cast<hipStream_t>(stream));
+    else
+        e = ssg::launch_reset(h->dev, dev_mask, dev_map_ids, dev_obs, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("reset launch: ") + hipGetErrorString(e));
     return SSG_OK;
 }
@@ -783,7 +788,13 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
         // kernel, which reads this step's goal positions and the traffic-contact bit it left in the dyn columns.
         const bool shift = h->cfg.history > 2;
         if (h->cfg.map_ring > 0 && !h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds first");
+        std::vector<hipEvent_t> evs; // measurement aid: three events per step (before the full cpSpaceStep, between, after the step kernel)
+        if (dyn && h->time_kernels) {
+            evs.resize(3 * (size_t)K);
+            for (auto &ev : evs) hipEventCreate(&ev);
+        }
         for (int k = 0; k < K; ++k) {
+            if (!evs.empty()) hipEventRecord(evs[3 * k], static_cast<hipStream_t>(stream));
             if (h->cfg.map_ring > 0) { // every step may start one episode per env: keep an unused world in every ring
                 if (h->ring_credit < 1) {
                     rc = ring_refill(h, nullptr, stream);
@@ -813,9 +824,11 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                     return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
                 }
             }
+            if (!evs.empty()) hipEventRecord(evs[3 * k + 1], static_cast<hipStream_t>(stream));
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
                                             shift ? h->dev.obs2 : obs_at(k), rew_at(k), done_at(k), flags_at(k), 0,
                                             static_cast<hipStream_t>(stream));
+            if (!evs.empty()) hipEventRecord(evs[3 * k + 2], static_cast<hipStream_t>(stream));
             if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
             if (e != hipSuccess) {
                 h->dyn_queue_valid = false; // (the next call rebuilds the dyn queue from the flags, counters zeroed)
@@ -826,6 +839,16 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 h->masked_resets_since_step = 0;
                 h->dev.dyn_par ^= 1;
             }
+        }
+        if (!evs.empty()) { // (this call then waits for its own work: a measurement run, not the product path)
+            hipStreamSynchronize(static_cast<hipStream_t>(stream));
+            for (int k = 0; k < K; ++k) {
+                float a = 0.f, b = 0.f;
+                hipEventElapsedTime(&a, evs[3 * k], evs[3 * k + 1]);
+                hipEventElapsedTime(&b, evs[3 * k + 1], evs[3 * k + 2]);
+                h->t_dyn_ms += a; h->t_step_ms += b; h->t_steps++;
+            }
+            for (auto &ev : evs) hipEventDestroy(ev);
         }
         return SSG_OK;
     }
@@ -925,6 +948,18 @@ int ssg_render(ssg_handle *h, int env_index, int width, int height, uint8_t *dev
         return fail(h, SSG_ERR_BAD_ARG, "ssg_render: bad argument");
     hipError_t e = ssg::launch_render(h->dev, h->dyn, env_index, width, height, dev_rgb, flags, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("render launch: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
+int ssg_debug_kernel_times(ssg_handle *h, int enable, double *dyn_step_us, double *step_kernel_us, uint64_t *steps)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    if (dyn_step_us) *dyn_step_us = h->t_steps ? h->t_dyn_ms * 1e3 / (double)h->t_steps : 0.0;
+    if (step_kernel_us) *step_kernel_us = h->t_steps ? h->t_step_ms * 1e3 / (double)h->t_steps : 0.0;
+    if (steps) *steps = h->t_steps;
+    h->time_kernels = enable != 0;
+    h->t_dyn_ms = h->t_step_ms = 0.0;
+    h->t_steps = 0;
     return SSG_OK;
 }
 

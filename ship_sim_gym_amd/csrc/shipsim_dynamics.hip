@@ -558,13 +558,16 @@ struct ArbLds {
 
 // append: the queue of the next full step is valid (the step kernel produced it) and stays so — the envs reset here join it
 // (masked ssg_reset between two steps: the RLlib flow resets its done envs this way after every step, ship_env.py:171-184 per env).
-__global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *__restrict__ mask, const int append)
+// (One launch does the whole reset of a config-4 env: the player's columns and observation rows — reset_env, what reset_kernel runs
+// for the 1-ship configs — and the env's other bodies: a masked reset is a launch between every two steps of the RLlib flow.)
+__global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *__restrict__ mask, const int32_t *__restrict__ map_ids,
+                                 double *__restrict__ obs, const int append)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs) return;
     if (mask && !mask[e]) return;
     DynCols col{c.dyn_f64, c.dyn_u32, c.dyn_live, c.dyn_flag, (size_t)c.n_pad};
-    const int m = c.i32cols[(size_t)ICOL_MAP * col.np + e]; // written by reset_kernel just before (same stream)
+    const int m = reset_env(c, e, map_ids, obs);
     const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
     const unsigned old_flag = col.flag[e];
     const int old_map = c.dyn_qmap[e];
@@ -1875,14 +1878,18 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipS
 __global__ void dyn_invalidate_kernel(const DevCfg c, const uint8_t *__restrict__ mask)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= c.n_envs || (mask && !mask[e])) return;
-    c.dyn_flag[e] &= (uint8_t)~4u;
-    // the caller wrote the body columns: bring the row-major shadow the full step loads from up to date
+    if (e >= c.n_envs) return;
     const size_t np = (size_t)c.n_pad;
-    double *row = c.dyn_row + (size_t)e * kDynRow;
-    for (int i = 0; i < DC_GOAL_COLS * SSG_MAX_GOALS; ++i) row[i] = c.dyn_f64[(size_t)(DC_GOALS + i) * np + e];
-    for (int i = 0; i < 9 * SSG_N_TRAFFIC; ++i) row[kDynRowTraffic + i] = c.dyn_f64[(size_t)(DC_TRAFFIC + i) * np + e];
-    for (int k = 0; k < SSG_N_TRAFFIC; ++k) { // ... and the rotations of the (possibly rewritten) angle columns
+    if (!mask || mask[e]) {
+        c.dyn_flag[e] &= (uint8_t)~4u;
+        // the caller wrote the body columns: bring the row-major shadow the full step loads from up to date
+        double *row = c.dyn_row + (size_t)e * kDynRow;
+        for (int i = 0; i < DC_GOAL_COLS * SSG_MAX_GOALS; ++i) row[i] = c.dyn_f64[(size_t)(DC_GOALS + i) * np + e];
+        for (int i = 0; i < 9 * SSG_N_TRAFFIC; ++i) row[kDynRowTraffic + i] = c.dyn_f64[(size_t)(DC_TRAFFIC + i) * np + e];
+    }
+    // the rotations of the (possibly rewritten) angle columns — for EVERY env, masked or not: the step kernel's collide_ship turns
+    // the traffic hulls with these, and a caller's mask may name fewer envs than it wrote
+    for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
         double sa, ca;
         sincos_body(c.dyn_f64[(size_t)(DC_TRAFFIC + 9 * k + 2) * np + e], &sa, &ca);
         c.dyn_f64[(size_t)(DC_TROT + 2 * k) * np + e] = ca;
@@ -1896,10 +1903,10 @@ hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, bool append, hipStream_t stream)
+hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, const int32_t *map_ids, double *obs, bool append, hipStream_t stream)
 {
     const int block = 256;
-    hipLaunchKernelGGL(dyn_reset_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), 0, stream, c, d, mask, append ? 1 : 0);
+    hipLaunchKernelGGL(dyn_reset_kernel, dim3((unsigned)((c.n_envs + block - 1) / block)), dim3(block), 0, stream, c, d, mask, map_ids, obs, append ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -176,7 +176,7 @@ struct DynCfg {
 // traj: env rows between the output slots of consecutive steps of the launch (0 = every step rewrites the same rows)
 hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, const int32_t *actions_kn, int K, double *obs,
                        double *reward, uint8_t *done, uint8_t *flags, long long traj, hipStream_t stream);
-size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps);
+size_t step_lds_bytes(int n_beams, int block, bool lds_bank, int n_maps, bool dyn /* the config-4 instantiations */);
 hipError_t prepare_step(const DevCfg &c, int block, bool lds, size_t lds_bytes);
 hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map_ids, double *obs, hipStream_t stream);
 // sort + full step of the queue; classify = true: rebuild the queue first from the per-env flags (the step kernel did not
@@ -184,7 +184,7 @@ hipError_t launch_reset(const DevCfg &c, const uint8_t *mask, const int32_t *map
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream);
 hipError_t prepare_dyn(const DevCfg &c);
 hipError_t launch_dyn_invalidate(const DevCfg &c, const uint8_t *mask, hipStream_t stream);
-hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, bool append, hipStream_t stream);
+hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mask, const int32_t *map_ids, double *obs, bool append, hipStream_t stream); // player + other bodies, one launch
 hipError_t launch_render(const DevCfg &c, const DynCfg &d, int e, int width, int height, uint8_t *rgb, unsigned flags,
                          hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
@@ -200,6 +200,48 @@ hipError_t launch_fill_actions(uint64_t seed, uint64_t step0, int K, long long e
                                hipStream_t stream);
 
 #ifdef __HIPCC__
+// ShipEnv.reset / ShipGame.reset of ONE env (ship_env.py:171-184, game.py:260-277): the player's columns, the goal mask, the
+// observation rows (deque([-1]*n), then the spawn frame).  Shared by reset_kernel and, for config 4, the kernel that also rebuilds
+// the env's traffic ships and goal bodies in the same launch (shipsim_dynamics.hip).  Returns the bank record the env is reset onto.
+__device__ __forceinline__ int reset_env(const DevCfg &c, const int e, const int32_t *__restrict__ map_ids, double *__restrict__ obs)
+{
+    const size_t np = (size_t)c.n_pad;
+    int m;
+    const int started = c.i32cols[ICOL_EPISODE * np + e]; // episodes this env has started so far
+    if (map_ids) m = (int)((unsigned)map_ids[e] % (unsigned)c.n_maps); // a record index never points outside the bank
+    else if (c.map_ring > 0) m = e * c.map_ring + started % c.map_ring;   // the env's next brand-new world
+    else m = (int)((c.env_id_base + (long long)e) % (long long)c.n_maps);
+    c.i32cols[ICOL_EPISODE * np + e] = started + 1;
+    const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
+    c.f64cols[COL_X * np + e] = c.spawn_x;
+    c.f64cols[COL_Y * np + e] = c.spawn_y;
+    c.f64cols[COL_VX * np + e] = 0.0;
+    c.f64cols[COL_VY * np + e] = 0.0;
+    c.f64cols[COL_A * np + e] = 0.0;
+    c.f64cols[COL_W * np + e] = 0.0;
+    c.f64cols[COL_CUM * np + e] = 0.0;
+    for (int i = 0; i < c.n_beams; ++i) c.f64cols[(COL_LIDAR + i) * np + e] = -1.0;
+    c.i32cols[ICOL_RUDDER * np + e] = 0;
+    c.i32cols[ICOL_STEP * np + e] = 0;
+    c.i32cols[ICOL_MAP * np + e] = m;
+    c.mask[e] = (uint8_t)((1u << c.n_goals) - 1u);
+    // deque([-1]*n), ship_env.py:180-181, then the spawn frame — into the caller's rows and, with HISTORY_SIZE > 2, into the
+    // handle's own copy of the rows (the frame-shift kernel's source: the caller's buffer is output only)
+    const int F = 6 + c.n_beams;
+    double *dst[2] = {obs ? obs + (size_t)e * (size_t)(F * c.full_history) : nullptr,
+                      c.obsH ? c.obsH + (size_t)e * (size_t)(F * c.full_history) : nullptr};
+    for (int t = 0; t < 2; ++t) {
+        double *orow = dst[t];
+        if (!orow) continue;
+        for (int i = 0; i < F * (c.full_history - 1); ++i) orow[i] = -1.0;
+        orow += F * (c.full_history - 1);
+        orow[0] = c.spawn_x; orow[1] = c.spawn_y; orow[2] = 0.0; orow[3] = 0.0;
+        orow[4] = rec[SSG_MAP_OFF_SPAWN_GOAL]; orow[5] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
+        for (int i = 0; i < c.n_beams; ++i) orow[6 + i] = -1.0;
+    }
+    return m;
+}
+
 // sin / cos of a body angle (cpvforangle).  The library's sincos is ~190 instructions of full-range machinery; body
 // angles stay within a few turns, so for |a| <= 2^18 this is a three-term Cody-Waite reduction by pi/2 with FMAs
 // (error < 2^-100 |a|) followed by the fdlibm / musl kernels on [-pi/4, pi/4] with the reduction's tail: within 1 ulp

@@ -257,9 +257,12 @@ constexpr int kTrafficTabBytes = SSG_N_TRAFFIC * 4 * 8 * 8; // config 4: per tra
 constexpr int kPoseDoubles = 7;
 constexpr int kGoalScratchBytes = 64 * SSG_MAX_GOALS * 2 + 64 * 4; // per goals wave: pair queue (u16) + consumed-goal masks
 constexpr int kTrafficScratchBytes = 64 * SSG_N_TRAFFIC * 2 + 64 * 4; // config 4, per lidar-hi wave: (lane, ship) pair queue (u16) + hit words (lidar-lo: inside its beam pair queue)
-__host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw)
+// (dyn: the config-4 instantiations — the traffic hull table, the per-env traffic words and the lidar-hi wave's (lane, ship) pair
+// queue exist only there; the 1-ship kernels do not pay ~5.4 KB of LDS for them, which is 4-5 records of a staged bank)
+__host__ __device__ __forceinline__ constexpr int lds_fixed_bytes(int epw, bool dyn)
 {
-    return kBeamTabBytes + kShipTabBytes + kTrafficTabBytes + kPoseDoubles * epw * 8 + 8 * epw * 4 + 4 * (epw / 64) * 4 + (epw / 64) * (kGoalScratchBytes + kTrafficScratchBytes);
+    return kBeamTabBytes + kShipTabBytes + (dyn ? kTrafficTabBytes : 0) + kPoseDoubles * epw * 8 + (dyn ? 8 : 6) * epw * 4 + 4 * (epw / 64) * 4 +
+           (epw / 64) * (kGoalScratchBytes + (dyn ? kTrafficScratchBytes : 0));
 }
 __host__ __device__ __forceinline__ constexpr int lds_res_bytes(int nb) { return nb * 64 * 8; } // one parity of one tile
 __host__ __device__ __forceinline__ constexpr int lds_queue_bytes(int nb0) { return (2 * nb0 * 64 + 64) * 2; }
@@ -865,18 +868,18 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     double *beamtab = reinterpret_cast<double *>(lds_fixed);
     double *shiptab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes);
     double *traffictab = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes); // [3][4][8], config 4
-    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes + kTrafficTabBytes); // [7][EPW]
+    double *pose = reinterpret_cast<double *>(lds_fixed + kBeamTabBytes + kShipTabBytes + (DYN ? kTrafficTabBytes : 0)); // [7][EPW]
     int *posem = reinterpret_cast<int *>(pose + kPoseDoubles * EPW);                         // [EPW]
     int *poser = posem + EPW;                                                                // [EPW]
     unsigned *gres = reinterpret_cast<unsigned *>(poser + EPW);                              // [2 parities][EPW]
     unsigned *gdone = gres + 2 * EPW;                                                        // [2 parities][EPW]
-    unsigned *gtraf = gdone + 2 * EPW;                                                       // [2][EPW] config 4: the player touches a traffic ship (one word per lidar role -> all; DYN launches are single steps)
-    unsigned *sync_ready = gtraf + 2 * EPW;                                                  // [EPW/64]
+    unsigned *gtraf = gdone + 2 * EPW;                                                       // [2][EPW] config 4 only: the player touches a traffic ship (one word per lidar role -> all; DYN launches are single steps)
+    unsigned *sync_ready = gtraf + (DYN ? 2 * EPW : 0);                                      // [EPW/64]
     unsigned *sync_ack = sync_ready + EPW / 64;                                              // [EPW/64]
     unsigned *sync_bar = sync_ack + EPW / 64;                                                // [EPW/64] (+ one pad word each)
     char *goal_scratch0 = reinterpret_cast<char *>(sync_bar + 2 * (EPW / 64));
     char *traffic_scratch0 = goal_scratch0 + (EPW / 64) * kGoalScratchBytes;
-    char *scratch0 = lds_fixed + lds_fixed_bytes(EPW);
+    char *scratch0 = lds_fixed + lds_fixed_bytes(EPW, DYN);
     char *tile_base = scratch0 + (tl >> 6) * lds_tile_bytes(NB); // this env tile's lidar buffers
     // gathered bank: the record heads in LDS (see lds_hdr_bytes); hL = this env's column of the lidar role's copy, hG = of the goals
     double *hdr0 = reinterpret_cast<double *>(scratch0 + (EPW / 64) * lds_tile_bytes(NB));
@@ -1717,40 +1720,7 @@ __global__ void reset_kernel(const DevCfg c, const uint8_t *__restrict__ mask, c
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n_envs) return;
     if (mask && !mask[e]) return;
-    const size_t np = (size_t)c.n_pad;
-    int m;
-    const int started = c.i32cols[ICOL_EPISODE * np + e]; // episodes this env has started so far
-    if (map_ids) m = (int)((unsigned)map_ids[e] % (unsigned)c.n_maps); // a record index never points outside the bank
-    else if (c.map_ring > 0) m = e * c.map_ring + started % c.map_ring;   // the env's next brand-new world
-    else m = (int)((c.env_id_base + (long long)e) % (long long)c.n_maps);
-    c.i32cols[ICOL_EPISODE * np + e] = started + 1;
-    const double *rec = c.bank + (size_t)m * SSG_MAP_STRIDE;
-    c.f64cols[COL_X * np + e] = c.spawn_x;
-    c.f64cols[COL_Y * np + e] = c.spawn_y;
-    c.f64cols[COL_VX * np + e] = 0.0;
-    c.f64cols[COL_VY * np + e] = 0.0;
-    c.f64cols[COL_A * np + e] = 0.0;
-    c.f64cols[COL_W * np + e] = 0.0;
-    c.f64cols[COL_CUM * np + e] = 0.0;
-    for (int i = 0; i < c.n_beams; ++i) c.f64cols[(COL_LIDAR + i) * np + e] = -1.0;
-    c.i32cols[ICOL_RUDDER * np + e] = 0;
-    c.i32cols[ICOL_STEP * np + e] = 0;
-    c.i32cols[ICOL_MAP * np + e] = m;
-    c.mask[e] = (uint8_t)((1u << c.n_goals) - 1u);
-    // deque([-1]*n), ship_env.py:180-181, then the spawn frame — into the caller's rows and, with HISTORY_SIZE > 2, into the
-    // handle's own copy of the rows (the frame-shift kernel's source: the caller's buffer is output only)
-    const int F = 6 + c.n_beams;
-    double *dst[2] = {obs ? obs + (size_t)e * (size_t)(F * c.full_history) : nullptr,
-                      c.obsH ? c.obsH + (size_t)e * (size_t)(F * c.full_history) : nullptr};
-    for (int t = 0; t < 2; ++t) {
-        double *orow = dst[t];
-        if (!orow) continue;
-        for (int i = 0; i < F * (c.full_history - 1); ++i) orow[i] = -1.0;
-        orow += F * (c.full_history - 1);
-        orow[0] = c.spawn_x; orow[1] = c.spawn_y; orow[2] = 0.0; orow[3] = 0.0;
-        orow[4] = rec[SSG_MAP_OFF_SPAWN_GOAL]; orow[5] = rec[SSG_MAP_OFF_SPAWN_GOAL + 1];
-        for (int i = 0; i < c.n_beams; ++i) orow[6 + i] = -1.0;
-    }
+    reset_env(c, e, map_ids, obs);
 }
 
 // After ssg_set_map_bank installed a SMALLER bank: stale record indices are folded into the new range.
@@ -1907,10 +1877,10 @@ static step_fn_t step_fn(int nb, int epw, bool lds, int variant)
 }
 
 // dynamic LDS: [bank (if staged)] [tables + pose exchange] [per-tile lidar result buffers and queues]
-size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps)
+size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps, bool dyn)
 {
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
-    b += (size_t)lds_fixed_bytes(epw);
+    b += (size_t)lds_fixed_bytes(epw, dyn);
     b += (size_t)(epw / 64) * (size_t)lds_tile_bytes(n_beams);
     b += (size_t)lds_hdr_bytes(epw, lds_bank);
     return b;

@@ -340,8 +340,10 @@ class ShipVecEnv(*_BASES):
 
     def wake_dynamics(self, mask=None):
         """Config 4: call after writing ANY state column through field() — the traffic / goal-body columns (envs whose
-        bodies had come to rest are otherwise not stepped) and the player's own columns (a resting env whose player was moved
-        next to a parked ship is otherwise not tested against it): ssg_dyn_invalidate.  mask: uint8 device tensor [num_envs]
+        bodies had come to rest are otherwise not stepped; the ships' rotation columns, which the step kernel's collide_ship turns
+        their hulls with, are recomputed from the angles — for every env) and the player's own columns (which envs the next full
+        cpSpaceStep visits was decided from the state the last step ended with): ssg_dyn_invalidate.  Also after restoring or
+        copying the state blob.  mask: uint8 device tensor [num_envs]
         (envs whose rest bit is cleared) or None = all; the next step's queue is rebuilt from the columns either way."""
         with _torch().cuda.device(self.device):
             mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
@@ -350,6 +352,13 @@ class ShipVecEnv(*_BASES):
     def field_stats_tensor(self):
         """int64 device tensor [4]: sum_return*100, sum_length, episodes, goals_hit of this handle (slots summed)."""
         return self.field(N.F_STATS).sum(dim=0)
+
+    def kernel_times(self, enable):
+        """Config 4 measurement aid (ssg_debug_kernel_times): returns (full cpSpaceStep us, step kernel us, steps) averaged over
+        the steps since the previous call, and switches the per-launch HIP events on or off for the calls that follow."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
+        N.check(N.lib().ssg_debug_kernel_times(self._h, int(bool(enable)), C.byref(a), C.byref(b), C.byref(n)), self._h, "ssg_debug_kernel_times")
+        return float(a.value), float(b.value), int(n.value)
 
     def dyn_counters(self):
         """Config 4: (launches of the full cpSpaceStep, how many of them rebuilt their queue from the per-env flags first)."""
@@ -435,9 +444,11 @@ class ShipVecEnv(*_BASES):
             plan = self.__dict__.setdefault("_traj_plans", {}).get(po)
             if plan is not None:
                 K = actions_kn.shape[0]
-                fn, cur_stream, pr, pd, pf, cap, shp = plan
+                fn, cur_stream, pr, pd, pf, cap, sig = plan
+                # (a hit needs the four buffers to be what was checked when the plan was made: addresses AND dtype / shape /
+                # strides / device of each — the caching allocator readily hands a freed buffer's address to another tensor)
                 if (K <= cap and out[1].data_ptr() == pr and out[2].data_ptr() == pd and out[3].data_ptr() == pf
-                        and tuple(out[0].shape) == shp and out[1].shape[0] == shp[0] and out[2].shape[0] == shp[0] and out[3].shape[0] == shp[0]):
+                        and tuple((t.dtype, tuple(t.shape), t.stride(), t.device.index) for t in out) == sig):
                     if fn(self._h, actions_kn.data_ptr(), K, po, pr, pd, pf, self.num_envs, cur_stream(self.device).cuda_stream) == 0:
                         return out[0][:K], out[1][:K], out[2][:K], out[3][:K]  # (sliced after the launch: the GPU is already busy)
                     # (an error — e.g. another device is current: the checked path below repeats the call and reports)
@@ -470,12 +481,13 @@ class ShipVecEnv(*_BASES):
                                           n, self._stream())
         if rc:
             N.check(rc, self._h, "ssg_rollout_traj")
-        plans = self.__dict__.setdefault("_traj_plans", {})
-        if len(plans) >= 8:  # (a handful of rotating buffer sets at most)
-            plans.pop(next(iter(plans)))
         if caller_out:
+            plans = self.__dict__.setdefault("_traj_plans", {})
+            if len(plans) >= 8 and to.data_ptr() not in plans:  # (a handful of rotating buffer sets at most)
+                plans.pop(next(iter(plans)))
             plans[to.data_ptr()] = (N.lib().ssg_rollout_traj, torch.cuda.current_stream, tr.data_ptr(), td.data_ptr(), tf.data_ptr(),
-                                min(int(t.shape[0]) for t in out), tuple(to.shape))
+                                    min(int(t.shape[0]) for t in out),
+                                    tuple((t.dtype, tuple(t.shape), t.stride(), t.device.index) for t in out))
         return to[:K], tr[:K], td[:K], tf[:K]
 
     def clear_traj_cache(self):

@@ -520,3 +520,29 @@ def test_config4_masked_reset_joins_the_queue(n, n_maps, memo):
     steps, rebuilds = vec.dyn_counters()
     assert steps == K and rebuilds == 1 + doubles, (steps, rebuilds, doubles)      # the first step, and the steps after a double reset
     vec.close()
+
+
+def test_config4_snapshot_restore_of_the_state_blob():
+    """The caller owns the state blob (include/shipsim.h): a copy taken between two steps and copied back later, followed by
+    ssg_dyn_invalidate (the queue of the next full cpSpaceStep lives in the blob, its live counter set is named by the handle),
+    replays the same steps bit for bit — bodies, arbiters, memo table and all."""
+    torch, O, N, ShipVecEnv = _mods()
+    n = 1536
+    vec = ShipVecEnv(n, n_beams=10, n_maps=16, n_ships=4)
+    vec.reset_tensor()
+    acts = vec.random_actions(2718, 0, 31 + 45)
+    for k in range(31):                                            # (an odd count: the queue's other counter set is the live one)
+        vec.step_tensor(acts[k])
+    snap = vec.state.clone()
+    first = [tuple(t.clone() for t in vec.step_tensor(acts[31 + k])) for k in range(45)]
+    end1 = vec.state.clone()
+    vec.state.copy_(snap)
+    vec.wake_dynamics()
+    for k in range(45):
+        o, r, d, f = vec.step_tensor(acts[31 + k])
+        assert torch.equal(o, first[k][0]) and torch.equal(r, first[k][1]) and torch.equal(d, first[k][2]) and torch.equal(f, first[k][3]), k
+    got = {fid: vec.field(fid).clone() for fid in (N.F_X, N.F_Y, N.F_ANGLE, N.F_LIDAR, N.F_STEP_COUNT, N.F_MAP_ID, N.F_GOAL_MASK, N.F_TRAFFIC, N.F_GOAL_BODIES)}
+    vec.state.copy_(end1)
+    for fid, a in got.items():
+        assert torch.equal(a, vec.field(fid)), fid
+    vec.close()
