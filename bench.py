@@ -592,10 +592,11 @@ def main():
                 other["c4_single_step_auto_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=False)
                 other["c4_host_masked_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=True)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
-                # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 48 worlds per env: launches
-                # of up to 47 fused steps between refills)
-                other["c3_fresh_world_per_episode"] = side_config(dev, 65536, 8, 1, 470, 94, map_mode="fresh_device", ring=48)
-                other["c3_fresh_world_per_episode"]["ring"] = 48
+                # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 128 worlds per env: up to 127
+                # steps between refills — a refill's time is its dependent chain whatever the item count, so a deeper ring means
+                # fewer of them per step; 9.7 GB of the 288)
+                other["c3_fresh_world_per_episode"] = side_config(dev, 65536, 8, 1, 635, 127, map_mode="fresh_device", ring=128)
+                other["c3_fresh_world_per_episode"]["ring"] = 128
                 # the headline workload with every step overwriting the same [N, ...] rows (ssg_rollout): outputs stay in cache
                 vec.reset_tensor()
                 ao = vec.random_actions(999, 0, 600)

@@ -121,8 +121,8 @@ typedef struct ssg_config {
                               (game.py:279-286): goal bodies become dynamic and Chipmunk's contact solver runs for the
                               traffic ships and goals; every step is then two launches — cpSpaceStep of the queued envs, the step
                               kernel — (no fused rollout) */
-    int32_t map_ring;      /* 0 (default): envs walk through a shared bank of worlds.  R in 2..64: EVERY EPISODE GETS A BRAND-NEW
-                              WORLD, as ShipGame.reset does (game.py:260-277: gen_level + gen_goal_path at every reset): the bank
+    int32_t map_ring;      /* 0 (default): envs walk through a shared bank of worlds.  R in 2..128: EVERY EPISODE GETS A BRAND-NEW
+                              WORLD (R up to 128; n_envs * R * SSG_MAP_STRIDE < 2^31), as ShipGame.reset does (game.py:260-277: gen_level + gen_goal_path at every reset): the bank
                               holds n_envs * R records, env e owns records [e*R, e*R + R) as a ring, episode p of env e lives
                               in record e*R + p mod R and is drawn on the device by ssg_refill_worlds from a Philox stream keyed
                               by (seed, global env id, p).  An (auto-)reset moves the env to its next record; the library

@@ -503,8 +503,11 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
     if (cfg->max_steps < 1) return fail(nullptr, SSG_ERR_BAD_ARG, "ssg_create: max_steps must be >= 1");
     if (cfg->n_ships != 0 && cfg->n_ships != 1 && cfg->n_ships != 1 + SSG_N_TRAFFIC)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_ships must be 1 or 4 (player + add_default_traffic)");
-    if (cfg->map_ring != 0 && (cfg->map_ring < 2 || cfg->map_ring > 64))
-        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring must be 0 or in 2..64");
+    if (cfg->map_ring != 0 && (cfg->map_ring < 2 || cfg->map_ring > 128))
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring must be 0 or in 2..128");
+    // (record offsets are 32-bit: record index x SSG_MAP_STRIDE doubles must stay below 2^31)
+    if (cfg->map_ring != 0 && (long long)cfg->n_envs * cfg->map_ring * SSG_MAP_STRIDE > 2147483647LL)
+        return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: n_envs * map_ring * SSG_MAP_STRIDE must be < 2^31 (use a smaller ring, or shard the envs over more handles)");
     if (cfg->map_ring != 0 && cfg->history > 2)
         return fail(nullptr, SSG_ERR_UNSUPPORTED, "ssg_create: map_ring needs history <= 2");
     if (cfg->n_ships > 1 && (cfg->flags & SSG_FLAG_EXACT_LIDAR))
@@ -639,6 +642,7 @@ int ssg_init_state(ssg_handle *h, void *stream)
 int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
 {
     if (!h || !dev_bank || n_maps < 1) return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bad argument");
+    if ((long long)n_maps * SSG_MAP_STRIDE > 2147483647LL) return fail(h, SSG_ERR_UNSUPPORTED, "ssg_set_map_bank: n_maps * SSG_MAP_STRIDE must be < 2^31");
     if (reinterpret_cast<uintptr_t>(dev_bank) % 16 != 0)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: bank must be 16-byte aligned");
     if (h->cfg.map_ring > 0 && (long long)n_maps != (long long)h->cfg.n_envs * h->cfg.map_ring)

@@ -204,3 +204,25 @@ def test_fresh_device_trajectory_rollout_equals_single_steps(native):
         assert torch.equal(o, to[k]) and torch.equal(r, tr[k]) and torch.equal(d, td[k]) and torch.equal(f, tf[k]), k
     assert torch.equal(a.field(native.F_EPISODES), b.field(native.F_EPISODES)) and torch.equal(a.bank, b.bank)
     a.close(); b.close()
+
+
+def test_fresh_device_ring_depth_does_not_change_anything(native):
+    """The world of (env, episode) is keyed by (seed, global env id, episode): a ring of 128 worlds per env (refills every 127
+    steps, launches of 100 + 27 fused steps) and a ring of 6 (refills every 5 steps) step through the same worlds — every output
+    of a 300-step trajectory rollout and the final state columns, bit for bit."""
+    import torch
+    n, K = 2048, 300
+    a = _vec(n, ring=128, map_seed=77, n_beams=8)
+    b = _vec(n, ring=6, map_seed=77, n_beams=8)
+    assert torch.equal(a.reset_tensor(), b.reset_tensor())
+    acts = a.random_actions(5, 0, K)
+    ta = a.rollout_tensor(acts, trajectory=True)
+    tb = b.rollout_tensor(acts, trajectory=True)
+    for x, y in zip(ta, tb):
+        assert torch.equal(x, y)
+    for fid in (native.F_X, native.F_Y, native.F_ANGLE, native.F_LIDAR, native.F_STEP_COUNT, native.F_GOAL_MASK, native.F_EPISODES):
+        assert torch.equal(a.field(fid), b.field(fid)), fid
+    assert int(a.field(native.F_EPISODES).max()) > 8                       # the small ring wrapped around
+    with pytest.raises(native.ShipSimError):
+        _vec(64, ring=129, map_seed=1, n_beams=8)                          # map_ring must be in 2..128
+    a.close(); b.close()
