@@ -837,6 +837,13 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             a0 = acc[0 * np]; a1 = acc[1 * np]; a2 = acc[2 * np]; a3 = acc[3 * np];
         }
     };
+    if (d.stop_after == -1) { // (development aid: the head — queue entry, row, cached arbiters — has arrived)
+        unsigned long long pk_ = 0ull;
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) pk_ += (unsigned long long)pmeta[i] + (unsigned long long)__double_as_longlong(pacc[i][0]);
+        asm volatile("" : "+v"(pk_));
+        stamp(15);
+    }
     // Did this step write back anything but the bits it read?  The body columns are compared directly: what was read stays
     // in registers until the write-back (this kernel runs one wave per SIMD, 512 VGPRs to spare; hashing both sides cost
     // ~150 64-bit multiplies per step).  The arbiters' accumulated impulses, touched for a few pairs only, go through

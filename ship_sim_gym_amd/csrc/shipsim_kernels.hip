@@ -1467,7 +1467,13 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     w = w * c.damp + tq * c.i_inv * c.dt;
     // (4) impulse solver: its output cannot reach an observation before the env is reset.
     double sa, ca;
-    { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; }
+    if constexpr (DYN) {
+        // (config 4 = single-step launches: no loop for the inlined polynomial's constants to be hoisted out of — and a CALL here
+        // makes the wave wait for the goal / flag columns it asked for after barrier 0, a memory round trip before the pose)
+        sincos_body(ang, &sa, &ca);
+    } else {
+        const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y;
+    }
 
     // cpPolyShapeCacheData: world vertices and AABB of the ship
     double sbl, sbr, sbb, sbt;

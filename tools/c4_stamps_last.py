@@ -29,6 +29,6 @@ for rep in range(6):
     i = int(np.argmax(np.where(sel, st[5], 0)))
     s = st[:, i]
     mp = int(vec.field(N.F_MAP_ID)[i]); age = int(vec.field(N.F_STEP_COUNT)[i])
-    print("launch %d: %d lanes computed; slowest lane env %d (map %d, age %d): load+pos %.0f | broadphase %.0f | memo: hash+probe %.0f verify %.0f mates' hit path %.0f | collide %.0f | ageing %.0f prestep %.0f | solver %.0f | writeback %.0f | total %.0f cycles; n_act %d gjk %d epa %d queries %d"
-          % (rep, sel.sum(), i, mp, age, s[0], s[10] - s[0], s[12] - s[10], s[13] - s[12], s[11] - s[13], s[2] - s[11], s[14] - s[2], s[3] - s[14], s[4] - s[3], s[5] - s[4], s[5], s[6], s[7], s[8], s[9]))
+    print("launch %d: %d lanes computed; slowest lane env %d (map %d, age %d): head (queue, row, arbiters) %.0f position + LDS %.0f | broadphase %.0f | memo: hash+probe %.0f verify %.0f mates' hit path %.0f | collide %.0f | ageing %.0f prestep %.0f | solver %.0f | writeback %.0f | total %.0f cycles; n_act %d gjk %d epa %d queries %d"
+          % (rep, sel.sum(), i, mp, age, s[15], s[0] - s[15], s[10] - s[0], s[12] - s[10], s[13] - s[12], s[11] - s[13], s[2] - s[11], s[14] - s[2], s[3] - s[14], s[4] - s[3], s[5] - s[4], s[5], s[6], s[7], s[8], s[9]))
 print(vec.dyn_memo_stats())
