@@ -599,17 +599,6 @@ __device__ __forceinline__ unsigned long long mixd(unsigned long long h, double 
     return mix(h, (unsigned long long)__double_as_longlong(v));
 }
 
-// Stage the hull constants ([0] the player, [1..3] the traffic ships; vertices then normals) at lds[cbase ..].
-__device__ __forceinline__ void stage_hulls(const DevCfg &c, const DynCfg &d, int cbase, int tid)
-{
-    if (tid < kHullDoubles) {
-        const int i = tid % (2 * SSG_SHIP_VERTS);
-        const bool nr = tid >= 2 * SSG_SHIP_VERTS;
-        lds[cbase + tid] = nr ? c.nrm[i] : c.hull[i];
-        for (int k = 0; k < SSG_N_TRAFFIC; ++k) lds[cbase + kHullDoubles * (1 + k) + tid] = nr ? d.tnrm[k][i] : d.thull[k][i];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // The rest bit.  cpSpaceStep is a deterministic function of the bodies' cpBody fields, the cached arbiters and
 // the static banks (the player never pushes anything: PLAYER assumption).  When a full step wrote back exactly the
@@ -708,7 +697,9 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     }
     unsigned n_map = 0;
 #pragma unroll
-    for (int j = 0; j < kDynAgeBuckets; ++j) n_map += min(ac[j], (unsigned)c.n_pad); // (clamped: garbage counters must not index past an array)
+    for (int j = 0; j < kDynAgeBuckets; ++j) n_map += min(ac[j], (unsigned)c.n_pad);
+    unsigned long long t_h1 = 0ull, t_h2 = 0ull, t_h3 = 0ull; // (development aid, SSG_DYN_STOP=-1: counters / entry / row have arrived)
+    if (d.stop_after == -1) { asm volatile("" : "+v"(n_map)); t_h1 = __builtin_amdgcn_s_memtime() - t_start; } // (clamped: garbage counters must not index past an array)
     const unsigned r_map = (n_map + (unsigned)(kGrp - 1)) / (unsigned)kGrp * (unsigned)kGrp;
     unsigned incl = r_map;
 #pragma unroll
@@ -740,7 +731,45 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         in_bucket = off - base;
     }
     if (!__any(queued)) return; // wave-uniform (only the rounding of a map's last wave)
+    // The wave's constants — the four hulls and, UNI, the two banks' planes of the wave's record (known from the counters alone) —
+    // are requested WITH the queue entry and parked in registers: staged where the env's row is awaited (hull constants, then a
+    // two-trip loop over the planes, each waiting for its own loads before its LDS write), they were three dependent round trips
+    // in front of every wave's first instruction of real work.
+    double hc[1 + SSG_N_TRAFFIC] = {0.0, 0.0, 0.0, 0.0}, plq[2] = {0.0, 0.0};
+    double bk[2][5]; // both banks' vertex counts and AABBs
+    if (lane < kHullDoubles) {
+        const int i = lane % (2 * SSG_SHIP_VERTS);
+        const bool nr = lane >= 2 * SSG_SHIP_VERTS;
+        hc[0] = nr ? c.nrm[i] : c.hull[i];
+#pragma unroll
+        for (int k = 0; k < SSG_N_TRAFFIC; ++k) hc[1 + k] = nr ? d.tnrm[k][i] : d.thull[k][i];
+    }
+    if (UNI) {
+        const double *rec_u = c.bank + (size_t)qmap * SSG_MAP_STRIDE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = lane + 64 * t;
+            if (q < 2 * kBankDoubles) {
+                const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
+                plq[t] = rec_u[SSG_MAP_OFF_PLANES + sd * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
+            }
+        }
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            bk[sd][0] = rec_u[SSG_MAP_OFF_COUNTS + sd];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bk[sd][1 + f] = rec_u[SSG_MAP_OFF_AABB + 4 * sd + f];
+        }
+    }
     const int e_q = queued ? c.dyn_bucket[(size_t)(kDynAgeBuckets * qmap + qage) * (size_t)c.n_pad + in_bucket] : 0;
+    asm volatile("" : "+v"(hc[0]), "+v"(hc[1]), "+v"(hc[2]), "+v"(hc[3]), "+v"(plq[0]), "+v"(plq[1]));
+    if (UNI) {
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int f = 0; f < 5; ++f) asm volatile("" : "+v"(bk[sd][f]));
+    }
+    if (d.stop_after == -1) { int eq_ = e_q; asm volatile("" : "+v"(eq_)); t_h2 = __builtin_amdgcn_s_memtime() - t_start; }
     queued &= (e_q >= 0) & (e_q < c.n_envs);
     const int e = queued ? e_q : 0;
     const int lane_doubles = dyn_lane_doubles(c.n_goals, UNI);
@@ -763,21 +792,23 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
         for (int i = 0; i < kDynRow / 2; ++i) { const double2 rv = row2[i]; rw[2 * i] = rv.x; rw[2 * i + 1] = rv.y; }
     }
-    stage_hulls(c, d, cbase, lane);
+    if (lane < kHullDoubles) { // the hull constants ([0] the player, [1..3] the traffic ships; vertices then normals) at lds[cbase ..]
+#pragma unroll
+        for (int k = 0; k < 1 + SSG_N_TRAFFIC; ++k) lds[cbase + kHullDoubles * k + lane] = hc[k];
+    }
     int map_id = map_col;
     if (UNI) {
         if (!__any(queued)) return;
         map_id = qmap; // (banks of at most 64 records: the wave's map bucket IS its record — known before the entries are)
-        const double *rec_u = c.bank + (size_t)map_id * SSG_MAP_STRIDE;
-        for (int q = lane; q < 2 * kBankDoubles; q += 64) {
-            const int sd = q / kBankDoubles, j = (q % kBankDoubles) / 4, f = q % 4;
-            lds[sbank + q] = rec_u[SSG_MAP_OFF_PLANES + sd * SSG_MAX_HULL * SSG_PLANE_DOUBLES + SSG_PLANE_DOUBLES * j + f];
-        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (lane + 64 * t < 2 * kBankDoubles) lds[sbank + lane + 64 * t] = plq[t];
     }
     asm volatile("" : "+v"(map_col), "+v"(gm_raw), "+v"(flag_raw), "+v"(live_raw));
 #pragma unroll
     for (int i = 0; i < kDynRow; ++i) asm volatile("" : "+v"(rw[i]));
     if (!UNI) map_id = map_col;
+    if (d.stop_after == -1) t_h3 = __builtin_amdgcn_s_memtime() - t_start;
     // an entry queued under another record than the env now sits on is stale: a masked ssg_reset moved the env after it was
     // queued (and queued it again under its new record); entries under the env's record are all equivalent
     if (UNI) queued &= (map_col & (kDynMapBuckets - 1)) == qmap;
@@ -843,6 +874,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         for (int i = 0; i < kPre; ++i) pk_ += (unsigned long long)pmeta[i] + (unsigned long long)__double_as_longlong(pacc[i][0]);
         asm volatile("" : "+v"(pk_));
         stamp(15);
+        col.f64[(size_t)(DC_ARB + 4 * 45 + 0) * np + e] = (double)t_h1; col.f64[(size_t)(DC_ARB + 4 * 45 + 1) * np + e] = (double)t_h2;
+        col.f64[(size_t)(DC_ARB + 4 * 45 + 2) * np + e] = (double)t_h3;
     }
     // Did this step write back anything but the bits it read?  The body columns are compared directly: what was read stays
     // in registers until the write-back (this kernel runs one wave per SIMD, 512 VGPRs to spare; hashing both sides cost
@@ -931,13 +964,14 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         s.cache();
         return s;
     };
-    // both banks' vertex counts and AABBs up front (one round trip); planes are staged on demand
-    double bk[2][5];
+    // both banks' vertex counts and AABBs (UNI: requested with the queue entry, above; per-lane records: one round trip here)
+    if (!UNI) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bk[s][0] = rec[SSG_MAP_OFF_COUNTS + s];
+        for (int s = 0; s < 2; ++s) {
+            bk[s][0] = rec[SSG_MAP_OFF_COUNTS + s];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) bk[s][1 + f] = rec[SSG_MAP_OFF_AABB + 4 * s + f];
+            for (int f = 0; f < 4; ++f) bk[s][1 + f] = rec[SSG_MAP_OFF_AABB + 4 * s + f];
+        }
     }
     const int bbase = (abase + A_STRIDE * kLdsArb) * kGrp + lane; // !UNI: this lane's staged bank planes; EPA's hull follows
     Mink epa_ov[2 * (kMaxEpa + 4 - kEpaLds)];
@@ -1204,32 +1238,40 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         u64 sw[SSG_N_TRAFFIC][kMemoValShipWords];
         if (memo_ok & (cand_p >= 0)) {
             u64 diff = 0ull;
-            // (header, ships and the first two arbiter slots unconditionally — slots past the env's count hold whatever an older
-            // entry left and are masked out — so that the whole comparison of the common case is one batch of loads; goals that
-            // take part and further arbiters, lane by lane)
-            key_visit([&](int i, u64 w0, u64 w1) {
-                const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + i);
-                diff |= (w.x ^ w0) | (w.y ^ w1);
-            }, 0u, 0);
+            // Header, ships and the first two arbiter slots of the key (slots past the env's count hold whatever an older entry
+            // left and are masked out), and each section in ONE batch of 16-byte loads, all issued before
+            // the first of them is looked at (the key's 21, then the value's header and ship records, 19).  (Written as a visitor that loads and compares pair by pair, the compiler issued
+            // four loads, waited, compared, issued the next four: ten dependent round trips, 10-12 k cycles of every wave.)
+            constexpr int kKb = 1 + 14 + 6, kVb = 1 + 3 * (kMemoValShipWords / 2);
+            ulonglong2 kb[kKb], vb[kVb] = {};
+            kb[0] = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY);
+#pragma unroll
+            for (int j = 0; j < 14; ++j) kb[1 + j] = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyShips + 2 * j);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) kb[15 + 3 * a + f] = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyArbs + kMemoArbWords * a + 2 * f);
+#pragma unroll
+            for (int i = 0; i < kKb; ++i) asm volatile("" : "+v"(kb[i].x), "+v"(kb[i].y));
+            diff |= (kb[0].x ^ memo_hdr) | (kb[0].y ^ live0);
+#pragma unroll
+            for (int j = 0; j < 14; ++j) diff |= (kb[1 + j].x ^ key_ship_word(2 * j)) | (kb[1 + j].y ^ key_ship_word(2 * j + 1));
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 u64 da = 0ull;
 #pragma unroll
-                for (int f = 0; f < kMemoArbWords; f += 2) {
-                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyArbs + kMemoArbWords * a + f);
-                    da |= (w.x ^ key_arb_word(a, f)) | (w.y ^ key_arb_word(a, f + 1));
-                }
+                for (int f = 0; f < 3; ++f) da |= (kb[15 + 3 * a + f].x ^ key_arb_word(a, 2 * f)) | (kb[15 + 3 * a + f].y ^ key_arb_word(a, 2 * f + 1));
                 diff |= (a < n_live) ? da : 0ull;
             }
-            if ((incl != 0u) | (n_live > 2)) {
+            if ((incl != 0u) | (n_live > 2)) { // goals that take part and further arbiters, lane by lane
 #pragma unroll
                 for (int g = 0; g < SSG_MAX_GOALS; ++g) {
                     if (!((incl >> g) & 1u)) continue;
+                    ulonglong2 gk[DC_GOAL_COLS / 2];
 #pragma unroll
-                    for (int f = 0; f < DC_GOAL_COLS; f += 2) {
-                        const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyGoals + DC_GOAL_COLS * g + f);
-                        diff |= (w.x ^ dbits(gin[g][f])) | (w.y ^ dbits(gin[g][f + 1]));
-                    }
+                    for (int f = 0; f < DC_GOAL_COLS / 2; ++f) gk[f] = *reinterpret_cast<const ulonglong2 *>(ent + ME_KEY + kMemoKeyGoals + DC_GOAL_COLS * g + 2 * f);
+#pragma unroll
+                    for (int f = 0; f < DC_GOAL_COLS / 2; ++f) diff |= (gk[f].x ^ dbits(gin[g][2 * f])) | (gk[f].y ^ dbits(gin[g][2 * f + 1]));
                 }
 #pragma unroll
                 for (int a = 2; a < kMemoArbIn; ++a) {
@@ -1241,11 +1283,21 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                     }
                 }
             }
-            vh = ld2(0);
+            // ... then, for the lanes whose key matched, the value's header and ship records: a second batch
+            if (diff == 0ull) {
+                vb[0] = ld2(0);
+#pragma unroll
+                for (int k = 0; k < SSG_N_TRAFFIC; ++k)
+#pragma unroll
+                    for (int i = 0; i < kMemoValShipWords / 2; ++i) vb[1 + (kMemoValShipWords / 2) * k + i] = ld2(kMemoValShips + kMemoValShipWords * k + 2 * i);
+#pragma unroll
+                for (int i = 0; i < kVb; ++i) asm volatile("" : "+v"(vb[i].x), "+v"(vb[i].y));
+            }
+            vh = vb[0];
 #pragma unroll
             for (int k = 0; k < SSG_N_TRAFFIC; ++k)
 #pragma unroll
-                for (int i = 0; i < kMemoValShipWords; i += 2) { const ulonglong2 w = ld2(kMemoValShips + kMemoValShipWords * k + i); sw[k][i] = w.x; sw[k][i + 1] = w.y; }
+                for (int i = 0; i < kMemoValShipWords / 2; ++i) { sw[k][2 * i] = vb[1 + (kMemoValShipWords / 2) * k + i].x; sw[k][2 * i + 1] = vb[1 + (kMemoValShipWords / 2) * k + i].y; }
             hit = diff == 0ull;
         }
         {   // statistics (how often the table answers), spread over slots, fire and forget
