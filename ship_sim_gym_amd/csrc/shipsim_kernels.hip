@@ -120,8 +120,10 @@ __device__ __forceinline__ double2 bank_at2(const DevCfg &c, int i)
 
 // Stage `bytes` (multiple of 8) from global memory into LDS at offset 0 with LDS-DMA (global_load_lds_dwordx4:
 // 1 KiB per wave-instruction, no VGPR round trip, all requests in flight at once), tail < 1 KiB through registers.
+// (The tail's 8 bytes per thread are only REQUESTED here: `tail_v` is written to LDS at `tail_o` (>= 0) by the caller right before
+// its wait in front of the barrier — written here, the wave waited for its whole DMA batch before asking for anything else.)
 template <int THREADS>
-__device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, int bytes)
+__device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, int bytes, double &tail_v, int &tail_o)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int NW = THREADS / 64;
@@ -134,7 +136,9 @@ __device__ __forceinline__ void stage_bank_lds(const double *__restrict__ bank, 
     }
     const int tail0 = nchunk << 10;
     const int o = tail0 + (int)threadIdx.x * 8;
-    if (o < bytes) *reinterpret_cast<double *>(l + o) = *reinterpret_cast<const double *>(g + o);
+    tail_o = (o < bytes) ? o : -1;
+    tail_v = 0.0;
+    if (o < bytes) tail_v = *reinterpret_cast<const double *>(g + o);
     static_assert(THREADS * 8 >= 1024, "tail copy needs one thread per 8 bytes of a 1 KiB chunk");
 }
 
@@ -899,23 +903,46 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
 #endif
     SSG_STAMP(8);
 
-    // small constant tables (written once per workgroup, read after the first barrier)
+    // The bank's LDS-DMA goes out FIRST: the table entries below are vector loads from the kernel-argument segment (indexed by
+    // the thread id) that the wave waits for before its LDS write — a memory round trip that used to sit in front of the staging
+    // of the waves that own a table (three of a workgroup's sixteen), i.e. in front of barrier 0 of every launch.
+    double bank_tail_v = 0.0;
+    int bank_tail_o = -1;
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8), bank_tail_v, bank_tail_o);
+    // small constant tables (written once per workgroup, read after the first barrier).  Their entries are vector loads from the
+    // kernel-argument segment, indexed by the thread id: they are only REQUESTED here and written to LDS by flush_tables(), which
+    // every role calls right before its wait in front of barrier 0 — written here, each cost its wave a memory round trip of its own
+    // in front of the state loads.
+    double tv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (threadIdx.x < 2 * SSG_MAX_BEAMS)
-        beamtab[threadIdx.x] = (threadIdx.x < SSG_MAX_BEAMS) ? c.beam_cos[threadIdx.x & (SSG_MAX_BEAMS - 1)]
-                                                             : c.beam_sin[threadIdx.x & (SSG_MAX_BEAMS - 1)];
+        tv[0] = (threadIdx.x < SSG_MAX_BEAMS) ? c.beam_cos[threadIdx.x & (SSG_MAX_BEAMS - 1)] : c.beam_sin[threadIdx.x & (SSG_MAX_BEAMS - 1)];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + SSG_SHIP_VERTS) {
         const int i = threadIdx.x - 64, ip = (i == 0) ? (SSG_SHIP_VERTS - 1) : (i - 1);
-        shiptab[0 * 8 + i] = c.hull[2 * i];     shiptab[1 * 8 + i] = c.hull[2 * i + 1];   // vertex i
-        shiptab[2 * 8 + i] = c.nrm[2 * i];      shiptab[3 * 8 + i] = c.nrm[2 * i + 1];    // plane normal i
-        shiptab[4 * 8 + i] = c.hull[2 * ip];    shiptab[5 * 8 + i] = c.hull[2 * ip + 1];  // vertex i-1 (edge start)
+        tv[0] = c.hull[2 * i]; tv[1] = c.hull[2 * i + 1]; tv[2] = c.nrm[2 * i]; tv[3] = c.nrm[2 * i + 1]; tv[4] = c.hull[2 * ip]; tv[5] = c.hull[2 * ip + 1];
     }
     if constexpr (DYN) {
         if (threadIdx.x >= 160 && threadIdx.x < 160 + SSG_N_TRAFFIC * SSG_SHIP_VERTS) {
             const int kk = (threadIdx.x - 160) / SSG_SHIP_VERTS, i = (threadIdx.x - 160) % SSG_SHIP_VERTS;
-            traffictab[(kk * 4 + 0) * 8 + i] = c.thull[kk][2 * i]; traffictab[(kk * 4 + 1) * 8 + i] = c.thull[kk][2 * i + 1];
-            traffictab[(kk * 4 + 2) * 8 + i] = c.tnrm[kk][2 * i];  traffictab[(kk * 4 + 3) * 8 + i] = c.tnrm[kk][2 * i + 1];
+            tv[0] = c.thull[kk][2 * i]; tv[1] = c.thull[kk][2 * i + 1]; tv[2] = c.tnrm[kk][2 * i]; tv[3] = c.tnrm[kk][2 * i + 1];
         }
     }
+    auto flush_tables = [&]() {
+        if (bank_tail_o >= 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(lds_base()) + bank_tail_o) = bank_tail_v; // the staged bank's last < 1 KiB
+        if (threadIdx.x < 2 * SSG_MAX_BEAMS) beamtab[threadIdx.x] = tv[0];
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + SSG_SHIP_VERTS) {
+            const int i = threadIdx.x - 64;
+            shiptab[0 * 8 + i] = tv[0]; shiptab[1 * 8 + i] = tv[1];   // vertex i
+            shiptab[2 * 8 + i] = tv[2]; shiptab[3 * 8 + i] = tv[3];   // plane normal i
+            shiptab[4 * 8 + i] = tv[4]; shiptab[5 * 8 + i] = tv[5];   // vertex i-1 (edge start)
+        }
+        if constexpr (DYN) {
+            if (threadIdx.x >= 160 && threadIdx.x < 160 + SSG_N_TRAFFIC * SSG_SHIP_VERTS) {
+                const int kk = (threadIdx.x - 160) / SSG_SHIP_VERTS, i = (threadIdx.x - 160) % SSG_SHIP_VERTS;
+                traffictab[(kk * 4 + 0) * 8 + i] = tv[0]; traffictab[(kk * 4 + 1) * 8 + i] = tv[1];
+                traffictab[(kk * 4 + 2) * 8 + i] = tv[2]; traffictab[(kk * 4 + 3) * 8 + i] = tv[3];
+            }
+        }
+    };
     if (threadIdx.x == 128) {
         // lidar origin of a freshly reset ship (angle 0: cpvforangle(0) = (1, 0)): pos + half the world AABB extents,
         // by the very operations ship_world() runs
@@ -929,7 +956,6 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         shiptab[1 * 8 + 6] = c.spawn_y + (bt - bb) / 2;
     }
     if (threadIdx.x >= 192 && threadIdx.x < 192 + 4 * (EPW / 64)) sync_ready[threadIdx.x - 192] = 0u; // ready, ack, bar words
-    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8));
     const bool auto_reset = (c.flags & SSG_FLAG_AUTO_RESET) != 0u;
     const int tile = tl >> 6;
     // Pose hand-over, per tile (the four waves of a tile are the only ones that exchange anything): role 3 publishes pose k
@@ -1067,6 +1093,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if constexpr (!LDS_BANK) load_hdr_lidar(map_id * SSG_MAP_STRIDE);
             { const double2 sc = sincos_call(ang); sa = sc.x; ca = sc.y; } // body->transform rotation
             if (role == 0) { pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa; } // -> role 3: the first step's thrust direction
+            flush_tables();
             if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
             __syncthreads();                             // barrier 0: bank + tables visible
             SSG_STAMP(9);
@@ -1186,6 +1213,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             if constexpr (DYN) asm volatile("" : "+v"(pv[4]), "+v"(pv[5]));
             int map0_ = map0; unsigned gm0_ = gm0;
             asm volatile("" : "+v"(map0_), "+v"(gm0_));
+            flush_tables();
             if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
             __syncthreads(); // barrier 0
             SSG_STAMP(9);
@@ -1403,6 +1431,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // loads below the barrier and the first step starts a memory round trip late)
     asm volatile("" : "+v"(x), "+v"(y), "+v"(vx), "+v"(vy), "+v"(ang), "+v"(w), "+v"(cum));
     asm volatile("" : "+v"(gm), "+v"(map_id), "+v"(rudder), "+v"(steps), "+v"(episodes), "+v"(act_next));
+    flush_tables();
     if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the LDS-DMA writes of this wave have landed
     __syncthreads();                             // barrier 0: bank + tables + role 0's initial rotation visible
     SSG_STAMP(9);
