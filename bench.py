@@ -587,8 +587,8 @@ def main():
                                                                     "(verified word for word); c4_memo_off / c4_fresh_world_per_episode "
                                                                     "are the figures without that sharing")
                 other["c4_memo_off"] = side_config(dev, 65536, 10, 4, 200, 200, dyn_memo=False, kernel_split=True)
-                other["c4_fresh_world_per_episode"] = side_config(dev, 65536, 10, 4, 60, 30, map_mode="fresh_device", ring=8)
-                other["c4_fresh_world_per_episode"]["ring"] = 8
+                other["c4_fresh_world_per_episode"] = side_config(dev, 65536, 10, 4, 62, 31, map_mode="fresh_device", ring=32)
+                other["c4_fresh_world_per_episode"]["ring"] = 32
                 other["c4_single_step_auto_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=False)
                 other["c4_host_masked_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=True)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)

@@ -619,6 +619,11 @@ int ssg_bind_state(ssg_handle *h, void *dev_state)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_bind_state: state blob must be 256-byte aligned");
     h->state = dev_state;
     h->zeroed = false;
+    // whatever memo tables the blob carries were not filled by this handle on this bank: they are zeroed before the first launch
+    // that could read them (a blob this handle filled itself — a snapshot copied back IN PLACE — keeps its entries: they are results
+    // of the same pure function)
+    memo_new_generation(h);
+    h->memo_clear_pending = true;
     refresh_dev(h);
     return SSG_OK;
 }
@@ -795,10 +800,10 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
         std::vector<hipEvent_t> evs; // measurement aid: three events per step (before the full cpSpaceStep, between, after the step kernel)
         if (dyn && h->time_kernels) {
             evs.resize(3 * (size_t)K);
-            for (auto &ev : evs) hipEventCreate(&ev);
+            for (auto &ev : evs) (void)hipEventCreate(&ev);
         }
         for (int k = 0; k < K; ++k) {
-            if (!evs.empty()) hipEventRecord(evs[3 * k], static_cast<hipStream_t>(stream));
+            if (!evs.empty()) (void)hipEventRecord(evs[3 * k], static_cast<hipStream_t>(stream));
             if (h->cfg.map_ring > 0) { // every step may start one episode per env: keep an unused world in every ring
                 if (h->ring_credit < 1) {
                     rc = ring_refill(h, nullptr, stream);
@@ -828,11 +833,11 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                     return fail(h, SSG_ERR_HIP, std::string("dyn step launch: ") + hipGetErrorString(e));
                 }
             }
-            if (!evs.empty()) hipEventRecord(evs[3 * k + 1], static_cast<hipStream_t>(stream));
+            if (!evs.empty()) (void)hipEventRecord(evs[3 * k + 1], static_cast<hipStream_t>(stream));
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, 1,
                                             shift ? h->dev.obs2 : obs_at(k), rew_at(k), done_at(k), flags_at(k), 0,
                                             static_cast<hipStream_t>(stream));
-            if (!evs.empty()) hipEventRecord(evs[3 * k + 2], static_cast<hipStream_t>(stream));
+            if (!evs.empty()) (void)hipEventRecord(evs[3 * k + 2], static_cast<hipStream_t>(stream));
             if (e == hipSuccess && shift) e = ssg::launch_history_shift(h->dev, done_at(k), obs_at(k), static_cast<hipStream_t>(stream));
             if (e != hipSuccess) {
                 h->dyn_queue_valid = false; // (the next call rebuilds the dyn queue from the flags, counters zeroed)
@@ -845,14 +850,14 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
             }
         }
         if (!evs.empty()) { // (this call then waits for its own work: a measurement run, not the product path)
-            hipStreamSynchronize(static_cast<hipStream_t>(stream));
+            (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
             for (int k = 0; k < K; ++k) {
                 float a = 0.f, b = 0.f;
-                hipEventElapsedTime(&a, evs[3 * k], evs[3 * k + 1]);
-                hipEventElapsedTime(&b, evs[3 * k + 1], evs[3 * k + 2]);
+                (void)hipEventElapsedTime(&a, evs[3 * k], evs[3 * k + 1]);
+                (void)hipEventElapsedTime(&b, evs[3 * k + 1], evs[3 * k + 2]);
                 h->t_dyn_ms += a; h->t_step_ms += b; h->t_steps++;
             }
-            for (auto &ev : evs) hipEventDestroy(ev);
+            for (auto &ev : evs) (void)hipEventDestroy(ev);
         }
         return SSG_OK;
     }

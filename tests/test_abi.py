@@ -190,3 +190,37 @@ def test_every_entry_point_cites_what_it_replaces():
             missing.append(name)
         prev = pos
     assert not missing, missing
+
+
+def test_create_limits_and_config4_blob_layout(native):
+    """Host-side contract of the round-5 additions, no GPU needed: `map_ring` up to 128 with the 32-bit record-offset guard, and the
+    config-4 state blob carrying the memo tables (SSG_F_DYN_MEMO_STATS is where ssg_state_field says, after the queue)."""
+    L = native.lib()
+
+    def create(**kw):
+        c = native.default_config()
+        for k, v in kw.items():
+            setattr(c, k, v)
+        h = C.c_void_p()
+        rc = L.ssg_create(C.byref(c), C.byref(h))
+        return rc, h
+
+    rc, h = create(n_envs=4096, map_ring=128, flags=native.FLAG_AUTO_RESET)
+    assert rc == 0
+    L.ssg_destroy(h)
+    assert create(n_envs=4096, map_ring=129)[0] < 0                          # map_ring must be in 2..128
+    assert create(n_envs=200000, map_ring=128)[0] < 0                        # 200 000 * 128 * 145 doubles: offsets would not fit 32 bits
+    assert b"2^31" in L.ssg_last_error(None)
+    rc, h1 = create(n_envs=1024, n_ships=1)
+    rc4, h4 = create(n_envs=1024, n_ships=4)
+    assert rc == 0 and rc4 == 0
+    n1, n4 = C.c_size_t(), C.c_size_t()
+    L.ssg_state_nbytes(h1, C.byref(n1)); L.ssg_state_nbytes(h4, C.byref(n4))
+    assert n4.value - n1.value > 30 << 20                                    # the memo tables (~35 MB) live in the caller's blob
+    off, es, nc, st = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t()
+    assert L.ssg_state_field(h4, native.F_DYN_MEMO_STATS, C.byref(off), C.byref(es), C.byref(nc), C.byref(st)) == 0
+    assert es.value == 8 and nc.value == 256 * 16 and off.value % 256 == 0 and off.value + 8 * nc.value < n4.value
+    assert L.ssg_state_field(h1, native.F_DYN_MEMO_STATS, C.byref(off), C.byref(es), C.byref(nc), C.byref(st)) < 0   # 1-ship handles have none
+    a, b = C.c_uint64(7), C.c_uint64(7)
+    assert L.ssg_debug_dyn_counters(h4, C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (0, 0)
+    L.ssg_destroy(h1); L.ssg_destroy(h4)
