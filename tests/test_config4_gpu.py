@@ -546,3 +546,31 @@ def test_config4_snapshot_restore_of_the_state_blob():
     for fid, a in got.items():
         assert torch.equal(a, vec.field(fid)), fid
     vec.close()
+
+
+def test_config4_memo_generations_wrap_around():
+    """Every bank change starts a new GENERATION of the memo tables (entries of the old bank count as empty, no memset); the
+    generation counter has 255 values and a wrap zeroes the tables.  Re-installing the bank 300 times — past the wrap — with steps in
+    between leaves memo on and memo off bit for bit equal, and both equal to a handle that never re-installed anything (the
+    bank's contents did not change: only rest bits and table generations did)."""
+    torch, O, N, ShipVecEnv = _mods()
+    n = 384
+    a = ShipVecEnv(n, n_beams=8, n_maps=4, n_ships=4)
+    b = ShipVecEnv(n, n_beams=8, n_maps=4, n_ships=4, dyn_memo=False)
+    c = ShipVecEnv(n, n_beams=8, n_maps=4, n_ships=4)
+    for v in (a, b, c):
+        v.reset_tensor()
+    acts = a.random_actions(17, 0, 300)
+    for k in range(300):
+        a.set_bank(a.bank); b.set_bank(b.bank)
+        oa, ra, da, fa = a.step_tensor(acts[k])
+        ob_, rb, db, fb = b.step_tensor(acts[k])
+        oc, rc, dc, fc = c.step_tensor(acts[k])
+        assert torch.equal(oa, ob_) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(fa, fb), k
+        assert torch.equal(oa, oc) and torch.equal(da, dc), k
+    for fid in (N.F_TRAFFIC, N.F_GOAL_BODIES, N.F_X, N.F_GOAL_MASK):
+        assert torch.equal(a.field(fid), b.field(fid)) and torch.equal(a.field(fid), c.field(fid)), fid
+    sa, sc = a.dyn_memo_stats(), c.dyn_memo_stats()
+    assert sc["hits"] > sc["computed"] and sa["stored"] > 250          # every generation starts empty and learns again
+    for v in (a, b, c):
+        v.close()
