@@ -415,12 +415,17 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
                 outside = need_exact ? o : outside;
             }
             const int q = pb + SSG_PLANE_DOUBLES * bj;
-            const double nx = bank_at<LDS_BANK>(c, q + 2), ny = bank_at<LDS_BANK>(c, q + 3);
             // the entry edge's extent: cpvcross(n, v[bj-1]) .. cpvcross(n, v[bj])
             const int jp = (bj == 0) ? cnt - 1 : bj - 1;
             const int qp = pb + SSG_PLANE_DOUBLES * ((jp >= 0 && jp < SSG_MAX_HULL) ? jp : 0);
-            const double dtmin = nx * bank_at<LDS_BANK>(c, qp + 1) - ny * bank_at<LDS_BANK>(c, qp + 0);
-            const double dtmax = nx * bank_at<LDS_BANK>(c, q + 1) - ny * bank_at<LDS_BANK>(c, q + 0);
+            // the entry plane's normal and the two vertices of its edge: three 16-byte requests in ONE batch (six 8-byte loads in
+            // program order between the products were compiled into three dependent round trips per pass — on a gathered bank each
+            // is a trip to L2 / HBM on the lidar wave's chain)
+            double2 nn = bank_at2<LDS_BANK>(c, q + 2), vj = bank_at2<LDS_BANK>(c, q + 0), vp = bank_at2<LDS_BANK>(c, qp + 0);
+            if constexpr (!LDS_BANK) asm volatile("" : "+v"(nn.x), "+v"(nn.y), "+v"(vj.x), "+v"(vj.y), "+v"(vp.x), "+v"(vp.y));
+            const double nx = nn.x, ny = nn.y;
+            const double dtmin = nx * vp.y - ny * vp.x;
+            const double dtmax = nx * vj.y - ny * vj.x;
             const double t = bd / bden;
             const double omt = 1.0 - t;
             ptx = wcx * omt + ex * t;
@@ -734,13 +739,14 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
                 }
             }
         } else {
-            // the record is gathered from L2 / HBM: four planes per trip (one dependent round trip instead of four); which plane
+            // the record is gathered from L2 / HBM: four planes per trip (one dependent round trip instead of four; eight per trip spill registers at 256 envs per workgroup); which plane
             // separates does not matter, only whether one does
-            for (int j0 = 0; __any(near_s & !sep & (j0 < cnt)); j0 += 4) {
+            constexpr int kNpChunk = 4;
+            for (int j0 = 0; __any(near_s & !sep & (j0 < cnt)); j0 += kNpChunk) {
                 if (near_s & !sep & (j0 < cnt)) {
-                    double nx[4], ny[4], v0n[4];
+                    double nx[kNpChunk], ny[kNpChunk], v0n[kNpChunk];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kNpChunk; ++u) {
                         const int j = (j0 + u < SSG_MAX_HULL) ? j0 + u : 0;
                         const int q = rec_off + SSG_MAP_OFF_PLANES + s * (SSG_MAX_HULL * SSG_PLANE_DOUBLES) + SSG_PLANE_DOUBLES * j;
                         const double2 nn = bank_at2<LDS_BANK>(c, q + 2);
@@ -748,7 +754,7 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
                         v0n[u] = bank_at<LDS_BANK>(c, q + 4);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kNpChunk; ++u) {
                         bool allfront = j0 + u < cnt;
 #pragma unroll
                         for (int i = 0; i < SSG_SHIP_VERTS; ++i) allfront = allfront & ((nx[u] * swx[i] + ny[u] * swy[i]) > v0n[u]);
