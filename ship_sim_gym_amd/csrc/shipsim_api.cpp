@@ -351,9 +351,8 @@ void refresh_dev(ssg_handle *h)
     d.dyn_qmap = dyn ? reinterpret_cast<int32_t *>(base + h->off_dyn_qmap) : nullptr;
     d.dyn_par = 0; // (the queue is rebuilt from the flags after every refresh: dyn_queue_valid = false below)
     d.dyn_row = dyn ? reinterpret_cast<double *>(base + h->off_dyn_row) : nullptr;
-    // the memo: shared bank records are what makes states repeat (not per-env worlds, not banks the queue's 64 map buckets cannot
-    // tell apart — the dyn_step_kernel<true, ...> condition of launch_dyn_step)
-    const bool memo = dyn && !(c.flags & SSG_FLAG_DYN_MEMO_OFF) && c.map_ring == 0 && h->n_maps > 0 && h->n_maps <= ssg::kDynMapBuckets;
+    // the memo: shared bank records are what makes states repeat (not per-env worlds; the key holds 16 bits of record index)
+    const bool memo = dyn && !(c.flags & SSG_FLAG_DYN_MEMO_OFF) && c.map_ring == 0 && h->n_maps > 0 && h->n_maps <= 65536;
     d.dyn_memo = memo ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_memo) : nullptr;
     d.dyn_memo_stats = dyn ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_memo_stats) : nullptr;
     d.dyn_npm = memo ? reinterpret_cast<unsigned long long *>(base + h->off_dyn_npm) : nullptr;

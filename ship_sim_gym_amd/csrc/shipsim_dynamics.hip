@@ -53,7 +53,12 @@ extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-unif
 // whatever its width).  Measured at 65 536 envs, planes once per wave: 48 (76 KB of LDS, two waves per CU) -> 62.5 us in
 // steady state and 135 us with every env queued; 32 (51 KB, three per CU) -> 63.9 / 132; 64 with per-lane planes (158 KB,
 // one per CU; round 2 and the first half of round 3) -> 60.9 / 165, and 100 whenever the queue outgrew 16 384 envs.
+// (SSG_DYN_NONUNI_TU: this file compiled a second time for the per-lane-planes variant alone, with 32 envs per wave — see the end)
+#ifdef SSG_DYN_NONUNI_TU
+constexpr int kGrp = 32;
+#else
 constexpr int kGrp = kDynGrp;
+#endif
 static_assert(kGrp == 32 || kGrp == 48 || kGrp == 64, "lds[field * kGrp + lane]: at 32 / 64 a lane keeps its LDS banks whatever the field; 48 pays an occasional 2-way conflict on the solver's per-lane body slots");
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
@@ -503,7 +508,7 @@ struct DynCols {
 };
 
 // (re)create the non-player bodies of one env: a fresh pm.Space() after ShipGame.reset + add_default_traffic
-__device__ void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, int e, const double *rec)
+__device__ __attribute__((unused)) void dyn_init(const DevCfg &c, const DynCfg &d, const DynCols &col, int e, const double *rec)
 {
     double *row = c.dyn_row + (size_t)e * kDynRow; // the row-major shadow the full step loads from
     for (int k = 0; k < SSG_N_TRAFFIC; ++k) {
@@ -556,6 +561,7 @@ struct ArbLds {
 
 } // namespace
 
+#ifndef SSG_DYN_NONUNI_TU
 // append: the queue of the next full step is valid (the step kernel produced it) and stays so — the envs reset here join it
 // (masked ssg_reset between two steps: the RLlib flow resets its done envs this way after every step, ship_env.py:171-184 per env).
 // (One launch does the whole reset of a config-4 env: the player's columns and observation rows — reset_env, what reset_kernel runs
@@ -588,6 +594,8 @@ __global__ void dyn_reset_kernel(const DevCfg c, const DynCfg d, const uint8_t *
     }
 }
 
+#endif // !SSG_DYN_NONUNI_TU
+
 // 64-bit mixing for the "did this step change anything" test of the full step (inputs vs outputs, no re-reads).
 __device__ __forceinline__ unsigned long long mix(unsigned long long h, unsigned long long v)
 {
@@ -611,7 +619,7 @@ __device__ __forceinline__ unsigned long long mixd(unsigned long long h, double 
 // Everything else is appended to the queue of the full step.  In steady state that is the few steps after each reset in
 // which ship 1 is pushed out of the left bank, plus whatever the player's goals or a caller stirred up.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kClassifyThreads = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
+constexpr int kClassifyThreads __attribute__((unused)) = 256; // 256 workgroups at 65 536 envs: one per CU (1024-thread workgroups left 192 of the 256 CUs idle)
 
 // Which goals' cached arbiters leave with the goals the player has reached (deferred space.remove, game.py:252).
 __device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigned long long live, unsigned gmask, int ng)
@@ -626,6 +634,7 @@ __device__ __forceinline__ unsigned long long drop_removed_goal_arbiters(unsigne
     return live;
 }
 
+#ifndef SSG_DYN_NONUNI_TU
 // In steady state the step kernel's body role classifies every env for the NEXT step at the end of each step (it holds the
 // player's state in registers: shipsim_kernels.hip, role 3) and this kernel does not run.  It runs when the host touched the
 // envs in between — ssg_reset, a new bank, ssg_dyn_invalidate, a fresh handle — and rebuilds the queue from the per-env flags.
@@ -665,6 +674,8 @@ __global__ __launch_bounds__(kClassifyThreads) void dyn_classify_kernel(const De
         c.dyn_bucket[(size_t)bucket * (size_t)c.n_pad + arrival] = e;
     }
 }
+
+#endif // !SSG_DYN_NONUNI_TU
 
 // ---------------------------------------------------------------------------------------------------------
 // dyn_step_kernel: the full cpSpaceStep of the queued envs, one lane per env, one wave per workgroup.
@@ -1195,8 +1206,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
         const int n_live = __popcll(live0);
         memo_n_live = n_live;
         const bool memo_ok = n_live <= kMemoArbIn; // (the first kMemoArbIn cached arbiters are the ones held in ppid / pacc)
-        memo_hdr = (u64)(unsigned)map_id | ((u64)incl << 8) | ((u64)(unsigned)n_live << 16) | ((u64)(d.memo_fp & 0xFFFFu) << 24) |
-                   ((u64)(d.bank_epoch & 0xFFFFFFu) << 40);
+        memo_hdr = (u64)((unsigned)map_id & 0xFFFFu) | ((u64)incl << 16) | ((u64)(unsigned)n_live << 24) | ((u64)(d.memo_fp & 0xFFFFu) << 32) |
+                   ((u64)(d.bank_epoch & 0xFFFFu) << 48); // (banks of up to 65 536 records: launch_dyn_step)
         // tag: two rotate-xor lanes over the key, one final mix (the key itself is compared on a hit: the tag only has to spread)
         u64 h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
         key_visit([&](int, u64 w0, u64 w1) {
@@ -1435,8 +1446,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                     u64 np_hdr = 0ull;
                     const u64 gen_np = (u64)(c.dyn_memo_gen & 0xFFu);
                     if constexpr (MEMO) {
-                        np_hdr = (u64)(unsigned)map_id | ((u64)(unsigned)r << 8) | ((u64)(unsigned)k << 12) | ((u64)(d.memo_fp & 0xFFFFu) << 16) |
-                                 ((u64)(d.bank_epoch & 0xFFFFFFu) << 32);
+                        np_hdr = (u64)((unsigned)map_id & 0xFFFFu) | ((u64)(unsigned)r << 16) | ((u64)(unsigned)k << 20) | ((u64)(d.memo_fp & 0xFFFFu) << 24) |
+                                 ((u64)(d.bank_epoch & 0xFFFFFFu) << 40);
                         u64 h0 = np_hdr ^ 0x452821E638D01377ull, h1 = 0xBE5466CF34E90C6Cull;
                         h0 = ((h0 << 7) | (h0 >> 57)) ^ dbits(sk.p.x); h1 = ((h1 << 11) | (h1 >> 53)) ^ dbits(sk.p.y);
                         h0 = ((h0 << 7) | (h0 >> 57)) ^ dbits(sk.ca);  h1 = ((h1 << 11) | (h1 >> 53)) ^ dbits(sk.sa);
@@ -1895,22 +1906,47 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     col.flag[e] = (uint8_t)(changed ? 0u : 4u); // unchanged = a fixed point of cpSpaceStep: at rest
 }
 
-size_t dyn_lds_bytes(int n_goals, bool uni)
+static size_t dyn_lds_bytes(int n_goals, bool uni) // (per translation unit: its kGrp)
 {
     return ((size_t)dyn_lane_doubles(n_goals, uni) * kGrp + (size_t)kHullDoubles * (1 + SSG_N_TRAFFIC) + (uni ? 2 * kBankDoubles : 0)) * sizeof(double);
 }
 
+#ifdef SSG_DYN_NONUNI_TU
+// The per-lane-planes variant (banks of more than 64 records, per-env rings of worlds: nothing tells a wave which record its lanes
+// sit on, so every lane stages its own two hulls: 283 doubles of LDS per lane).  Compiled in a translation unit of its own with 32
+// envs per wave: 72 KB per wave, two waves per CU, 16 384 envs resident at once — at 48 (108 KB, one wave per CU, 12 288 envs) the
+// ~16 k queued envs of a steady-state step needed two rounds.
+hipError_t prepare_dyn_nonuni(const DevCfg &c)
+{
+    if (dyn_lds_bytes(c.n_goals, false) > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_dyn_step_nonuni(const DevCfg &c, const DynCfg &dd, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((c.n_pad + kDynMapBuckets * kGrp) / kGrp));
+    // (a SHARED bank of more than 64 records: the waves no longer sit on one record each, but the envs still replay each other's
+    // states — the memo, keyed by the record, answers them just the same; per-env rings of worlds: nothing repeats, no memo)
+    if (c.dyn_memo) hipLaunchKernelGGL((dyn_step_kernel<false, true>), grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+    else hipLaunchKernelGGL((dyn_step_kernel<false, false>), grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+    return hipGetLastError();
+}
+#else
+hipError_t prepare_dyn_nonuni(const DevCfg &c);
+hipError_t launch_dyn_step_nonuni(const DevCfg &c, const DynCfg &dd, hipStream_t stream);
+
 // Raise the dynamic-LDS cap of the full-step kernel (once per handle, like prepare_step).
 hipError_t prepare_dyn(const DevCfg &c)
 {
-    if (dyn_lds_bytes(c.n_goals, false) > 160u * 1024u) return hipErrorInvalidValue;
+    if (dyn_lds_bytes(c.n_goals, true) > 160u * 1024u) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(dyn_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024);
+    return prepare_dyn_nonuni(c);
 }
 
 hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipStream_t stream)
@@ -1930,7 +1966,7 @@ hipError_t launch_dyn_step(const DevCfg &c, const DynCfg &d, bool classify, hipS
     const dim3 grid((unsigned)((c.n_pad + kDynPad) / kGrp));
     if (uni && c.dyn_memo) hipLaunchKernelGGL((dyn_step_kernel<true, true>), grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
     else if (uni) hipLaunchKernelGGL((dyn_step_kernel<true, false>), grid, dim3(64), dyn_lds_bytes(c.n_goals, true), stream, c, dd);
-    else hipLaunchKernelGGL((dyn_step_kernel<false, false>), grid, dim3(64), dyn_lds_bytes(c.n_goals, false), stream, c, dd);
+    else return launch_dyn_step_nonuni(c, dd, stream); // (its own translation unit: 32 envs per wave)
     return hipGetLastError();
 }
 
@@ -1969,4 +2005,5 @@ hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mas
     return hipGetLastError();
 }
 
+#endif // SSG_DYN_NONUNI_TU
 } // namespace ssg

@@ -435,7 +435,7 @@ def test_config4_goal_override_moves_the_goal_bodies():
     e.close()
 
 
-@pytest.mark.parametrize("n,n_maps,K", [(4096, 64, 140), (1000, 3, 90)])
+@pytest.mark.parametrize("n,n_maps,K", [(4096, 64, 140), (1000, 3, 90), (3000, 96, 110)])  # (96 records: the per-lane-planes variant of the full step, memo on)
 def test_config4_memo_is_invisible(n, n_maps, K):
     """The memo of the full cpSpaceStep (SSG_F_DYN_MEMO_STATS: envs that share a bank record replay the same body states, so
     a state's step is computed once and looked up afterwards) must change NOTHING: every output of every step, and every body /
