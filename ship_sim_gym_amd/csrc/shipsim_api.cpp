@@ -652,24 +652,29 @@ int ssg_set_map_bank(ssg_handle *h, const double *dev_bank, int n_maps)
     if (h->cfg.map_ring > 0 && (long long)n_maps != (long long)h->cfg.n_envs * h->cfg.map_ring)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_set_map_bank: map_ring mode needs n_maps == n_envs * map_ring");
     if (h->cfg.map_ring > 0) h->ring_ready = false; // a new bank: its rings are empty until ssg_refill_worlds
-    // Envs per workgroup: start from the size preferred for this env count and halve it until the staged bank fits
-    // the CU's LDS beside the lidar scratch; if even 64 does not fit, gather records from L2/HBM instead.
-    h->block = pick_block(h->cfg.n_envs);
-    if (!(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL))
-        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps, h->cfg.n_ships > 1) > 160u * 1024u) h->block /= 2;
-    if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64; // the config-4 step kernel is built for 64 and 256
+    // Envs per workgroup, and whether the bank is staged in the CU's LDS or gathered from L2 / HBM.  Staged: the largest size, from
+    // the one preferred for this env count down, at which the bank fits the LDS beside the lidar buffers.  Gathered: the largest
+    // size at which the record heads fit.  A staged bank wins at EQUAL workgroup size (65 536 envs, 10 beams, 64 records: 6.45
+    // against 7.2 us per step), but a workgroup smaller than the preferred one means more workgroups than the chip holds at once
+    // — they own their CU's LDS — i.e. launches of several rounds: 65 536 envs x 8 beams on 120 records took 16.1 us per step
+    // staged on 64-env workgroups (four rounds) against 6.4 gathered on 256-env ones; 100 records, 128-env workgroups: 8.6
+    // against 6.5.  (Round 5; before, the gathered path was only taken when nothing could be staged, and then on 64-env
+    // workgroups, whose instantiation holds 134 VGPRs = three per CU: two rounds again.)
+    const bool dyn_cfg = h->cfg.n_ships > 1;
+    auto fix_dyn = [&](int b) { return (dyn_cfg && b == 128) ? 64 : b; }; // the config-4 step kernel is built for 64 and 256
+    const int preferred = fix_dyn(pick_block(h->cfg.n_envs));
+    int staged_block = preferred, gathered_block = preferred;
+    while (staged_block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, staged_block, true, n_maps, dyn_cfg) > 160u * 1024u) staged_block = fix_dyn(staged_block / 2);
+    while (gathered_block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, gathered_block, false, n_maps, dyn_cfg) > 160u * 1024u) gathered_block = fix_dyn(gathered_block / 2);
+    const bool can_stage = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
+                           ssg::step_lds_bytes(h->cfg.n_beams, staged_block, true, n_maps, dyn_cfg) <= 160u * 1024u;
     if (h->bank && n_maps < h->n_maps) h->remap_pending = true; // stale record indices >= n_maps must not survive
     h->bank = dev_bank;
     h->n_maps = n_maps;
     h->dyn.bank_epoch++; // resting traffic must be re-collided against the new banks
     memo_new_generation(h);
-    // 160 KiB of LDS per CU on gfx950: stage the bank when it fits beside the per-wave lidar scratch
-    h->lds = !(h->cfg.flags & SSG_FLAG_BANK_IN_GLOBAL) &&
-             ssg::step_lds_bytes(h->cfg.n_beams, h->block, true, n_maps, h->cfg.n_ships > 1) <= 160u * 1024u;
-    if (!h->lds) { // gathered bank: the record heads live in LDS columns beside the lidar buffers — they must fit too
-        while (h->block > 64 && ssg::step_lds_bytes(h->cfg.n_beams, h->block, false, n_maps, h->cfg.n_ships > 1) > 160u * 1024u) h->block /= 2;
-        if (h->cfg.n_ships > 1 && h->block == 128) h->block = 64;
-    }
+    h->lds = can_stage && (staged_block == preferred || gathered_block <= staged_block);
+    h->block = h->lds ? staged_block : gathered_block;
     h->lds_bytes = ssg::step_lds_bytes(h->cfg.n_beams, h->block, h->lds, n_maps, h->cfg.n_ships > 1);
     h->prepared = false;
     refresh_dev(h);

@@ -827,22 +827,25 @@ def test_abi_garbage_blob_and_shrinking_bank(torch_cuda, native, n_ships):
 
 
 def test_lds_fit_fallbacks_are_exercised_and_exact(torch_cuda, oracle, native):
-    """ssg_set_map_bank halves the envs per workgroup until the staged bank fits the CU's LDS beside the lidar buffers, and
-    gathers the bank from L2 when even 64 do not fit: every one of those layouts must step exactly like the others."""
+    """ssg_set_map_bank stages the bank in the CU's LDS at the workgroup size preferred for the env count when it fits there;
+    when it only fits a smaller workgroup it weighs that against gathering the bank from L2 on a larger one (a smaller
+    workgroup = more workgroups than the chip holds at once = launches of several rounds), and gathers when nothing fits:
+    every one of those layouts must step exactly like the others."""
     torch = torch_cuda
     seen = set()
     for n, nb, n_maps, want in ((65536, 8, 64, (256, True)), (65536, 10, 64, (256, True)), (65536, 16, 64, (128, True)),
-                                (65536, 16, 100, (64, True)), (65536, 16, 140, (64, False)), (20000, 10, 64, (128, True)),
-                                (4096, 10, 64, (64, True))):
+                                (65536, 16, 100, (128, False)), (65536, 16, 140, (128, False)), (65536, 10, 140, (256, False)),
+                                (65536, 8, 100, (256, False)), (20000, 10, 64, (128, True)), (20000, 16, 100, (128, False)),
+                                (4096, 10, 64, (64, True)), (4096, 16, 100, (64, True)), (4096, 10, 200, (64, False))):
         v = _vec(n, n_beams=nb, n_maps=n_maps)
         epw, lds, nbytes = v.launch_geometry()
         assert (epw, lds) == want and nbytes <= 160 * 1024, (n, nb, n_maps, epw, lds, nbytes)
         seen.add((epw, lds))
         v.close()
-    assert seen == {(256, True), (128, True), (64, True), (64, False)}
+    assert seen == {(256, True), (128, True), (64, True), (64, False), (128, False), (256, False)}
     # exactness of each layout at a size the oracle handles: same n_beams / n_maps, fewer envs, geometry forced by SSG_BLOCK
     import os
-    for nb, n_maps, blk in ((16, 64, "128"), (16, 100, "64"), (16, 140, "64"), (10, 64, "256")):
+    for nb, n_maps, blk in ((16, 64, "128"), (16, 100, "64"), (16, 140, "64"), (16, 140, "128"), (10, 140, "256"), (10, 64, "256")):
         os.environ["SSG_BLOCK"] = blk
         try:
             v = _vec(1500, n_beams=nb, n_maps=n_maps)

@@ -1,0 +1,2 @@
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ship_sim_gym_amd.vec_env import ShipVecEnv
-R = int(os.environ.get("R", "32")); K = int(os.environ.get("K", "620"))
+R = int(os.environ.get("R", "32")); K = int(os.environ.get("K", "620"))  # (R=128 K=635: the bench form)
 vec = ShipVecEnv(int(os.environ.get("N", "65536")), n_beams=8, map_mode="fresh_device", ring=R)
 acts = vec.random_actions(12345, 0, K + 62)
 vec.reset_tensor(); vec.rollout_tensor(acts[:62]); torch.cuda.synchronize()
