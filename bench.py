@@ -191,10 +191,10 @@ def event_time_rollout(vec, acts, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_memo=True, kernel_split=False):
+def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_memo=True, kernel_split=False, n_maps=N_MAPS):
     """Informational timing of another BASELINE config on this GPU (outside the headline's timed region)."""
     from ship_sim_gym_amd.vec_env import ShipVecEnv
-    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, n_ships=n_ships, ring=ring,
+    vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=n_maps, map_seed=1000, n_beams=n_beams, n_ships=n_ships, ring=ring,
                      dyn_memo=dyn_memo)
     acts = vec.random_actions(12345, 0, K + W)
     vec.reset_tensor()
@@ -205,6 +205,8 @@ def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_me
     sps = n * K / (ms * 1e-3)
     out = {"envs": n, "outputs": "trajectory [K,N,...]", "n_beams": n_beams, "n_ships": n_ships, "map_mode": map_mode, "steps": K, "us_per_step": us, "env_steps_per_s": sps,
            "algorithmic_bytes_per_env_step": B, "achieved_GBps": sps * B / 1e9, "frac": sps * B / 1e9 / HBM_PEAK_GBPS}
+    epw, in_lds, lds_bytes = vec.launch_geometry()
+    out["launch"] = {"envs_per_workgroup": epw, "bank_in_lds": bool(in_lds), "lds_bytes": lds_bytes}
     if n_ships > 1:
         out["dyn_memo"] = bool(dyn_memo and map_mode == "bank")
         if out["dyn_memo"]:
@@ -592,9 +594,12 @@ def main():
                 other["c4_single_step_auto_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=False)
                 other["c4_host_masked_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=True)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
+                # the headline's envs on a bank of 120 records, which the LDS only holds beside 64-env workgroups (four rounds per
+                # launch): gathered from L2 on 256-env workgroups instead (ssg_set_map_bank weighs the two)
+                other["c3_bank_of_120_records"] = side_config(dev, 65536, 8, 1, 500, 100, n_maps=120)
                 # a brand-new world per episode, drawn on the device (map_mode="fresh_device", ring of 128 worlds per env: up to 127
-                # steps between refills — a refill's time is its dependent chain whatever the item count, so a deeper ring means
-                # fewer of them per step; 9.7 GB of the 288)
+                # steps between refills; 9.7 GB of the 288).  The world generator is throughput-bound — ~1 630 new worlds per step at
+                # ~780 wave-instructions each — so its share (~2.2 us per step) does not depend on the ring
                 other["c3_fresh_world_per_episode"] = side_config(dev, 65536, 8, 1, 635, 127, map_mode="fresh_device", ring=128)
                 other["c3_fresh_world_per_episode"]["ring"] = 128
                 # the headline workload with every step overwriting the same [N, ...] rows (ssg_rollout): outputs stay in cache

@@ -318,9 +318,10 @@ int ssg_debug_kernel_times(ssg_handle *h, int enable, double *dyn_step_us, doubl
  * join the queue the step kernel left). */
 int ssg_debug_dyn_counters(const ssg_handle *h, uint64_t *full_steps, uint64_t *queue_rebuilds);
 
-/* Inspection aid (no reference counterpart): how ssg_set_map_bank laid the step kernel out for this handle — envs per workgroup (256, 128 or 64: halved
- * until the staged bank fits the CU's 160 KiB of LDS beside the exchange and lidar buffers), whether the bank is staged in LDS
- * (0 = gathered from L2 / HBM) and the dynamic LDS bytes per workgroup. */
+/* Inspection aid (no reference counterpart): how ssg_set_map_bank laid the step kernel out for this handle — envs per workgroup (256, 128 or 64),
+ * whether the bank is staged in LDS (0 = gathered from L2 / HBM) and the dynamic LDS bytes per workgroup.  The bank is staged when it
+ * fits the CU's 160 KiB of LDS beside the exchange and lidar buffers at the workgroup size preferred for the env count; otherwise it is
+ * staged beside a smaller workgroup only if gathering would not allow a larger one. */
 int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int *bank_in_lds, size_t *lds_bytes);
 
 /* Measurement aid (no reference counterpart): coalesced 8-byte-per-lane device copy of n_doubles doubles, the

@@ -1,2 +1,6 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for i in 1 2; do
+R=128 K=635 python3 tools/time_fresh_device.py
+SSG_LIB_PATH=$PWD/ship_sim_gym_amd/libshipsim_genw2.so R=128 K=635 python3 tools/time_fresh_device.py
+done
+SSG_LIB_PATH=$PWD/ship_sim_gym_amd/libshipsim_genw2.so R=128 K=635 bash tools/fresh_kernel_times.sh
