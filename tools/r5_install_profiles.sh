@@ -5,11 +5,11 @@ mkdir -p profiles/r5/config4
 P=gpurun_out/prof_r5h
 cp $P/counters.json profiles/r5/counters.json; cp $P/counters.json profiles/counters_latest.json; cp $P/traffic.json profiles/r5/traffic.json
 cp $P/summary.txt profiles/r5/rocprofv3_summary_bench_65536x8beam_trajectory.txt
-find $P/trace -name "*kernel_stats.csv" -exec cp {} profiles/r5/kernel_stats.csv \;
-find $P/trace -name "*domain_stats.csv" -exec cp {} profiles/r5/domain_stats.csv \;
+cp "$(ls -t $(find $P/trace -name "*kernel_stats.csv") | head -1)" profiles/r5/kernel_stats.csv   # (gpurun_out accumulates earlier runs: the newest)
+cp "$(ls -t $(find $P/trace -name "*domain_stats.csv") | head -1)" profiles/r5/domain_stats.csv
 C=gpurun_out/prof_c4_r5
-find $C/trace -name "*kernel_stats.csv" -exec cp {} profiles/r5/config4/kernel_stats.csv \;
-find $C/trace_memo_off -name "*kernel_stats.csv" -exec cp {} profiles/r5/config4/kernel_stats_memo_off.csv \;
+cp "$(ls -t $(find $C/trace -name "*kernel_stats.csv") | head -1)" profiles/r5/config4/kernel_stats.csv
+cp "$(ls -t $(find $C/trace_memo_off -name "*kernel_stats.csv") | head -1)" profiles/r5/config4/kernel_stats_memo_off.csv
 cp $C/kernel_times.txt profiles/r5/config4/kernel_times.txt
 grep -A30 "== kernel stats ==" gpurun_out/prof_c4_r5.log > profiles/r5/config4/rocprofv3_summary_config4_memo.txt
 python3 - <<'PY'
