@@ -385,6 +385,34 @@ def test_full_size_fused_trajectory_properties(torch_cuda, oracle, native):
           % (len(smp.idx), K, smp.n_done, smp.worst))
 
 
+def test_full_size_bank_too_large_for_the_lds(torch_cuda, oracle, native):
+    """65 536 envs on a bank of 120 records: it fits the LDS only beside 64-env workgroups (four rounds per launch), so
+    ssg_set_map_bank gathers it from L2 on 256-env workgroups.  ~2 050 sampled envs against the oracle, every fused step; and
+    the whole batch, slot by slot, against the same bank staged beside 64-env workgroups (SSG_BLOCK forces that layout)."""
+    import os
+    torch = torch_cuda
+    n, K = 65536, 120
+    vec = _vec(n, n_maps=120, n_beams=8)
+    assert vec.launch_geometry()[:2] == (256, False)
+    os.environ["SSG_BLOCK"] = "64"
+    try:
+        ref = _vec(n, n_maps=120, n_beams=8)
+        assert ref.launch_geometry()[:2] == (64, True)
+    finally:
+        del os.environ["SSG_BLOCK"]
+    smp = OracleSample(oracle, vec, 2048, seed=120)
+    smp.reset(vec.reset_tensor().clone()); ref.reset_tensor()
+    acts = vec.random_actions(2026, 0, K)
+    to, tr, td, tf = vec.rollout_tensor(acts, trajectory=True)
+    ro, rr, rd, rf = ref.rollout_tensor(acts, trajectory=True)
+    assert torch.equal(to, ro) and torch.equal(tr, rr) and torch.equal(td, rd) and torch.equal(tf, rf)
+    for k in range(K):
+        smp.step(acts[k], to[k], tr[k], td[k], atol=ATOL)
+    assert smp.n_done > 500 and smp.worst <= 1e-9
+    assert int(vec.field(native.F_MAP_ID).max()) < 120
+    vec.close(); ref.close()
+
+
 def test_trajectory_rewards_add_up_to_the_in_kernel_episode_statistics(torch_cuda, native):
     """What train/random.py:14-27 does with the per-step tuples — accumulate `total_reward` until `done` — done on the
     trajectory tensors of a fused rollout must give exactly the episode statistics the step kernel accumulates itself
