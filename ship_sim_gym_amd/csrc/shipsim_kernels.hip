@@ -285,7 +285,14 @@ __host__ __device__ __forceinline__ constexpr int lds_tile_bytes(int nb)
 constexpr int kHdrLidar = 10, kHdrGoals = 2 * SSG_MAX_GOALS;
 static_assert(SSG_MAP_OFF_COUNTS == 0 && SSG_MAP_OFF_AABB == 2 && SSG_MAP_OFF_GOALS == kHdrLidar && SSG_MAP_OFF_SPAWN_GOAL == kHdrLidar + kHdrGoals,
               "the record's head: counts, boxes, goals, spawn goal");
-__host__ __device__ __forceinline__ constexpr int lds_hdr_bytes(int epw, bool lds_bank) { return lds_bank ? 0 : (2 * kHdrLidar + kHdrGoals) * epw * 8; }
+// Waves per 64-env tile.  Four roles (see the step kernel); SIX on 64-env workgroups of the 1-ship kernels — the small batches
+// (<= 16 384 envs: at most one workgroup per CU), where every wave is alone on its SIMD and a step is as long as its longest
+// dependent chain, which was a lidar wave's: query k (5.5 k cycles), then collide_ship against its bank hull (3.2 k) on the pose
+// the body had published 2.6 k cycles before the query ended, then the rendezvous.  collide_ship gets waves of its own (roles 4
+// and 5, one bank hull each): it runs beside the query instead of behind it.
+__host__ __device__ __forceinline__ constexpr int tile_roles(int epw, bool dyn) { return (epw == 64 && !dyn) ? 6 : 4; }
+// gathered bank: record doubles 0..9 per role that queries or collides (2, or 4 with six roles), the goal centres once
+__host__ __device__ __forceinline__ constexpr int lds_hdr_bytes(int epw, bool lds_bank, bool dyn) { return lds_bank ? 0 : ((tile_roles(epw, dyn) - 2) * kHdrLidar + kHdrGoals) * epw * 8; }
 
 constexpr unsigned long long kLidarMiss = ~0ull; // result key of a beam no hull reported a hit for
 
@@ -480,7 +487,7 @@ __device__ __forceinline__ void st_out(T *p, T v)
 #define SSG_STAMP_FLUSH(n)                                                                        \
     do {                                                                                          \
         if (c.dbg && lane == 0) {                                                                 \
-            unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (4 * EPW / 64) + (threadIdx.x >> 6)); \
+            unsigned long long *d_ = c.dbg + 16 * (size_t)(blockIdx.x * (NR * EPW / 64) + (threadIdx.x >> 6)); \
             for (int k_ = 0; k_ < 16; ++k_) d_[k_] = stamp_[k_];  /* 8: kernel start, 9: after barrier 0, 10: role end */ \
         }                                                                                         \
     } while (0)
@@ -839,7 +846,7 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
 // end of the kernel.
 // ---------------------------------------------------------------------------------------------------------
 template <int NB, int EPW, bool LDS_BANK, bool EXACT, bool DYN>
-__global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
+__global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const DevCfg c, const int32_t *__restrict__ actions_kn,
                                                        double *__restrict__ obs, double *__restrict__ reward_out,
                                                        uint8_t *__restrict__ done_out, uint8_t *__restrict__ flags_out,
                                                        const int K_launch, const long long traj)
@@ -853,6 +860,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // buffers' starts: traj = 0 rewrites the same [n_envs] rows every step (ssg_rollout), traj >= n_envs lays the steps of
     // the launch out as a trajectory [K][traj] (ssg_rollout_traj: what train/random.py:14-27 consumes, every step).
     constexpr int NB0 = nb_lo(NB);
+    constexpr int NR = tile_roles(EPW, DYN);                   // waves per tile: 4, or 6 (roles 4 / 5: collide_ship against bank hull 0 / 1)
     const int role = threadIdx.x / EPW;                        // wave-uniform (EPW is a multiple of 64)
     const int tl = threadIdx.x - role * EPW;                   // env slot inside the workgroup
     const int e = blockIdx.x * EPW + tl;
@@ -893,8 +901,8 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     char *tile_base = scratch0 + (tl >> 6) * lds_tile_bytes(NB); // this env tile's lidar buffers
     // gathered bank: the record heads in LDS (see lds_hdr_bytes); hL = this env's column of the lidar role's copy, hG = of the goals
     double *hdr0 = reinterpret_cast<double *>(scratch0 + (EPW / 64) * lds_tile_bytes(NB));
-    double *hL = LDS_BANK ? nullptr : hdr0 + (role & 1) * (kHdrLidar * EPW) + tl;
-    double *hG = LDS_BANK ? nullptr : hdr0 + 2 * kHdrLidar * EPW + tl;
+    double *hL = LDS_BANK ? nullptr : hdr0 + ((role & 1) + (role >= 4 ? 2 : 0)) * (kHdrLidar * EPW) + tl;
+    double *hG = LDS_BANK ? nullptr : hdr0 + (NR - 2) * kHdrLidar * EPW + tl;
     auto load_hdr_lidar = [&](int rec_off) { // record doubles 0..9 -> this role's copy (five 16-byte gathers)
 #pragma unroll
         for (int f = 0; f < kHdrLidar / 2; ++f) { const double2 v = bank_at2<LDS_BANK>(c, rec_off + 2 * f); hL[(2 * f) * EPW] = v.x; hL[(2 * f + 1) * EPW] = v.y; }
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // of the waves that own a table (three of a workgroup's sixteen), i.e. in front of barrier 0 of every launch.
     double bank_tail_v = 0.0;
     int bank_tail_o = -1;
-    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<4 * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8), bank_tail_v, bank_tail_o);
+    if (LDS_BANK && !SSG_ABL(8)) stage_bank_lds<NR * EPW>(c.bank, c.n_maps * (SSG_MAP_STRIDE * 8), bank_tail_v, bank_tail_o);
     // small constant tables (written once per workgroup, read after the first barrier).  Their entries are vector loads from the
     // kernel-argument segment, indexed by the thread id: they are only REQUESTED here and written to LDS by flush_tables(), which
     // every role calls right before its wait in front of barrier 0 — written here, each cost its wave a memory round trip of its own
@@ -983,7 +991,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     // raised GPU memory-access faults in the diagnostic builds that also execute s_memtime: not used.)
     auto tile_barrier = [&](int k) {
         if (lane == 0) __hip_atomic_fetch_add(&sync_bar[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&sync_bar[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(k + 1))
+        while (__hip_atomic_load(&sync_bar[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)NR * (unsigned)(k + 1))
             __builtin_amdgcn_s_sleep(1);
     };
 
@@ -1127,21 +1135,26 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first, b_count,
                                          cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
         for (int k = 0; k < K; ++k) {
-            wait_pose(k); // role 3 has published this step's post-step pose
+            if constexpr (NR == 4) wait_pose(k); // role 3 has published this step's post-step pose (six roles: collide_ship is roles 4 / 5's,
+                                                 // this wave goes straight to the rendezvous and picks the pose up behind it)
             if constexpr (DYN) {
 #pragma unroll
                 for (int i = 0; i < 4 * SSG_N_TRAFFIC; ++i) asm volatile("" : "+v"(tpre[i]));
             }
             SSG_STAMP_K(0);
-            const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
-            const double ncx = pose[4 * EPW + tl], ncy = pose[5 * EPW + tl];
-            const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
-            const int nmap = posem[tl];
-            ack_pose();
-            // collide_ship of this step, one bank hull per lidar role (role 2 is writing the previous step's rows; in a launch's
-            // first step the lidar waves have just finished the first query and would idle until B)
-            reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
-                    bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
+            double nca = 0.0, nsa = 0.0, ncx = 0.0, ncy = 0.0, npx = 0.0, npy = 0.0;
+            int nmap = 0;
+            if constexpr (NR == 4) {
+                nca = pose[2 * EPW + tl]; nsa = pose[3 * EPW + tl];
+                ncx = pose[4 * EPW + tl]; ncy = pose[5 * EPW + tl];
+                npx = pose[0 * EPW + tl]; npy = pose[1 * EPW + tl];
+                nmap = posem[tl];
+                ack_pose();
+                // collide_ship of this step, one bank hull per lidar role (role 2 is writing the previous step's rows; in a launch's
+                // first step the lidar waves have just finished the first query and would idle until B)
+                reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + role] =
+                        bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, role, hL, EPW) ? 1 : 0;
+            }
             SSG_STAMP_K(4);
             if constexpr (DYN) {
                 // lidar-lo's queue and hit words: its (beam, hull) pair queue, idle between two queries (64 + 128 of its >= 192 half-words)
@@ -1156,6 +1169,14 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
             SSG_STAMP_K(3);
             tile_barrier(k); // rendezvous B(k): collide_ship and role 3's done bits are in
             SSG_STAMP_K(1);
+            if constexpr (NR == 6) {
+                if (k + 1 < K) { // pose k is still in its slots: role 3 publishes pose k+1 only once every consumer has acknowledged this one
+                    nca = pose[2 * EPW + tl]; nsa = pose[3 * EPW + tl];
+                    ncx = pose[4 * EPW + tl]; ncy = pose[5 * EPW + tl];
+                    nmap = posem[tl];
+                    ack_pose();
+                }
+            }
             if (k + 1 < K) {
                 // step k+1's pre-step pose: this step's post-step pose, or ShipGame.reset's spawn pose on the next map
                 const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u) | (DYN ? traffic_hit(k) : 0u)) != 0u);
@@ -1186,6 +1207,42 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
         SSG_STAMP(10);
         SSG_STAMP_FLUSH(3);
         return;
+    }
+
+    if constexpr (NR == 6) {
+        if (role >= 4) {
+            // =================================================================================================
+            // ROLES 4 / 5 (six-role tiles): collide_ship (game.py:232-241) against bank hull 0 / 1, every step, on the pose
+            // role 3 has just published — beside the lidar waves' query instead of behind it
+            // =================================================================================================
+            const int h = role - 4;
+            int map0 = colMap[el_];
+            if constexpr (!LDS_BANK) load_hdr_lidar(map0 * SSG_MAP_STRIDE); // (this role's own copy of the record's head)
+            asm volatile("" : "+v"(map0));
+            flush_tables();
+            if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads(); // barrier 0
+            SSG_STAMP(9);
+            for (int k = 0; k < K; ++k) {
+                wait_pose(k);
+                const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
+                const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
+                const int nmap = posem[tl];
+                ack_pose();
+                reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + h] =
+                        bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, h, hL, EPW) ? 1 : 0;
+                tile_barrier(k); // rendezvous B(k)
+                if constexpr (!LDS_BANK) {
+                    if (k + 1 < K) { // a done env moves to its next record: its head goes into this role's columns
+                        const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u)) != 0u);
+                        if (rs) load_hdr_lidar(next_map(c, nmap, el_) * SSG_MAP_STRIDE);
+                    }
+                }
+            }
+            SSG_STAMP(10);
+            SSG_STAMP_FLUSH(5);
+            return;
+        }
     }
 
     const int wq = lane / 5, wi = lane - 5 * wq; // worker coordinates of the cooperative sections: lane L = 5*q + i
@@ -1518,7 +1575,7 @@ __global__ __launch_bounds__(4 * EPW) void step_kernel(const DevCfg c, const int
     }
     // publish the post-step pose (once its consumers are done with the previous one): roles 0 / 2 collide it now, role 2
     // reports it in the observation, the lidar roles query from it for the next step
-    while (__hip_atomic_load(&sync_ack[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 3u * (unsigned)k)
+    while (__hip_atomic_load(&sync_ack[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(NR - 1) * (unsigned)k)
         __builtin_amdgcn_s_sleep(1);
     pose[0 * EPW + tl] = x; pose[1 * EPW + tl] = y; pose[2 * EPW + tl] = ca; pose[3 * EPW + tl] = sa;
     pose[4 * EPW + tl] = x + (sbr - sbl) / 2; // lidar origin: pos + half the world AABB extents (models.py:51-53)
@@ -1923,7 +1980,7 @@ size_t step_lds_bytes(int n_beams, int epw, bool lds_bank, int n_maps, bool dyn)
     size_t b = lds_bank ? (((size_t)n_maps * SSG_MAP_STRIDE * 8 + 15) & ~(size_t)15) : 0;
     b += (size_t)lds_fixed_bytes(epw, dyn);
     b += (size_t)(epw / 64) * (size_t)lds_tile_bytes(n_beams);
-    b += (size_t)lds_hdr_bytes(epw, lds_bank);
+    b += (size_t)lds_hdr_bytes(epw, lds_bank, dyn);
     return b;
 }
 
@@ -1944,7 +2001,7 @@ hipError_t launch_step(const DevCfg &c, int epw, bool lds, size_t lds_bytes, con
     if (!k) return hipErrorInvalidValue;
     if (variant_of(c) == 2 && K != 1) return hipErrorInvalidValue; // the DYN instantiations run exactly one step per launch
     const int grid = (c.n_envs + epw - 1) / epw;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(4 * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K, traj);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(tile_roles(epw, variant_of(c) == 2) * epw), lds_bytes, stream, c, actions, obs, reward, done, flags, K, traj);
     return hipGetLastError();
 }
 

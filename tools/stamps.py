@@ -13,7 +13,8 @@ mode = os.environ.get("SSG_MODE", "bank")  # or fresh_device: per-env records ga
 vec = ShipVecEnv(n, n_maps=64, n_beams=nb, map_mode=mode, ring=64) if mode != "bank" else ShipVecEnv(n, n_maps=64, n_beams=nb)
 L = N.lib()
 epw = 64 if n <= 64 * 256 else (128 if n <= 128 * 256 else 256)
-nw = 4 * ((n + epw - 1) // epw) * epw // 64
+NR = 6 if epw == 64 else 4  # waves per tile (csrc: tile_roles)
+nw = NR * ((n + epw - 1) // epw) * epw // 64
 buf = torch.zeros((nw, 16), dtype=torch.int64, device="cuda")
 L.ssg_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 L.ssg_debug_set_stamp_buffer(vec._h, C.c_void_p(buf.data_ptr()))
@@ -26,7 +27,7 @@ acc = np.zeros((4, 8))
 for r in range(R):
     vec.rollout_tensor(acts[200 + r: 250 + r])  # 50 fused steps; stamps are those of step 48
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().astype(np.int64).reshape(-1, 4, wpr, 16)  # [workgroup][role][tile][stamp]
+    b = buf.cpu().numpy().astype(np.int64).reshape(-1, NR, wpr, 16)[:, :4]  # [workgroup][role][tile][stamp]
     t0 = b[:, 3, :, 0][:, None, :, None]                             # role 3's loop-top stamp of the same tile
     acc += (b[..., :8] - t0).mean(axis=(0, 2))
 acc /= R
