@@ -1225,13 +1225,16 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
             SSG_STAMP(9);
             for (int k = 0; k < K; ++k) {
                 wait_pose(k);
+                SSG_STAMP_K(0);
                 const double nca = pose[2 * EPW + tl], nsa = pose[3 * EPW + tl];
                 const double npx = pose[0 * EPW + tl], npy = pose[1 * EPW + tl];
                 const int nmap = posem[tl];
                 ack_pose();
                 reinterpret_cast<unsigned short *>(gres)[2 * ((k & 1) * EPW + tl) + h] =
                         bank_narrowphase<LDS_BANK>(c, shiptab, npx, npy, nca, nsa, nmap * SSG_MAP_STRIDE, live, lane, h, hL, EPW) ? 1 : 0;
+                SSG_STAMP_K(1);
                 tile_barrier(k); // rendezvous B(k)
+                SSG_STAMP_K(2);
                 if constexpr (!LDS_BANK) {
                     if (k + 1 < K) { // a done env moves to its next record: its head goes into this role's columns
                         const bool rs = auto_reset & ((gres[(k & 1) * EPW + tl] | (gdone[(k & 1) * EPW + tl] & 1u)) != 0u);

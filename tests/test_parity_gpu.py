@@ -385,6 +385,33 @@ def test_full_size_fused_trajectory_properties(torch_cuda, oracle, native):
           % (len(smp.idx), K, smp.n_done, smp.worst))
 
 
+def test_every_workgroup_layout_against_the_oracle(torch_cuda, oracle, native):
+    """The step kernel's workgroup layouts — 64 envs with SIX wave roles (what batches of <= 16 384 envs get: collide_ship on
+    waves of its own), 128 and 256 envs with four — each stepped against the oracle at a size the oracle handles (SSG_BLOCK
+    forces the layout): single steps, then a fused trajectory rollout compared slot by slot; staged and gathered bank."""
+    import os
+    torch = torch_cuda
+    for blk, kw in (("64", {}), ("128", {}), ("256", {}), ("64", {"bank_in_global": True}), ("256", {"bank_in_global": True})):
+        os.environ["SSG_BLOCK"] = blk
+        try:
+            for nb in (8, 10):
+                vec = _vec(1200, n_maps=64, n_beams=nb, **kw)
+                assert vec.launch_geometry()[0] == int(blk)
+                err, n_done = run_pair(oracle, native, vec, K=150)
+                assert err <= 1e-9 and n_done > 30
+                # fused trajectory: every slot against single steps of a second handle on the same layout
+                ref = _vec(1200, n_maps=64, n_beams=nb, **kw)
+                vec.reset_tensor(); ref.reset_tensor()
+                acts = vec.random_actions(77, 0, 60)
+                to, tr, td, tf = vec.rollout_tensor(acts, trajectory=True)
+                for k in range(60):
+                    o, r, d, f = ref.step_tensor(acts[k])
+                    assert torch.equal(to[k], o) and torch.equal(tr[k], r) and torch.equal(td[k], d) and torch.equal(tf[k], f), (blk, nb, k)
+                vec.close(); ref.close()
+        finally:
+            del os.environ["SSG_BLOCK"]
+
+
 def test_full_size_bank_too_large_for_the_lds(torch_cuda, oracle, native):
     """65 536 envs on a bank of 120 records: it fits the LDS only beside 64-env workgroups (four rounds per launch), so
     ssg_set_map_bank gathers it from L2 on 256-env workgroups.  ~2 050 sampled envs against the oracle, every fused step; and

@@ -23,11 +23,11 @@ vec.reset_tensor()
 vec.rollout_tensor(acts[:200])
 wpr = epw // 64
 R = 40
-acc = np.zeros((4, 8))
+acc = np.zeros((NR, 8))
 for r in range(R):
     vec.rollout_tensor(acts[200 + r: 250 + r])  # 50 fused steps; stamps are those of step 48
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().astype(np.int64).reshape(-1, NR, wpr, 16)[:, :4]  # [workgroup][role][tile][stamp]
+    b = buf.cpu().numpy().astype(np.int64).reshape(-1, NR, wpr, 16)  # [workgroup][role][tile][stamp]
     t0 = b[:, 3, :, 0][:, None, :, None]                             # role 3's loop-top stamp of the same tile
     acc += (b[..., :8] - t0).mean(axis=(0, 2))
 acc /= R
@@ -42,3 +42,7 @@ for role, nm in ((0, "lidar lo"), (1, "lidar hi")):
         role, nm, acc[role, 0], acc[role, 3], acc[role, 1], acc[role, 2], acc[role, 2] - acc[role, 1]))
 print("role 2 (observer): pose copied %.0f | first-step narrowphase slot %.0f (= %.0f cycles) | B complete %.0f | outputs + obs rows written %.0f (= %.0f cycles)" % (
     acc[2, 0], acc[2, 1], acc[2, 1] - acc[2, 0], acc[2, 2], acc[2, 3], acc[2, 3] - acc[2, 2]))
+if NR == 6:
+    for role in (4, 5):
+        print("role %d (collide_ship, bank hull %d): pose seen %.0f | arrives at B %.0f (= %.0f cycles) | B complete %.0f" % (
+            role, role - 4, acc[role, 0], acc[role, 1], acc[role, 1] - acc[role, 0], acc[role, 2]))
