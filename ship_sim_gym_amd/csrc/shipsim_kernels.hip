@@ -285,12 +285,16 @@ __host__ __device__ __forceinline__ constexpr int lds_tile_bytes(int nb)
 constexpr int kHdrLidar = 10, kHdrGoals = 2 * SSG_MAX_GOALS;
 static_assert(SSG_MAP_OFF_COUNTS == 0 && SSG_MAP_OFF_AABB == 2 && SSG_MAP_OFF_GOALS == kHdrLidar && SSG_MAP_OFF_SPAWN_GOAL == kHdrLidar + kHdrGoals,
               "the record's head: counts, boxes, goals, spawn goal");
-// Waves per 64-env tile.  Four roles (see the step kernel); SIX on 64-env workgroups of the 1-ship kernels — the small batches
-// (<= 16 384 envs: at most one workgroup per CU), where every wave is alone on its SIMD and a step is as long as its longest
-// dependent chain, which was a lidar wave's: query k (5.5 k cycles), then collide_ship against its bank hull (3.2 k) on the pose
-// the body had published 2.6 k cycles before the query ended, then the rendezvous.  collide_ship gets waves of its own (roles 4
-// and 5, one bank hull each): it runs beside the query instead of behind it.
-__host__ __device__ __forceinline__ constexpr int tile_roles(int epw, bool dyn) { return (epw == 64 && !dyn) ? 6 : 4; }
+// Waves per 64-env tile.  Four roles (see the step kernel); SIX on the 64- and 128-env workgroups of the 1-ship kernels — the
+// smaller batches (<= 32 768 envs: at most one workgroup per CU), where a wave is alone on its SIMD or shares it with one other
+// and a step is as long as its longest dependent chain, which was a lidar wave's: query k (5.5 k cycles), then collide_ship against
+// its bank hull (3.2 k) on the pose the body had published 2.6 k cycles before the query ended, then the rendezvous.  collide_ship
+// gets waves of its own (roles 4 and 5, one bank hull each): it runs beside the query instead of behind it.  4 096 envs x 10 beams:
+// 4.39 -> 3.63 us per step; 32 768 envs (128-env workgroups): 4.69 -> 4.41.  (256-env workgroups: 24 waves would be 1 536 threads.)
+#ifndef SSG_SIX_ROLE_MAX_EPW
+#define SSG_SIX_ROLE_MAX_EPW 128
+#endif
+__host__ __device__ __forceinline__ constexpr int tile_roles(int epw, bool dyn) { return (epw <= SSG_SIX_ROLE_MAX_EPW && !dyn) ? 6 : 4; }
 // gathered bank: record doubles 0..9 per role that queries or collides (2, or 4 with six roles), the goal centres once
 __host__ __device__ __forceinline__ constexpr int lds_hdr_bytes(int epw, bool lds_bank, bool dyn) { return lds_bank ? 0 : ((tile_roles(epw, dyn) - 2) * kHdrLidar + kHdrGoals) * epw * 8; }
 

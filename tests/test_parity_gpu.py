@@ -386,12 +386,13 @@ def test_full_size_fused_trajectory_properties(torch_cuda, oracle, native):
 
 
 def test_every_workgroup_layout_against_the_oracle(torch_cuda, oracle, native):
-    """The step kernel's workgroup layouts — 64 envs with SIX wave roles (what batches of <= 16 384 envs get: collide_ship on
-    waves of its own), 128 and 256 envs with four — each stepped against the oracle at a size the oracle handles (SSG_BLOCK
+    """The step kernel's workgroup layouts — 64 and 128 envs with SIX wave roles (what batches of <= 32 768 envs get:
+    collide_ship on waves of its own), 256 envs with four — each stepped against the oracle at a size the oracle handles (SSG_BLOCK
     forces the layout): single steps, then a fused trajectory rollout compared slot by slot; staged and gathered bank."""
     import os
     torch = torch_cuda
-    for blk, kw in (("64", {}), ("128", {}), ("256", {}), ("64", {"bank_in_global": True}), ("256", {"bank_in_global": True})):
+    for blk, kw in (("64", {}), ("128", {}), ("256", {}), ("64", {"bank_in_global": True}), ("128", {"bank_in_global": True}),
+                    ("256", {"bank_in_global": True})):
         os.environ["SSG_BLOCK"] = blk
         try:
             for nb in (8, 10):

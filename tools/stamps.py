@@ -13,7 +13,7 @@ mode = os.environ.get("SSG_MODE", "bank")  # or fresh_device: per-env records ga
 vec = ShipVecEnv(n, n_maps=64, n_beams=nb, map_mode=mode, ring=64) if mode != "bank" else ShipVecEnv(n, n_maps=64, n_beams=nb)
 L = N.lib()
 epw = 64 if n <= 64 * 256 else (128 if n <= 128 * 256 else 256)
-NR = 6 if epw == 64 else 4  # waves per tile (csrc: tile_roles)
+NR = 6 if epw <= 128 else 4  # waves per tile (csrc: tile_roles)
 nw = NR * ((n + epw - 1) // epw) * epw // 64
 buf = torch.zeros((nw, 16), dtype=torch.int64, device="cuda")
 L.ssg_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
