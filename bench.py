@@ -191,7 +191,7 @@ def event_time_rollout(vec, acts, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_memo=True, kernel_split=False, n_maps=N_MAPS):
+def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_memo=True, kernel_split=False, n_maps=N_MAPS, single_step=False):
     """Informational timing of another BASELINE config on this GPU (outside the headline's timed region)."""
     from ship_sim_gym_amd.vec_env import ShipVecEnv
     vec = ShipVecEnv(n, device=dev, map_mode=map_mode, n_maps=n_maps, map_seed=1000, n_beams=n_beams, n_ships=n_ships, ring=ring,
@@ -212,6 +212,22 @@ def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_me
         if out["dyn_memo"]:
             st = vec.dyn_memo_stats()
             out["memo_lookups"] = {k: st[k] for k in ("hits", "computed", "stored")}
+    if single_step:
+        # the policy-in-the-loop path at this size: one ssg_step launch per step, median of 5 repeats of 500 back-to-back steps
+        import torch
+        a1 = vec.random_actions(777, 0, 500)
+        rows = [a1[k] for k in range(500)]
+        reps = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for a in rows:
+                vec.step_tensor(a)
+            e1.record()
+            torch.cuda.synchronize()
+            reps.append(e0.elapsed_time(e1) * 1e3 / 500)
+        out["single_step_launch_us"] = sorted(reps)[2]
     if kernel_split and n_ships > 1:
         # the two launches of a config-4 step, by HIP events around each (a separate short run: the events and the wait at the end
         # of the call are not part of the figure above)
@@ -579,7 +595,7 @@ def main():
             out["single_step_launch_us"] = None
         if world == 1 and not args.no_other_configs and not c4:
             try:
-                other["c2_4096_envs_10_beams"] = side_config(dev, 4096, 10, 1, 1000, 200)
+                other["c2_4096_envs_10_beams"] = side_config(dev, 4096, 10, 1, 1000, 200, single_step=True)
                 # BASELINE configs[3].  Bank mode (the benchmark workload of SURVEY 8d: envs share the 64 records): cpSpaceStep of the
                 # traffic ships / goal bodies is MEMOISED (SSG_F_DYN_MEMO_STATS) — labelled, and next to it the same run with every
                 # step computed, and with a brand-new world per episode (no env shares a world: nothing to memoise)
