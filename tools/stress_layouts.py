@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Race hunt (GPU box): random (env count, beam count, bank size / gathered, launch length) — a fused trajectory rollout against
+the same steps launched one by one on a second handle, bitwise, slot by slot.  Any ordering bug in the tile's hand-overs (four or
+six wave roles) shows up as a mismatch sooner or later.  SECONDS = how long to keep going (default 240)."""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ship_sim_gym_amd.vec_env import ShipVecEnv
+rng = random.Random(int(os.environ.get("SEED", "2026")))
+t_end = time.time() + float(os.environ.get("SECONDS", "240"))
+cases = steps = 0
+while time.time() < t_end:
+    n = rng.choice([1, 63, 64, 65, 200, 1000, 4096, 5000, 16384, 16385, 20000, 32768, 40000, 65536])
+    nb = rng.choice([1, 2, 4, 5, 8, 10, 12, 16])
+    kw = rng.choice([{"n_maps": 64}, {"n_maps": 64, "bank_in_global": True}, {"n_maps": 150}, {"n_maps": 7}])
+    K = rng.choice([1, 2, 3, 7, 20, 50, 100, 101, 130])
+    if n >= 32768 and K > 50: K = 50
+    a = ShipVecEnv(n, n_beams=nb, **kw); b = ShipVecEnv(n, n_beams=nb, **kw)
+    a.reset_tensor(); b.reset_tensor()
+    warm = rng.choice([0, 5, 33])
+    acts = a.random_actions(rng.randrange(1 << 30), 0, warm + K)
+    if warm:
+        a.rollout_tensor(acts[:warm]); b.rollout_tensor(acts[:warm])
+    to, tr, td, tf = a.rollout_tensor(acts[warm:], trajectory=True)
+    for k in range(K):
+        o, r, d, f = b.step_tensor(acts[warm + k])
+        if not (torch.equal(to[k], o) and torch.equal(tr[k], r) and torch.equal(td[k], d) and torch.equal(tf[k], f)):
+            print("MISMATCH n=%d nb=%d %s K=%d warm=%d at step %d geometry %s" % (n, nb, kw, K, warm, k, a.launch_geometry()))
+            sys.exit(1)
+    for fid in range(12):
+        if not torch.equal(a.field(fid), b.field(fid)):
+            print("STATE MISMATCH field %d n=%d nb=%d %s K=%d" % (fid, n, nb, kw, K)); sys.exit(1)
+    cases += 1; steps += K
+    a.close(); b.close()
+print("stress: %d random cases, %d fused steps compared slot by slot with single-step launches, all bitwise equal" % (cases, steps))
