@@ -242,7 +242,11 @@ int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double 
  * kernel: inside a launch the map bank stays in LDS and the body state in registers from step to step.
  * obs/reward/done/flags are overwritten by every step and the state blob is updated every step; the final contents of
  * every buffer are bit for bit those of K separate ssg_step calls.  With history > 2 or n_ships = 4 every step is its own
- * launch sequence (frame shift / the two dyn kernels before the step kernel): same results, no fusion. */
+ * launch sequence (frame shift / the two dyn kernels before the step kernel): same results, no fusion.
+ * HIP graphs: a 1-ship handle on a shared bank with history <= 2 launches with constant arguments, so ssg_step / ssg_rollout on a
+ * capturing stream can be captured and replayed (on this ROCm a replay costs more than the plain launch it replaces).  Handles
+ * with n_ships > 1, map_ring or history > 2 take per-call host state in their kernel arguments: ssg_step / ssg_rollout / ssg_reset
+ * return SSG_ERR_UNSUPPORTED on a capturing stream instead of recording a step that every replay would repeat. */
 #define SSG_ROLLOUT_STEPS_PER_LAUNCH 100 /* steps fused into one launch of the step kernel by ssg_rollout */
 int ssg_rollout(ssg_handle *h, const int32_t *dev_actions_KN, int K, double *dev_obs, double *dev_reward,
                 uint8_t *dev_done, uint8_t *dev_flags /* nullable */, void *stream);

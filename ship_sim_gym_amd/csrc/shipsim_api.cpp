@@ -410,6 +410,20 @@ int pick_block(int n_envs)
     return 256;
 }
 
+// Config 4 and map_ring launches carry per-call HOST state in their kernel arguments (which counter set holds the live queue, the
+// launch number the memo's entries are stamped with, the ring's credit): captured into a HIP graph they would be replayed with
+// the arguments of the captured call — silently wrong steps.  Refuse a capturing stream for those handles.  (1-ship handles on a
+// shared bank launch with constant arguments and can be captured.)
+int refuse_capture(ssg_handle *h, void *stream, const char *what)
+{
+    if (h->cfg.n_ships <= 1 && h->cfg.map_ring <= 0 && h->cfg.history <= 2) return SSG_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) != hipSuccess) { (void)hipGetLastError(); return SSG_OK; }
+    if (cs == hipStreamCaptureStatusNone) return SSG_OK;
+    return fail(h, SSG_ERR_UNSUPPORTED, std::string(what) + ": the stream is capturing a HIP graph, and this handle's launches (n_ships > 1, map_ring or "
+                                        "history > 2) take per-call host state in their arguments — a replay would repeat the captured step's");
+}
+
 int check_ready(ssg_handle *h, bool need_bank)
 {
     if (!h) return SSG_ERR_BAD_ARG;
@@ -709,6 +723,8 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
 {
     int rc = check_ready(h, true);
     if (rc != SSG_OK) return rc;
+    rc = refuse_capture(h, stream, "ssg_reset");
+    if (rc != SSG_OK) return rc;
     if (!dev_mask && !h->zeroed) { // first full reset on a freshly bound blob: start from zeroed counters / columns
         rc = ssg_init_state(h, stream);
         if (rc != SSG_OK) return rc;
@@ -775,6 +791,8 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
         return fail(h, SSG_ERR_BAD_ARG, "ssg_step/ssg_rollout: NULL buffer or K < 1");
     if (step_stride_envs != 0 && step_stride_envs < (int64_t)h->cfg.n_envs)
         return fail(h, SSG_ERR_BAD_ARG, "ssg_rollout_traj: step_stride_envs must be 0 or >= n_envs (steps would overlap)");
+    rc = refuse_capture(h, stream, "ssg_step/ssg_rollout");
+    if (rc != SSG_OK) return rc;
     rc = prepare(h);
     if (rc != SSG_OK) return rc;
     rc = flush_remap(h, stream);

@@ -574,3 +574,45 @@ def test_config4_memo_generations_wrap_around():
     assert sc["hits"] > sc["computed"] and sa["stored"] > 250          # every generation starts empty and learns again
     for v in (a, b, c):
         v.close()
+
+
+def test_config4_refuses_hip_graph_capture():
+    """A config-4 step's kernel arguments carry host state that changes from call to call (which counter set holds the queue, the
+    launch number the memo stamps its entries with): captured in a HIP graph, every replay would repeat the captured step's — so
+    ssg_step refuses a capturing stream.  A 1-ship handle on a shared bank launches with constant arguments: capture + replay
+    equals plain launches."""
+    torch, O, N, ShipVecEnv = _mods()
+    from ship_sim_gym_amd._native import ShipSimError
+    n = 512
+    for ships in (1, 4):
+        a = ShipVecEnv(n, n_beams=10, n_ships=ships); b = ShipVecEnv(n, n_beams=10, n_ships=ships)
+        a.reset_tensor(); b.reset_tensor()
+        acts = a.random_actions(5, 0, 40)
+        static_act = torch.zeros(n, dtype=torch.int32, device="cuda")
+        static_act.copy_(acts[0]); a.step_tensor(static_act); b.step_tensor(acts[0])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        refused = False
+        with torch.cuda.stream(s):
+            static_act.copy_(acts[1])
+            g.capture_begin()
+            try:
+                a.step_tensor(static_act)
+            except ShipSimError as ex:
+                refused = True
+                assert "capturing" in str(ex)
+            g.capture_end()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        assert refused == (ships == 4)
+        for k in range(1, 40):
+            static_act.copy_(acts[k])
+            if ships == 1:
+                g.replay()
+            else:
+                a.step_tensor(static_act)  # (the refused capture left the handle as it was: plain launches go on)
+            ob, rb, db, fb = b.step_tensor(acts[k])
+            assert torch.equal(a.obs, ob) and torch.equal(a.reward, rb) and torch.equal(a.done, db), (ships, k)
+        a.close(); b.close()
