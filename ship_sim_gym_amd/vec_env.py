@@ -114,6 +114,7 @@ class ShipVecEnv(*_BASES):
         if env_config.HISTORY_SIZE < 1:  # ship_env.py:46-47
             raise ValueError("history_size must be greater than zero")
         self.num_envs = int(num_envs)
+        self._i32 = torch.int32
         self.device = torch.device(device)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", self._dev_index)  # (always with its index: tensors report `cuda:N`)
@@ -411,6 +412,10 @@ class ShipVecEnv(*_BASES):
         """actions: int32 device tensor [N].  Returns (obs, reward, done, flags) device tensors (reused buffers).
         This is the policy-in-the-loop path: one launch per call, so the host side is kept to one ctypes call with plain
         integers (the cached output pointers, the actions' address, the current stream's handle)."""
+        # (a tensor of another dtype / size would be read as int32 [N] all the same: wrong steps, or a read past its end)
+        if actions.dtype is not self._i32 or actions.numel() != self.num_envs or not actions.is_cuda or not actions.is_contiguous():
+            raise ValueError("step_tensor: actions must be a contiguous int32 device tensor of %d elements (got %s %s on %s)"
+                             % (self.num_envs, actions.dtype, tuple(actions.shape), actions.device))
         hot = self.__dict__.get("_hot")
         if hot is None or hot[0] != (self.obs.data_ptr(), self.reward.data_ptr()):
             torch = _torch()
@@ -435,6 +440,10 @@ class ShipVecEnv(*_BASES):
         rollout loop sees them (train/random.py:14-27) — returns (obs [K, N, D], reward [K, N], done [K, N], flags [K, N])
         device tensors; `out` = a tuple of four such preallocated tensors (first dimension >= K, contiguous) to write
         into instead of allocating.  self.obs / reward / done / flags are left untouched in trajectory mode."""
+        if (actions_kn.dtype is not self._i32 or actions_kn.dim() != 2 or actions_kn.shape[1] != self.num_envs or not actions_kn.is_cuda
+                or not actions_kn.is_contiguous()):
+            raise ValueError("rollout_tensor: actions must be a contiguous int32 device tensor [K, %d] (got %s %s on %s)"
+                             % (self.num_envs, actions_kn.dtype, tuple(actions_kn.shape), actions_kn.device))
         if trajectory and out is not None:
             # a buffer set seen before: one ctypes call with plain integers, like step_tensor — a 20-step launch is ~140 us, and
             # everything the host does before the launch is GPU idle time inside a caller's timed region.  The cache holds

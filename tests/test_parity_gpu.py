@@ -385,6 +385,26 @@ def test_full_size_fused_trajectory_properties(torch_cuda, oracle, native):
           % (len(smp.idx), K, smp.n_done, smp.worst))
 
 
+def test_action_tensors_are_checked(torch_cuda):
+    """step_tensor / rollout_tensor hand the actions' ADDRESS to the library: a tensor of another dtype, size or device would be
+    read as int32 [N] all the same (wrong steps, or a read past its end), so the host side refuses it."""
+    torch = torch_cuda
+    vec = _vec(300, n_maps=8)
+    vec.reset_tensor()
+    good = torch.zeros(300, dtype=torch.int32, device="cuda")
+    vec.step_tensor(good)
+    for bad in (torch.zeros(300, dtype=torch.int64, device="cuda"), torch.zeros(299, dtype=torch.int32, device="cuda"),
+                torch.zeros(300, dtype=torch.int32), torch.zeros((300, 2), dtype=torch.int32, device="cuda")[:, 0]):
+        with pytest.raises(ValueError):
+            vec.step_tensor(bad)
+    vec.rollout_tensor(torch.zeros((5, 300), dtype=torch.int32, device="cuda"))
+    for bad in (torch.zeros((5, 300), dtype=torch.int64, device="cuda"), torch.zeros((5, 301), dtype=torch.int32, device="cuda"),
+                torch.zeros(300, dtype=torch.int32, device="cuda"), torch.zeros((5, 600), dtype=torch.int32, device="cuda")[:, ::2]):
+        with pytest.raises(ValueError):
+            vec.rollout_tensor(bad)
+    vec.close()
+
+
 def test_every_workgroup_layout_against_the_oracle(torch_cuda, oracle, native):
     """The step kernel's workgroup layouts — 64 and 128 envs with SIX wave roles (what batches of <= 32 768 envs get:
     collide_ship on waves of its own), 256 envs with four — each stepped against the oracle at a size the oracle handles (SSG_BLOCK
