@@ -268,7 +268,10 @@ class ShipVecEnv(*_BASES):
         torch = _torch()
         if isinstance(bank, np.ndarray):
             bank = torch.from_numpy(np.ascontiguousarray(bank, dtype=np.float64)).to(self.device)
-        assert bank.dtype == torch.float64 and bank.shape[1] == N.MAP_STRIDE and bank.is_contiguous()
+        if not bank.is_cuda:
+            bank = bank.to(self.device)
+        assert bank.dtype == torch.float64 and bank.dim() == 2 and bank.shape[1] == N.MAP_STRIDE and bank.is_contiguous()
+        assert bank.device == self.device, "set_bank: the bank lives on %s, the env on %s" % (bank.device, self.device)
         self.bank = bank
         self.n_maps = int(bank.shape[0])
         with torch.cuda.device(self.device):
@@ -339,6 +342,26 @@ class ShipVecEnv(*_BASES):
         v = self.state[off.value: off.value + nc.value * stride.value].view(dt).view(nc.value, n_pad)[:, :self.num_envs]
         return v[0] if nc.value == 1 else v
 
+    def _mask_ptr(self, mask, what):
+        """A per-env byte mask as a C pointer (None = all envs): uint8 or bool, one element per env, on this env's device."""
+        if mask is None:
+            return None
+        torch = _torch()
+        if (mask.dtype not in (torch.uint8, torch.bool) or mask.numel() != self.num_envs or not mask.is_cuda or mask.device != self.device
+                or not mask.is_contiguous()):
+            raise ValueError("%s: mask must be a contiguous uint8 / bool tensor of %d elements on %s (got %s %s on %s)"
+                             % (what, self.num_envs, self.device, mask.dtype, tuple(mask.shape), mask.device))
+        return C.c_void_p(mask.data_ptr())
+
+    def _ids_ptr(self, ids, what):
+        if ids is None:
+            return None
+        torch = _torch()
+        if ids.dtype != torch.int32 or ids.numel() != self.num_envs or ids.device != self.device or not ids.is_contiguous():
+            raise ValueError("%s: map_ids must be a contiguous int32 tensor of %d elements on %s (got %s %s on %s)"
+                             % (what, self.num_envs, self.device, ids.dtype, tuple(ids.shape), ids.device))
+        return C.c_void_p(ids.data_ptr())
+
     def wake_dynamics(self, mask=None):
         """Config 4: call after writing ANY state column through field() — the traffic / goal-body columns (envs whose
         bodies had come to rest are otherwise not stepped; the ships' rotation columns, which the step kernel's collide_ship turns
@@ -346,8 +369,8 @@ class ShipVecEnv(*_BASES):
         cpSpaceStep visits was decided from the state the last step ended with): ssg_dyn_invalidate.  Also after restoring or
         copying the state blob.  mask: uint8 device tensor [num_envs]
         (envs whose rest bit is cleared) or None = all; the next step's queue is rebuilt from the columns either way."""
+        mp = self._mask_ptr(mask, "wake_dynamics")
         with _torch().cuda.device(self.device):
-            mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
             N.check(N.lib().ssg_dyn_invalidate(self._h, mp, self._stream()), self._h, "ssg_dyn_invalidate")
 
     def field_stats_tensor(self):
@@ -386,9 +409,8 @@ class ShipVecEnv(*_BASES):
     # ------------------------------------------------------------------------------------------------
     def reset_tensor(self, mask=None, map_ids=None):
         torch = _torch()
+        mp, ip = self._mask_ptr(mask, "reset_tensor"), self._ids_ptr(map_ids, "reset_tensor")
         with torch.cuda.device(self.device):
-            mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
-            ip = C.c_void_p(map_ids.data_ptr()) if map_ids is not None else None
             if self.map_mode == "fresh" and map_ids is None:
                 ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
                 ip = C.c_void_p(ids.data_ptr())

@@ -397,6 +397,13 @@ def test_action_tensors_are_checked(torch_cuda):
                 torch.zeros(300, dtype=torch.int32), torch.zeros((300, 2), dtype=torch.int32, device="cuda")[:, 0]):
         with pytest.raises(ValueError):
             vec.step_tensor(bad)
+    vec.reset_tensor(mask=torch.zeros(300, dtype=torch.uint8, device="cuda"))
+    vec.reset_tensor(mask=torch.zeros(300, dtype=torch.bool, device="cuda"), map_ids=torch.zeros(300, dtype=torch.int32, device="cuda"))
+    for bad in (torch.zeros(300, dtype=torch.int64, device="cuda"), torch.zeros(299, dtype=torch.uint8, device="cuda"), torch.zeros(300, dtype=torch.uint8)):
+        with pytest.raises(ValueError):
+            vec.reset_tensor(mask=bad)
+    with pytest.raises(ValueError):
+        vec.reset_tensor(map_ids=torch.zeros(300, dtype=torch.int64, device="cuda"))
     vec.rollout_tensor(torch.zeros((5, 300), dtype=torch.int32, device="cuda"))
     for bad in (torch.zeros((5, 300), dtype=torch.int64, device="cuda"), torch.zeros((5, 301), dtype=torch.int32, device="cuda"),
                 torch.zeros(300, dtype=torch.int32, device="cuda"), torch.zeros((5, 600), dtype=torch.int32, device="cuda")[:, ::2]):
