@@ -892,8 +892,9 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 rc = ring_refill(h, nullptr, stream);
                 if (rc != SSG_OK) return rc;
             }
-            int kk = (K - k < kFuse) ? (K - k) : kFuse;
-            kk = kk < h->ring_credit ? kk : h->ring_credit;
+            // (up to the ring's whole credit, at most 127 steps, in ONE launch: 100 + 27 was a launch more per refill cycle)
+            int kk = (K - k < h->ring_credit) ? (K - k) : h->ring_credit;
+            if (kFuse < SSG_ROLLOUT_STEPS_PER_LAUNCH && kk > kFuse) kk = kFuse; // (SSG_FUSE = 1: the one-launch-per-step experiment)
             hipError_t e = ssg::launch_step(h->dev, h->block, h->lds, h->lds_bytes, dev_actions + (size_t)k * h->cfg.n_envs, kk,
                                             obs_at(k), rew_at(k), done_at(k), flags_at(k), traj, static_cast<hipStream_t>(stream));
             if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
