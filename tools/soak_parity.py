@@ -62,7 +62,7 @@ def soak_fused(n, chunks, seed=99, **kw):
 
 def soak_traj(n, chunks, seed=2026, **kw):
     """ssg_rollout_traj (round 3): EVERY step of launches of 100 fused steps against the oracle, at the full env count."""
-    vec = ShipVecEnv(n, n_maps=64, **kw)
+    vec = ShipVecEnv(n, n_maps=kw.pop("n_maps", 64), **kw)
     ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
     np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
     worst, t0, ndone = 0.0, time.time(), 0
@@ -95,6 +95,14 @@ if __name__ == "__main__":
         soak(16384, 3000, seed=11, n_beams=10, n_ships=4)             # 49 M env-steps of config 4
         soak(16384, 1500, seed=12, n_beams=8, game_config=Train, n_maps=32)  # the training configuration (episodes of ~6 steps)
         soak(4096, 2500, seed=13, n_beams=16)                         # 16 beams: the bank gathered from L2, record heads in LDS
+        sys.exit(0)
+    if "--extra" in sys.argv:  # round 5: other seeds, and the layouts the round added
+        soak_traj(65536, 10, seed=35, n_beams=8)                      # the headline layout, another action stream
+        soak_traj(65536, 6, seed=31, n_beams=8, n_maps=120)           # a bank too large for the LDS: gathered on 256-env workgroups
+        soak(20000, 1500, seed=32, n_beams=10)                        # 128-env workgroups, six wave roles
+        soak(32768, 800, seed=33, n_beams=8)
+        soak(4096, 4000, seed=36, n_beams=10)                         # BASELINE configs[1]: 64-env workgroups, six wave roles
+        soak(16384, 2000, seed=34, n_beams=10, n_ships=4)             # config 4, another action stream
         sys.exit(0)
     soak_traj(65536, 4, n_beams=8)
     soak_fused(65536, 4, n_beams=8)
