@@ -8,7 +8,7 @@ import torch
 from ship_sim_gym_amd.vec_env import ShipVecEnv
 rng = random.Random(int(os.environ.get("SEED", "2026")))
 t_end = time.time() + float(os.environ.get("SECONDS", "240"))
-cases = steps = c4_cases = 0
+cases = steps = c4_cases = ring_cases = 0
 while time.time() < t_end:
     n = rng.choice([1, 63, 64, 65, 200, 1000, 4096, 5000, 16384, 16385, 20000, 32768, 40000, 65536])
     nb = rng.choice([1, 2, 4, 5, 8, 10, 12, 16])
@@ -19,6 +19,11 @@ while time.time() < t_end:
     if ships == 4:  # config 4: the memoised full step (fused API = its loop of two launches per step) against single steps WITHOUT the memo
         n = min(n, 20000); K = min(K, 50); kw = dict(kw); kw.pop("bank_in_global", None)
         a = ShipVecEnv(n, n_beams=nb, n_ships=4, **kw); b = ShipVecEnv(n, n_beams=nb, n_ships=4, dyn_memo=False, **kw)
+    elif rng.random() < float(os.environ.get("RING_SHARE", "0.15")):  # a brand-new world per episode: rings refilled between launches
+        n = min(n, 20000); ring = rng.choice([2, 3, 8, 33, 128]); ships = 0
+        if n * ring > 600000: ring = 8
+        kw = {"map_mode": "fresh_device", "ring": ring, "map_seed": rng.randrange(1 << 20)}
+        a = ShipVecEnv(n, n_beams=nb, **kw); b = ShipVecEnv(n, n_beams=nb, **kw)
     else:
         a = ShipVecEnv(n, n_beams=nb, **kw); b = ShipVecEnv(n, n_beams=nb, **kw)
     a.reset_tensor(); b.reset_tensor()
@@ -37,6 +42,6 @@ while time.time() < t_end:
     for fid in fids:
         if not torch.equal(a.field(fid), b.field(fid)):
             print("STATE MISMATCH field %d n=%d nb=%d ships=%d %s K=%d" % (fid, n, nb, ships, kw, K)); sys.exit(1)
-    cases += 1; steps += K; c4_cases += ships == 4
+    cases += 1; steps += K; c4_cases += ships == 4; ring_cases += ships == 0
     a.close(); b.close()
-print("stress: %d random cases (%d of config 4: memo on, fused API, against memo off, single steps), %d fused steps compared slot by slot with single-step launches, all bitwise equal" % (cases, c4_cases, steps))
+print("stress: %d random cases (%d of config 4: memo on, fused API, against memo off, single steps; %d on per-env rings of fresh worlds), %d fused steps compared slot by slot with single-step launches, all bitwise equal" % (cases, c4_cases, ring_cases, steps))
