@@ -686,6 +686,42 @@ __device__ __forceinline__ void write_obs_tile(const ObsTile<NB> &ot, double *co
     }
 }
 
+// The same transposition with 16-byte operations (even row lengths, >= 8 beams: the 4 KiB buffer holds 64 rows x 8 columns): a lane
+// writes its row's columns [C0, C0 + 8) as four double2 into row-major LDS — pair q of row r in slot q ^ ((r >> 2) & 3), so that
+// the sixteen lanes of a ds_write_b128 / ds_read_b128 phase fall on sixteen different four-bank groups — and reads pair
+// p = lane + 64 jj of the chunk back (row p / pairs, pair p % pairs): consecutive lanes then store consecutive 16-byte pieces of a
+// row.  Twelve memory instructions per eight columns instead of twenty-four, and shifts instead of per-element positions.
+template <int NB, bool H2, int C_BEGIN, int C_END, class Val>
+__device__ __forceinline__ void write_obs_pairs(double *buf /* 16-byte aligned, >= 4 KiB */, const Val &val /* val(j): column j of this lane's row */,
+                                                double *__restrict__ obase, const int rows_live, const int lane)
+{
+    constexpr int FF = 6 + NB;
+    constexpr int DH = H2 ? 2 * FF : FF;
+    static_assert(C_BEGIN % 2 == 0 && C_END % 2 == 0 && DH % 2 == 0 && NB >= 8, "pairs of columns; 64 x 8 doubles of buffer");
+    int ln = lane;
+    asm volatile("" : "+v"(ln)); // (positions derived from the lane id are not hoisted out of the step loop: registers)
+    const int wsw = (ln >> 2) & 3;
+#pragma unroll
+    for (int c0 = C_BEGIN; c0 < C_END; c0 += 8) {
+        constexpr int kMax = 4;
+        const int np = ((C_END - c0) / 2 < kMax) ? (C_END - c0) / 2 : kMax; // pairs per row in this chunk (a constant once unrolled)
+#pragma unroll
+        for (int q = 0; q < kMax; ++q)
+            if (q < np) *reinterpret_cast<double2 *>(buf + ln * 8 + 2 * (q ^ wsw)) = make_double2(val(c0 + 2 * q), val(c0 + 2 * q + 1));
+#pragma unroll
+        for (int jj = 0; jj < kMax; ++jj) {
+            if (jj < np) {
+                const int pidx = ln + 64 * jj;
+                const int r = (np == 4) ? (pidx >> 2) : (np == 2) ? (pidx >> 1) : (np == 1) ? pidx : pidx / 3;
+                const int q = pidx - r * np;
+                const double2 v = *reinterpret_cast<const double2 *>(buf + r * 8 + 2 * (q ^ ((r >> 2) & 3)));
+                if (r < rows_live) *reinterpret_cast<double2 *>(&obase[(unsigned)(r * DH + c0 + 2 * q)]) = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the chunks apart: the next chunk's values are not computed (and held) early
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // player <-> bank hulls: collide_ship (game.py:232-241) for the 64 envs of a wave.  cpBBIntersects reject, then "closed
 // convex sets intersect" (GJK distance <= 0) evaluated as SAT over both polygons' edge normals: separated iff some axis
@@ -1299,7 +1335,10 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         // EARLY, while the body role still integrates — speculatively, because an env that turns out to be done at this step
         // shows a history of -1 instead (ShipEnv.reset); its lanes rewrite their 6 + NB doubles after the rendezvous.
         // (Only when the previous frame is a whole number of column passes: 8 and 10 beams are.)
-        constexpr bool kSplitOk = (F % ObsTile<NB>::CP) == 0;
+        // rows written with 16-byte LDS / global operations (write_obs_pairs; round 5: 5.36 -> 5.30 us per fused step, 14.1 -> 13.8 per
+        // one-step launch): even row lengths, and at least 8 beams for the 4 KiB the transposition needs
+        constexpr bool kPairs = (NB >= 8) && (NB % 2 == 0);
+        constexpr bool kSplitOk = kPairs || (F % ObsTile<NB>::CP) == 0;
         const bool split_last = kSplitOk && hist2 && c.history == 2 && !SSG_ABL(7);
         for (int k = 0; k < K; ++k) {
             const bool early = split_last && (k == K - 1);
@@ -1311,8 +1350,11 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
                     // the other parity's result buffer: emptied by this wave a step ago, written again only after B(k)
                     double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + ((k + 1) & 1) * lds_res_bytes(NB));
                     double *__restrict__ ob = obs + ((size_t)te0 + (size_t)k * (size_t)traj) * (size_t)(2 * F);
-                    write_obs_tile<NB, true, 0, F / ObsTile<NB>::CP>(ot, colbuf, [&](int j) -> double { return pv[(j < F) ? j : 0]; }, ob,
-                                                                    min(64, c.n_envs - te0), lane);
+                    if constexpr (kPairs)
+                        write_obs_pairs<NB, true, 0, F>(colbuf, [&](int j) -> double { return pv[(j < F) ? j : 0]; }, ob, min(64, c.n_envs - te0), lane);
+                    else
+                        write_obs_tile<NB, true, 0, F / ObsTile<NB>::CP>(ot, colbuf, [&](int j) -> double { return pv[(j < F) ? j : 0]; }, ob,
+                                                                        min(64, c.n_envs - te0), lane);
                 }
             }
             if constexpr (DYN) {
@@ -1426,14 +1468,25 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
                                 for (int j = 0; j < F; ++j) st_out(&obase[(unsigned)(lane * 2 * F + j)], -1.0);
                             }
                         }
-                        write_obs_tile<NB, true, kSplitOk ? F / ObsTile<NB>::CP : 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
-                            return nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
-                    } else if (hist2)
-                        write_obs_tile<NB, true, 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
-                            return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
-                            obase, rows_live, lane);
-                    else
-                        write_obs_tile<NB, false, 0, kObsPasses>(ot, colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
+                        if constexpr (kPairs)
+                            write_obs_pairs<NB, true, F, 2 * F>(colbuf, [&](int j) -> double { return nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
+                        else
+                            write_obs_tile<NB, true, kSplitOk ? F / ObsTile<NB>::CP : 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
+                                return nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
+                    } else if (hist2) {
+                        if constexpr (kPairs)
+                            write_obs_pairs<NB, true, 0, 2 * F>(colbuf, [&](int j) -> double {
+                                return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; }, obase, rows_live, lane);
+                        else
+                            write_obs_tile<NB, true, 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
+                                return (j < F) ? (do_reset ? -1.0 : pv[(j < F) ? j : 0]) : nv[(j < F) ? 0 : j - F]; },
+                                obase, rows_live, lane);
+                    } else {
+                        if constexpr (kPairs)
+                            write_obs_pairs<NB, false, 0, F>(colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
+                        else
+                            write_obs_tile<NB, false, 0, kObsPasses>(ot, colbuf, [&](int j) -> double { return nv[(j < F) ? j : 0]; }, obase, rows_live, lane);
+                    }
                 }
             }
             SSG_STAMP_K(7);
