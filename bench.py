@@ -25,7 +25,10 @@ TEST-ONLY overrides (tests/test_sharding_gpu.py; never set by the driver): SSG_B
 on device 0 and SSG_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on a 1-GPU box; the
 line's `data` field then says "TEST RUN ... timings meaningless".
 
-Timing: W untimed warm-up steps, then the K-step rollout is timed `--repeats` (default 5) times, every repeat
+Timing: an untimed, time-based device conditioning (`--precondition-ms`, default 300: launches of the same kernel on a SCRATCH env
+and scratch buffers, reported as `preconditioning_ms`; every trajectory buffer set is written once beforehand), then W untimed
+warm-up steps, then the K-step rollout is timed `--repeats` (default 5) times (`repeats_min_ms` / `repeats_median_ms` /
+`repeats_max_ms`, the shader clock probed in front of each repeat in `repeats_shader_clock_ghz`), every repeat
 bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's interval runs from the opening barrier + synchronize
 to its own closing synchronize; the closing barrier follows) and reduced with MAX over ranks; `value` is the
 MEDIAN repeat, all repeats are listed in `repeats_ms`.
@@ -318,23 +321,73 @@ def launch_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def timed_rollouts(vec, K, W, R, use_dist, dev):
-    """W untimed warm-up steps, then R timed repeats of exactly K trajectory-mode steps, each bracketed by barrier +
-    synchronize on both sides; returns (wall seconds per repeat, MAX over ranks; HIP-event ms per repeat; buffer sets)."""
+def shader_clock_probe(dev, buf):
+    """GHz of the shader clock under an FP64 VALU load, right now (ssg_debug_clock_probe: 1 024 workgroups x ~25 us of double
+    mul + add chains; s_memtime cycles over s_memrealtime's constant 100 MHz ticks, median over the workgroups).  Outside every
+    timed region: it tells whether the repeat that follows starts on a GPU that has left its idle clocks."""
+    import ctypes as C
+    import torch
+    from ship_sim_gym_amd import _native as N
+    N.check(N.lib().ssg_debug_clock_probe(C.c_void_p(buf.data_ptr()), 1024, 1500, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            None, "ssg_debug_clock_probe")
+    v = buf.view(1024, 2).to(torch.float64)
+    return float((v[:, 0] / v[:, 1].clamp(min=1.0)).median().item()) * 0.1
+
+
+def precondition(pvec, pacts, pout, min_ms, dev):
+    """Time-based device conditioning BEFORE the warm-up steps: the same kernel, in the same output mode, on a SCRATCH env and
+    scratch trajectory buffers for at least `min_ms` of wall time, so that the W warm-up steps and the timed repeats start on a
+    GPU at its loaded clocks instead of one still ramping up from idle (a 20-step launch is 150 us; BENCH_r05's five repeats
+    fell 206 -> 158 us while the box was waking up).  Nothing it touches is read or written by the timed region."""
+    import torch
+    if min_ms <= 0:
+        return 0.0, 0
+    pvec.reset_tensor()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(8):
+            pvec.rollout_tensor(pacts, trajectory=True, out=pout)
+            n += 1
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= min_ms:
+            break
+    return (time.perf_counter() - t0) * 1e3, n
+
+
+def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
+    """Device conditioning (untimed, scratch buffers), W untimed warm-up steps, then R timed repeats of exactly K trajectory-mode
+    steps, each bracketed by barrier + synchronize on both sides; returns (wall seconds per repeat, MAX over ranks; HIP-event ms
+    per repeat; buffer sets; shader clock GHz probed in front of every repeat; preconditioning info)."""
     import torch
     import torch.distributed as dist
     acts = vec.random_actions(12345, 0, W + K * R)  # int32 [W + R*K, n], generated on device before any timed region
     per_set = traj_bytes_per_step(vec.num_envs, vec.states_history) * K
     n_bufs = max(1, min(R, int(TRAJ_RING_BYTES // per_set)))
     bufs = traj_buffers(vec, K, n_bufs)  # distinct slots per repeat: a repeat never rewrites lines still in the Infinity Cache
+    for set_ in bufs:                     # pre-touch: no repeat is the first writer of its buffer set's pages
+        for t in set_:
+            t.zero_()
+    probe_buf = torch.zeros(2048, dtype=torch.int64, device=dev)
+    pre = {"preconditioning_ms": 0.0, "preconditioning_launches": 0}
+    if precondition_ms > 0 and pvec is not None:
+        kp = min(K, 100)
+        pacts = pvec.random_actions(4321, 0, kp)
+        pout = traj_buffers(pvec, kp, 1)[0]
+        ms, nl = precondition(pvec, pacts, pout, precondition_ms, dev)
+        pre = {"preconditioning_ms": ms, "preconditioning_launches": nl,
+               "preconditioning": "%d launches of %d steps of the same kernel on a scratch env and scratch trajectory buffers, "
+                                  "untimed, before the warm-up steps" % (nl, kp)}
     vec.reset_tensor()
     for w0 in range(0, W, K):  # warm-up: the same kernel in the same output mode (chunks of <= K steps into the first set)
         vec.rollout_tensor(acts[w0: min(W, w0 + K)], trajectory=True, out=bufs[0])
-    walls, evs = [], []
+    walls, evs, clocks = [], [], []
     for r in range(R):
         a = acts[W + r * K: W + (r + 1) * K]
         out = bufs[r % n_bufs]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        clocks.append(shader_clock_probe(dev, probe_buf))  # (untimed; ends with a device -> host read, i.e. a synchronize)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -355,7 +408,7 @@ def timed_rollouts(vec, K, W, R, use_dist, dev):
         walls = [float(v) for v in t.tolist()]
     del bufs, acts
     torch.cuda.empty_cache()
-    return walls, evs, n_bufs
+    return walls, evs, n_bufs, clocks, pre
 
 
 def main():
@@ -365,6 +418,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step rollout; value = the median")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--precondition-ms", type=float, default=300.0,
+                    help="untimed device conditioning before the warm-up steps: the same kernel on a scratch env and scratch buffers "
+                         "for at least this many ms of wall time (reported as preconditioning_ms; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true", help="skip the informational one-launch-per-step timing")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C4 timings")
@@ -452,7 +508,15 @@ def main():
     # the device-copy calibration runs BEFORE the timed region (it also brings the GPU out of its idle clocks; it is not a
     # step of the hot path and touches none of its buffers)
     copy_gbps = measured_copy_gbps(dev) if rank == 0 else None
-    walls, evs, n_bufs = timed_rollouts(vec, K, W, R, use_dist, dev)
+    # scratch env for the untimed device conditioning: same kernel instantiation, same bank, its own state and buffers
+    pvec = None
+    if args.precondition_ms > 0:
+        pvec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, env_id_base=rank * n,
+                          n_ships=4 if c4 else 1)
+    walls, evs, n_bufs, clocks, pre = timed_rollouts(vec, K, W, R, use_dist, dev, args.precondition_ms, pvec)
+    if pvec is not None:
+        pvec.close()
+        del pvec
     order = sorted(range(R), key=lambda i: walls[i])
     med = order[R // 2]
     wall, ev_ms = walls[med], evs[med]
@@ -472,7 +536,7 @@ def main():
         if use_dist:
             sharding.broadcast_bank(vec5, src=0)
         k5 = min(K, 500)
-        w5, e5, _ = timed_rollouts(vec5, k5, min(W, 100), 3, use_dist, dev)
+        w5, e5 = timed_rollouts(vec5, k5, min(W, 100), 3, use_dist, dev)[:2]
         m5 = sorted(w5)[1]
         B5 = algorithmic_bytes(1, 10, 2)
         c5_full = {"workload": "BASELINE configs[4]: %d envs = 131072 per rank x %d ranks, 1 ship, 10-beam lidar, trajectory outputs"
@@ -549,6 +613,13 @@ def main():
                                       "collective" % (world, world),
                        "ranks": ranks_info},
             "repeats": R, "repeats_ms": [w * 1e3 for w in walls], "timing": "median of %d repeats of the K-step rollout" % R,
+            # spread of the timed repeats (value = the median one), the shader clock probed in front of each (FP64 VALU load,
+            # s_memtime over the 100 MHz reference counter; rank 0) and the untimed device conditioning that preceded the warm-up
+            "repeats_min_ms": min(walls) * 1e3, "repeats_median_ms": wall * 1e3, "repeats_max_ms": max(walls) * 1e3,
+            "repeats_spread": (max(walls) - min(walls)) / wall,
+            "value_min": total_steps / max(walls), "value_max": total_steps / min(walls),
+            "repeats_event_ms": evs, "repeats_shader_clock_ghz": clocks,
+            "preconditioning_ms": pre["preconditioning_ms"], "preconditioning": pre.get("preconditioning"),
             "roofline": dict({"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS,
                               "frac_note": "SURVEY 8d's algorithmic bytes per env-step (single-step API with persistent state) over "

@@ -332,6 +332,12 @@ int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int 
  * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);
 
+/* Measurement aid (no reference counterpart): the shader clock under an FP64 VALU load.  n_blocks workgroups of 256 lanes run
+ * `iters` rounds of eight independent double mul + add chains; dev_out[2*b] = shader-clock cycles (s_memtime) and dev_out[2*b+1] =
+ * ticks of the constant 100 MHz reference counter (s_memrealtime) that workgroup b saw pass meanwhile: clock = 100 MHz x cycles /
+ * ticks.  bench.py logs it in front of every timed repeat, so that a repeat timed on a GPU still leaving its idle clocks shows. */
+int ssg_debug_clock_probe(uint64_t *dev_out, int n_blocks, int iters, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Host-side geometry (what pymunk's cffi exposed at reset time); no GPU needed.
  * ------------------------------------------------------------------------------------------------- */

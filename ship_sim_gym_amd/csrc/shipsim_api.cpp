@@ -1018,6 +1018,13 @@ int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, vo
     return ssg::launch_calib_copy8(dev_src, dev_dst, n_doubles, static_cast<hipStream_t>(stream)) == hipSuccess ? SSG_OK : SSG_ERR_HIP;
 }
 
+int ssg_debug_clock_probe(uint64_t *dev_out, int n_blocks, int iters, void *stream)
+{
+    if (!dev_out || n_blocks < 1 || iters < 1) return SSG_ERR_BAD_ARG;
+    return ssg::launch_clock_probe(reinterpret_cast<unsigned long long *>(dev_out), n_blocks, iters, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? SSG_OK : SSG_ERR_HIP;
+}
+
 // ---- host geometry ----
 int ssg_host_convex_hull(int count, const double *verts_xy, double *out_xy, int *out_count)
 {

@@ -188,6 +188,7 @@ hipError_t launch_dyn_reset(const DevCfg &c, const DynCfg &d, const uint8_t *mas
 hipError_t launch_render(const DevCfg &c, const DynCfg &d, int e, int width, int height, uint8_t *rgb, unsigned flags,
                          hipStream_t stream);
 hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStream_t stream);
+hipError_t launch_clock_probe(unsigned long long *out, int n_blocks, int iters, hipStream_t stream);
 hipError_t launch_remap_map_ids(const DevCfg &c, hipStream_t stream); // ICOL_MAP %= n_maps after the bank shrank
 hipError_t launch_history_shift(const DevCfg &c, const uint8_t *done, double *obs, hipStream_t stream);
 hipError_t launch_generate_bank(uint64_t seed, int n_maps, int n_goals, double width, double height, double width_frac,

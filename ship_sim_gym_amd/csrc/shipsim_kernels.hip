@@ -1923,6 +1923,31 @@ __global__ void calib_copy8_kernel(const double *__restrict__ src, double *__res
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Measurement aid: the shader clock under an FP64 VALU load.  Every workgroup runs `iters` rounds of eight independent
+// double mul+add chains per lane (what the step kernel's arithmetic is made of) and its first lane records how far the
+// shader-clock counter (s_memtime) and the constant 100 MHz reference counter (s_memrealtime) advanced meanwhile:
+// out[2*block] = shader cycles, out[2*block + 1] = reference ticks.  bench.py logs the clock in front of every timed repeat.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void clock_probe_kernel(unsigned long long *__restrict__ out, int iters, double seed)
+{
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = seed + (double)(threadIdx.x + j);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = a[j] * 0.999999 + 1.0e-6;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j];
+    asm volatile("" : "+v"(s));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+    if (s == 1.2345e300) out[0] = 0; // (keeps the chains alive)
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // counter-based action stream: Philox4x32-10, counter = (env_lo, env_hi, step_lo, step_hi), key = seed
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], const uint32_t (&key)[2])
@@ -2090,6 +2115,12 @@ hipError_t launch_calib_copy8(const double *src, double *dst, size_t n, hipStrea
 {
     const int block = 256;
     hipLaunchKernelGGL(calib_copy8_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_clock_probe(unsigned long long *out, int n_blocks, int iters, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, out, iters, 1.0);
     return hipGetLastError();
 }
 
