@@ -277,6 +277,77 @@ def c4_policy_in_the_loop(dev, n, host_reset, ks=300):
             "full_cpSpaceSteps": steps, "queue_rebuilds": rebuilds}
 
 
+def vecenv_numpy_path(dev, n, n_beams, ks=300):
+    """The SB / RLlib-facing numpy protocol (train/stable_baselines/ppo.py:122-123: `env.step(actions)` on host arrays): per step,
+    actions host -> device, ONE ssg_step, ONE device -> host copy of the packed obs | reward | done | flags block into pinned memory
+    (ShipVecEnv.step_async / step_wait).  Wall time per step over `ks` steps (median of 5), next to the PCIe bound of the same
+    bytes: the block's device -> host copy and the actions' host -> device copy timed alone on this box."""
+    import numpy as np
+    import torch
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams)
+    acts = vec.random_actions(31337, 0, ks).cpu().numpy().astype(np.int64)  # what a host-side policy hands over
+    rows = [acts[k] for k in range(ks)]
+    vec.reset()
+    for a in rows[:20]:
+        vec.step(a)
+    reps = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for a in rows:
+            vec.step_async(a)
+            vec.step_wait()
+        reps.append((time.perf_counter() - t0) / ks)
+    per_step = sorted(reps)[2]
+    # the PCIe bound of exactly these bytes: the two copies alone, HIP events, pinned memory, best of 7
+    hs = vec._host_side()
+    blk, hact = hs["blocks"][0], hs["acts"]
+    best_d2h = best_h2d = 1e9
+    for _ in range(7):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize()
+        e0.record(); blk.copy_(vec._out_blob, non_blocking=True); e1.record(); vec._actions.copy_(hact, non_blocking=True); e2.record()
+        torch.cuda.synchronize()
+        best_d2h, best_h2d = min(best_d2h, e0.elapsed_time(e1) * 1e-3), min(best_h2d, e1.elapsed_time(e2) * 1e-3)
+    bytes_down = n * (8 * vec.states_history + 8 + 1 + 1)
+    bound = n / (best_d2h + best_h2d)
+    out = {"envs": n, "n_beams": n_beams, "steps": ks, "us_per_step": per_step * 1e6, "env_steps_per_s": n / per_step,
+           "repeats_us": [r * 1e6 for r in reps],
+           "bytes_per_env_step": {"device_to_host": bytes_down / n, "host_to_device": 4},
+           "pcie_bound": {"env_steps_per_s": bound, "d2h_us": best_d2h * 1e6, "h2d_us": best_h2d * 1e6,
+                          "d2h_GBps": vec._out_nbytes / best_d2h / 1e9,
+                          "method": "the packed output block's device -> host copy and the actions' host -> device copy alone, "
+                                    "pinned memory, HIP events, best of 7"},
+           "frac_of_pcie_bound": (n / per_step) / bound,
+           "path": "ShipVecEnv.step_async (pinned actions -> H2D, ssg_step, one D2H of the packed block, side stream) + step_wait "
+                   "(event wait, numpy views of the pinned block)"}
+    vec.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def ppo_end_to_end(dev, n, single_step_us, updates=4, horizon=32):
+    """An end-to-end training rate (the reference prints steps per minute, train/stable_baselines/ppo.py:86-96): train/ppo_torch.py —
+    a GPU-resident PPO loop, one env step per policy forward — at `n` envs, with its rollout step launched eagerly, captured as ONE
+    HIP graph {policy forward + sampling + ssg_step + buffer writes}, and as two half-batch graphs ping-ponging on two streams.
+    `env_share_of_rollout` = the env's own one-launch-per-step time (single_step_launch_us) over the rollout's time per step."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("ppo_torch", os.path.join(ROOT, "train", "ppo_torch.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = {"envs": n, "horizon": horizon, "updates": updates, "policy": "MLP 28-64-64-(3+1), fp32, Adam, 2 epochs x 4 minibatches per update",
+           "env_single_step_launch_us": single_step_us}
+    for mode in ("eager", "graph", "pingpong"):
+        mod.train(envs=n, updates=1, horizon=horizon, log=lambda s: None, mode=mode, device=str(dev))  # (first-use costs: hipBLASLt, allocator)
+        hist, det = mod.train(envs=n, updates=updates, horizon=horizon, log=lambda s: None, mode=mode, device=str(dev), return_details="timing")
+        out[mode] = {"rollout_env_steps_per_s": det["rollout_env_steps_per_s"], "rollout_us_per_step": det["rollout_us_per_step"],
+                     "training_env_steps_per_s": det["training_env_steps_per_s"],
+                     "env_share_of_rollout": (single_step_us / det["rollout_us_per_step"]) if single_step_us else None}
+        del det
+        torch.cuda.empty_cache()
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -680,6 +751,11 @@ def main():
                 other["c4_fresh_world_per_episode"]["ring"] = 32
                 other["c4_single_step_auto_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=False)
                 other["c4_host_masked_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=True)
+                # the numpy protocol stable-baselines / RLlib callers use, next to its PCIe bound
+                other["vecenv_numpy_path"] = {"65536_envs_8_beams": vecenv_numpy_path(dev, 65536, 8),
+                                              "4096_envs_10_beams": vecenv_numpy_path(dev, 4096, 10)}
+                # an end-to-end PPO loop over the zero-copy API: eager / HIP graph / two-half-batch ping-pong
+                other["ppo_torch_end_to_end"] = ppo_end_to_end(dev, n, out.get("single_step_launch_us"))
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
                 # the headline's envs on a bank of 120 records, which the LDS only holds beside 64-env workgroups (four rounds per
                 # launch): gathered from L2 on 256-env workgroups instead (ssg_set_map_bank weighs the two)

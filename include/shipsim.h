@@ -155,7 +155,8 @@ typedef enum ssg_field {
     SSG_F_EPISODES,     /* i32: episodes this env has started so far (every reset counts; in map_ring mode episode p lives in
                            bank record e*R + p mod R) */
     SSG_F_DYN_MEMO_STATS, /* i64 [256 slots][16], n_ships == 4 only, to be summed over slots: [0] cpSpaceSteps answered by the memo
-                           table, [1] computed, [2] results stored, — inspection only.  No reference counterpart: Chipmunk steps
+                           table, [1] computed, [2] results stored, [3] / [4] cpCollide(traffic ship, bank hull) answered by the narrowphase memo / computed
+                           ([5..15] unused) — inspection only.  No reference counterpart: Chipmunk steps
                            every space every time (game.py:194).  In bank mode (shared worlds, <= 64 records) the traffic ships
                            and goal bodies of thousands of envs pass through the SAME states after every reset — cpSpaceStep of
                            those bodies is a pure function of their cpBody fields, the cached arbiters and the bank record (the

@@ -745,7 +745,12 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
     // resets its done envs this way after every step; rebuilding the queue from the per-env flags instead — memset + the classify
     // pass over every env — cost the next step 12-19 us).  One such reset per step: every env then has at most one entry per sort
     // bucket, which is what a bucket's n_pad slots hold; a second one, a full reset, or a queue that is not there rebuild it.
-    const bool append = h->cfg.n_ships > 1 && dev_mask && h->dyn_queue_valid && h->masked_resets_since_step == 0;
+    // Only where the full step runs its one-record-per-wave kernel (shared banks of at most kDynMapBuckets records): that kernel
+    // drops an entry queued under another record than the env now sits on, and a record IS its map bucket there.  The per-lane-planes
+    // kernel (larger banks, map_ring) cannot tell a stale entry from the new one — both would be stepped, by different waves,
+    // i.e. an env's bodies could advance twice in one step — so those handles rebuild the queue after any reset.
+    const bool dyn_uni = h->cfg.map_ring == 0 && h->n_maps <= ssg::kDynMapBuckets;
+    const bool append = h->cfg.n_ships > 1 && dev_mask && h->dyn_queue_valid && h->masked_resets_since_step == 0 && dyn_uni;
     if (append) h->masked_resets_since_step = 1;
     else h->dyn_queue_valid = false;
     hipError_t e;
@@ -819,11 +824,20 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
         // kernel, which reads this step's goal positions and the traffic-contact bit it left in the dyn columns.
         const bool shift = h->cfg.history > 2;
         if (h->cfg.map_ring > 0 && !h->ring_ready) return fail(h, SSG_ERR_NOT_BOUND, "map_ring mode: call ssg_refill_worlds first");
-        std::vector<hipEvent_t> evs; // measurement aid: three events per step (before the full cpSpaceStep, between, after the step kernel)
-        if (dyn && h->time_kernels) {
-            evs.resize(3 * (size_t)K);
-            for (auto &ev : evs) (void)hipEventCreate(&ev);
-        }
+        // measurement aid: three events per step (before the full cpSpaceStep, between, after the step kernel); destroyed on every
+        // way out of this call, and no timing at all if one of them cannot be created
+        struct EventSet {
+            std::vector<hipEvent_t> v;
+            bool empty() const { return v.empty(); }
+            hipEvent_t operator[](size_t i) const { return v[i]; }
+            void create(size_t n) {
+                v.reserve(n);
+                for (size_t i = 0; i < n; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { clear(); return; } v.push_back(ev); }
+            }
+            void clear() { for (auto ev : v) (void)hipEventDestroy(ev); v.clear(); }
+            ~EventSet() { clear(); }
+        } evs;
+        if (dyn && h->time_kernels) evs.create(3 * (size_t)K);
         for (int k = 0; k < K; ++k) {
             if (!evs.empty()) (void)hipEventRecord(evs[3 * k], static_cast<hipStream_t>(stream));
             if (h->cfg.map_ring > 0) { // every step may start one episode per env: keep an unused world in every ring
@@ -879,7 +893,6 @@ int ssg_rollout_traj(ssg_handle *h, const int32_t *dev_actions, int K, double *d
                 (void)hipEventElapsedTime(&b, evs[3 * k + 1], evs[3 * k + 2]);
                 h->t_dyn_ms += a; h->t_step_ms += b; h->t_steps++;
             }
-            for (auto &ev : evs) (void)hipEventDestroy(ev);
         }
         return SSG_OK;
     }
@@ -967,6 +980,10 @@ int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream)
     if (rc != SSG_OK) return rc;
     if (h->cfg.n_ships <= 1) return SSG_OK; // nothing to wake
     h->dyn_queue_valid = false;
+    if (!dev_mask) { // "the blob may have been copied or restored": its memo tables may hold another bank's / handle's results under
+        memo_new_generation(h);        // this handle's generation (the key names the record, not the bank's contents), so they are
+        h->memo_clear_pending = true;  // emptied before the next launch that could read them
+    }
     hipError_t e = ssg::launch_dyn_invalidate(h->dev, dev_mask, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("dyn_invalidate launch: ") + hipGetErrorString(e));
     return SSG_OK;

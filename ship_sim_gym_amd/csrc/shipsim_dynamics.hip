@@ -845,6 +845,8 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
     // fetched where cpArbiterUpdate needs them (push(), below; the ageing loop after the narrowphase) each was a dependent
     // L2 / HBM round trip in the middle of the collide phase — 8 k cycles of a wave's chain with two arbiters.
     constexpr int kPre = 4;
+    static_assert(kPre == kMemoArbIn, "the memo key holds exactly the cached arbiters that are prefetched here");
+    static_assert(kMaxActive <= kMemoArbOut, "the memo value has one slot per arbiter the solver's list can hold");
     int ppid[kPre];
     unsigned pmeta[kPre], phh[kPre];
     double pacc[kPre][4];
@@ -1310,6 +1312,10 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
 #pragma unroll
                 for (int i = 0; i < kMemoValShipWords / 2; ++i) { sw[k][2 * i] = vb[1 + (kMemoValShipWords / 2) * k + i].x; sw[k][2 * i + 1] = vb[1 + (kMemoValShipWords / 2) * k + i].y; }
             hit = diff == 0ull;
+            // the value's counts index fixed-size sections of the entry and of this env's columns: an entry whose header is
+            // not one this kernel could have written (the blob is the caller's) counts as a miss
+            const unsigned vh0 = (unsigned)vh.x;
+            hit &= ((vh0 >> 8) & 0xFFu) <= (unsigned)kMemoArbOut && ((vh0 >> 16) & 0xFFu) <= (unsigned)kMemoAged;
         }
         {   // statistics (how often the table answers), spread over slots, fire and forget
             const u64 mh = __ballot(hit), mm = __ballot(!hit);
@@ -1376,6 +1382,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
                 else { a0 = ld2(kMemoValArbs + kMemoArbWords * i); a1 = ld2(kMemoValArbs + kMemoArbWords * i + 2); a2 = ld2(kMemoValArbs + kMemoArbWords * i + 4); }
                 const u64 pk = a0.x;
                 const int pid = (int)(pk & 0xFFull);
+                if (pid >= kDynPairs) continue; // (never written by this kernel; see the header check above)
                 col.u32[(size_t)(DU_META + pid) * np + e] = (unsigned)((pk >> 8) & 0xFFull);
                 if (pid < kPolyPairs) col.u32[(size_t)(DU_HASH + pid) * np + e] = (unsigned)(pk >> 32);
                 double *acc = col.f64 + (size_t)(DC_ARB + 4 * pid) * np + e;
@@ -1383,6 +1390,7 @@ __global__ __launch_bounds__(64) void dyn_step_kernel(const DevCfg c, const DynC
             }
             for (int i = 0; i < n_aged; ++i) { // cached arbiters that aged this step
                 const u64 pk = ent[ME_VAL + kMemoValAged + i];
+                if ((int)(pk & 0xFFull) >= kDynPairs) continue;
                 col.u32[(size_t)(DU_META + (int)(pk & 0xFFull)) * np + e] = (unsigned)((pk >> 8) & 0xFFull);
             }
             col.live[e] = live_out;

@@ -102,7 +102,7 @@ constexpr int kMemoProbes = 4;
 // value = count | contact hashes, normal, p1[2], p2[2].
 constexpr int kNpmEntries = 1 << 14, kNpmProbes = 2;
 enum { NE_KEY = 4, NE_VAL = NE_KEY + 6, kNpmStride = NE_VAL + 12 };
-constexpr int kMemoStatSlots = 256, kMemoStatWords = 16; // per workgroup slot: [0] hits [1] misses [2] inserts [3] not memoisable
+constexpr int kMemoStatSlots = 256, kMemoStatWords = 16; // per workgroup slot: [0] hits [1] computed [2] results stored [3] / [4] ship x bank narrowphase memo: hits / computed; [5..15] unused
 static_assert(ME_KEY % 2 == 0 && ME_VAL % 2 == 0 && kMemoStride % 2 == 0, "16-byte loads of key and value");
 constexpr int kPadEnvs = 256;   // columns are padded to a multiple of this many envs
 constexpr int kStatsSlots = 256;   // per-workgroup-slot i64 counters: [0] sum_return*100 [1] sum_length [2] episodes [3] goals hit

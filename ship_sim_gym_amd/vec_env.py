@@ -104,7 +104,7 @@ class ShipVecEnv(*_BASES):
     def __init__(self, num_envs, game_config=None, env_config=None, device="cuda:0", map_mode="bank", n_maps=64,
                  map_seed=1000, width_frac=0.5, env_id_base=0, auto_reset=True, n_beams=None, bank=None,
                  fix_collision_reward=False, bank_in_global=False, exact_lidar=False, n_ships=1, rllib=False, ring=32,
-                 dyn_memo=True):
+                 dyn_memo=True, host_slots=4, copy_host_outputs=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise N.ShipSimError("ShipVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -177,13 +177,22 @@ class ShipVecEnv(*_BASES):
         N.check(L.ssg_create(C.byref(c), C.byref(self._h)), None, "ssg_create")
         nbytes = C.c_size_t()
         N.check(L.ssg_state_nbytes(self._h, C.byref(nbytes)), self._h, "ssg_state_nbytes")
+        # obs | reward | done | flags are views of ONE device block (256-byte aligned sections), so that the numpy protocols
+        # (SB VecEnv / RLlib VectorEnv) bring a whole step to the host with ONE device -> host copy into a pinned block
+        n_, D_ = self.num_envs, self.states_history
+        up = lambda v: (v + 255) // 256 * 256
+        self._o_obs, self._o_rew = 0, up(n_ * D_ * 8)
+        self._o_done = self._o_rew + up(n_ * 8)
+        self._o_flags = self._o_done + up(n_)
+        self._out_nbytes = self._o_flags + up(n_)
+        self.host_slots = max(2, int(host_slots))
+        self.copy_host_outputs = bool(copy_host_outputs)
         with torch.cuda.device(self.device):
             self.state = torch.zeros(nbytes.value, dtype=torch.uint8, device=self.device)
-            self.obs = torch.empty((self.num_envs, self.states_history), dtype=torch.float64, device=self.device)
-            self.reward = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
-            self.done = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
-            self.flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+            self._out_blob = torch.zeros(self._out_nbytes, dtype=torch.uint8, device=self.device)
+            self.obs, self.reward, self.done, self.flags = self._blob_views(self._out_blob)
             self._actions = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self._host = None  # pinned host side of the numpy protocols, made by the first step_async (the tensor API never needs it)
         N.check(L.ssg_bind_state(self._h, C.c_void_p(self.state.data_ptr())), self._h, "ssg_bind_state")
 
         # ---- map bank ----
@@ -257,6 +266,29 @@ class ShipVecEnv(*_BASES):
     # ------------------------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _blob_views(self, blob):
+        """(obs [N, D] f64, reward [N] f64, done [N] u8, flags [N] u8) views of an output block (device or pinned host)."""
+        torch = _torch()
+        n, D = self.num_envs, self.states_history
+        return (blob[self._o_obs: self._o_obs + n * D * 8].view(torch.float64).view(n, D),
+                blob[self._o_rew: self._o_rew + n * 8].view(torch.float64),
+                blob[self._o_done: self._o_done + n], blob[self._o_flags: self._o_flags + n])
+
+    def _host_side(self):
+        """The host half of the numpy protocols, made once: `host_slots` pinned output blocks (rotated, so that the arrays of
+        one step stay valid while the next steps run), a pinned action buffer, a side stream and one event per slot."""
+        if self._host is None:
+            torch = _torch()
+            with torch.cuda.device(self.device):
+                blocks = [torch.empty(self._out_nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(self.host_slots)]
+                acts = torch.empty(self.num_envs, dtype=torch.int32, pin_memory=True)
+                self._host = {"blocks": blocks,
+                              "np": [tuple(v.numpy() for v in self._blob_views(b)) for b in blocks],
+                              "acts": acts, "acts_np": acts.numpy(), "stream": torch.cuda.Stream(device=self.device),
+                              "events": [torch.cuda.Event() for _ in range(self.host_slots)], "slot": 0, "inflight": None,
+                              "infos": [{} for _ in range(self.num_envs)]}
+        return self._host
 
     def _fresh_world(self, e):
         rec, polys, goals = worldgen.generate_world(self.bounds, n_goals=self.cfg.n_goals, width_frac=self.width_frac)
@@ -395,9 +427,7 @@ class ShipVecEnv(*_BASES):
         computed (`computed`), results stored (`stored`); SSG_F_DYN_MEMO_STATS."""
         s = self.field(N.F_DYN_MEMO_STATS).sum(dim=0).cpu().numpy()
         return {"hits": int(s[0]), "computed": int(s[1]), "stored": int(s[2]),
-                "ship_x_bank_narrowphase": {"hits": int(s[3]), "computed": int(s[4])},
-                "not_stored": {"not_memoisable_or_tag_collision": int(s[5]), "no_free_entry": int(s[6]), "too_many_aged": int(s[7])},
-                "computed_by_age_bucket": [int(v) for v in s[8:16]]}
+                "ship_x_bank_narrowphase": {"hits": int(s[3]), "computed": int(s[4])}}
 
     def stats(self):
         """Per-handle episode counters accumulated in-kernel: sum_return, sum_length, episodes, goals_hit."""
@@ -435,7 +465,8 @@ class ShipVecEnv(*_BASES):
         This is the policy-in-the-loop path: one launch per call, so the host side is kept to one ctypes call with plain
         integers (the cached output pointers, the actions' address, the current stream's handle)."""
         # (a tensor of another dtype / size would be read as int32 [N] all the same: wrong steps, or a read past its end)
-        if actions.dtype is not self._i32 or actions.numel() != self.num_envs or not actions.is_cuda or not actions.is_contiguous():
+        if (actions.dtype is not self._i32 or actions.numel() != self.num_envs or actions.device != self.device
+                or not actions.is_contiguous()):
             raise ValueError("step_tensor: actions must be a contiguous int32 device tensor of %d elements (got %s %s on %s)"
                              % (self.num_envs, actions.dtype, tuple(actions.shape), actions.device))
         hot = self.__dict__.get("_hot")
@@ -462,8 +493,8 @@ class ShipVecEnv(*_BASES):
         rollout loop sees them (train/random.py:14-27) — returns (obs [K, N, D], reward [K, N], done [K, N], flags [K, N])
         device tensors; `out` = a tuple of four such preallocated tensors (first dimension >= K, contiguous) to write
         into instead of allocating.  self.obs / reward / done / flags are left untouched in trajectory mode."""
-        if (actions_kn.dtype is not self._i32 or actions_kn.dim() != 2 or actions_kn.shape[1] != self.num_envs or not actions_kn.is_cuda
-                or not actions_kn.is_contiguous()):
+        if (actions_kn.dtype is not self._i32 or actions_kn.dim() != 2 or actions_kn.shape[1] != self.num_envs
+                or actions_kn.device != self.device or not actions_kn.is_contiguous()):
             raise ValueError("rollout_tensor: actions must be a contiguous int32 device tensor [K, %d] (got %s %s on %s)"
                              % (self.num_envs, actions_kn.dtype, tuple(actions_kn.shape), actions_kn.device))
         if trajectory and out is not None:
@@ -546,17 +577,46 @@ class ShipVecEnv(*_BASES):
         return self.reset_tensor().cpu().numpy()
 
     def step_async(self, actions):
+        """VecEnv.step_async: checks the actions, then LAUNCHES the step — actions host -> device from a pinned buffer, ssg_step,
+        and ONE device -> host copy of the packed obs | reward | done | flags block into a pinned host block, all on a side
+        stream — and returns at once: the step runs while the caller does whatever it does between step_async and step_wait."""
         a = np.asarray(actions)
         # ship_env.py:143 `assert self.action_space.contains(action)` for the whole batch in one range check
         ok = a.dtype.kind in "iu" and a.size == self.num_envs and bool(np.all((a >= 0) & (a < self.action_space.n)))
         assert ok, "%r (%s) invalid" % (a, a.dtype)
         self._pending = a.astype(np.int32).reshape(self.num_envs)
+        if self._closed:
+            return
+        torch = _torch()
+        hs = self._host_side()
+        np.copyto(hs["acts_np"], self._pending)
+        slot = hs["slot"]
+        io = hs["stream"]
+        io.wait_stream(torch.cuda.current_stream(self.device))  # after whatever the tensor API queued (a reset, say)
+        with torch.cuda.stream(io):
+            self._actions.copy_(hs["acts"], non_blocking=True)
+            self.step_tensor(self._actions)
+            hs["blocks"][slot].copy_(self._out_blob, non_blocking=True)
+            hs["events"][slot].record(io)
+        hs["inflight"] = slot
+        hs["slot"] = (slot + 1) % self.host_slots
 
     def step_wait(self):
+        """VecEnv.step_wait: waits for the event behind step_async's device -> host copy and returns numpy views of that pinned
+        block — obs [N, D] float64, rewards [N], dones [N] bool — plus a reused list of N empty info dicts.  The observation
+        array is a view of one of `host_slots` rotating blocks: it stays valid until `host_slots - 1` further steps have been
+        taken (stable-baselines' runners copy it into their own buffer at once: `self.obs[:] = obs`); rewards and dones are
+        fresh small arrays (runners keep them in lists).  `copy_host_outputs=True` returns a fresh observation array too."""
         torch = _torch()
-        self._actions.copy_(torch.from_numpy(self._pending))
-        obs, rew, done, flags = self.step_tensor(self._actions)
-        done_h = done.cpu().numpy().astype(bool)
+        hs = self._host_side()
+        slot = hs["inflight"]
+        if slot is None:
+            raise N.ShipSimError("step_wait without a step_async")
+        hs["inflight"] = None
+        hs["events"][slot].synchronize()
+        torch.cuda.current_stream(self.device).wait_stream(hs["stream"])  # later tensor-API calls see this step
+        obs_h, rew_h, done_u8, _ = hs["np"][slot]
+        done_h = done_u8.view(np.bool_).copy()
         if self.map_mode == "fresh" and self.auto_reset and done_h.any():
             # host-side auto-reset with brand-new worlds (reference-exact resets)
             for e in np.nonzero(done_h)[0]:
@@ -565,9 +625,9 @@ class ShipVecEnv(*_BASES):
             mask = torch.from_numpy(done_h.astype(np.uint8)).to(self.device)
             ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
             self.reset_tensor(mask=mask, map_ids=ids)
+            obs_h[done_h] = self.obs[mask.bool()].cpu().numpy()  # (the reset observations replace the terminal ones)
             torch.cuda.current_stream(self.device).synchronize()
-        infos = [{} for _ in range(self.num_envs)]
-        return obs.cpu().numpy(), rew.cpu().numpy(), done_h, infos
+        return (obs_h.copy() if self.copy_host_outputs else obs_h), rew_h.copy(), done_h, hs["infos"]
 
     def step(self, actions):
         self.step_async(actions)
@@ -575,6 +635,13 @@ class ShipVecEnv(*_BASES):
 
     def close(self):
         self.__dict__.pop("_traj_plans", None)
+        hs = self.__dict__.get("_host")
+        if hs is not None:
+            try:
+                hs["stream"].synchronize()  # a step_async still in flight reads and writes the buffers about to go
+            except Exception:
+                pass
+            self._host = None
         if not self._closed and self._h:
             N.lib().ssg_destroy(self._h)
             self._h = None
@@ -711,16 +778,21 @@ class ShipVecEnv(*_BASES):
         self._await_reset |= done_h
 
     def vector_step(self, actions):
+        """VectorEnv.vector_step.  Returns (obs, rewards, dones, infos) as SEQUENCES of per-env items: numpy arrays [N, D] /
+        [N] / [N] — RLlib's own adapter only enumerates them (`dict(enumerate(self.new_obs))`), and a per-row `list()` of 65 536
+        rows costs more than the step — and the reused list of info dicts.  The observation array is a fresh copy: RLlib's
+        sample builders keep the rows by reference."""
         if not self.rllib:
             obs, rew, done, infos = self.step(np.asarray(actions))
-            return list(obs), list(rew), list(done), infos
+            return (obs if self.copy_host_outputs else obs.copy()), rew, done, infos
         if self._await_reset.any():
             raise N.ShipSimError("vector_step: envs %r were reported done and have not been reset_at()"
                                  % (np.nonzero(self._await_reset)[0][:8].tolist(),))
         obs, rew, done, infos = self.step(np.asarray(actions))  # no auto-reset: obs rows of done envs are terminal
+        obs = obs if self.copy_host_outputs else obs.copy()
         if done.any():
             self._reset_done_envs(done)
-        return list(obs), list(rew), list(done), infos
+        return obs, rew, done, infos
 
     def get_unwrapped(self):
         """VectorEnv.get_unwrapped: the underlying envs, as per-env handles."""

@@ -563,6 +563,46 @@ def test_vec_env_protocols(torch_cuda, native):
         _vec(4, env_config=E)
 
 
+def test_numpy_protocol_is_the_tensor_path_through_pinned_blocks(torch_cuda, native):
+    """step_async LAUNCHES (pinned actions -> device, ssg_step, one device -> host copy of the packed obs | reward | done | flags
+    block, side stream), step_wait waits on the event and hands out numpy views of a rotating pinned block: every step equals the
+    tensor API's on a twin env, an array handed out stays intact for host_slots - 1 further steps, tensor-API calls between
+    numpy steps are ordered with them, and copy_host_outputs=True returns arrays nobody rewrites."""
+    import torch
+    n = 4096
+    a_env, b_env = _vec(n, n_maps=8), _vec(n, n_maps=8)
+    c_env = _vec(n, n_maps=8, copy_host_outputs=True, host_slots=2)
+    assert a_env.obs.data_ptr() == a_env._out_blob.data_ptr() and a_env.obs.is_contiguous()
+    np.testing.assert_array_equal(a_env.reset(), b_env.reset_tensor().cpu().numpy())
+    c_env.reset()
+    acts = b_env.random_actions(2024, 0, 60)
+    acts_h = acts.cpu().numpy()
+    held, kept = [], []
+    for k in range(60):
+        a_env.step_async(acts_h[k].astype(np.int64))
+        want = [t.cpu().numpy() for t in b_env.step_tensor(acts[k])]      # (the other env steps while a's step is in flight)
+        o, r, d, infos = a_env.step_wait()
+        np.testing.assert_array_equal(o, want[0]); np.testing.assert_array_equal(r, want[1])
+        np.testing.assert_array_equal(d, want[2].astype(bool))
+        assert d.dtype == np.bool_ and len(infos) == n and infos[0] == {}
+        held.append((o, want[0]))
+        for oo, ww in held[-(a_env.host_slots - 1):]:                     # views of the last host_slots - 1 steps are intact
+            np.testing.assert_array_equal(oo, ww)
+        oc, rc, dc, _ = c_env.step(acts_h[k])
+        kept.append((oc, want[0]))
+        if k == 30:                                                       # a tensor-API call between two numpy steps
+            m = torch.zeros(n, dtype=torch.uint8, device=a_env.device); m[:100] = 1
+            ids = (a_env.field(native.F_MAP_ID) + 1) % a_env.n_maps
+            a_env.reset_tensor(mask=m, map_ids=ids.to(torch.int32).contiguous())
+            b_env.reset_tensor(mask=m.clone(), map_ids=(b_env.field(native.F_MAP_ID) + 1).remainder(b_env.n_maps).to(torch.int32).contiguous())
+            c_env.reset_tensor(mask=m.clone(), map_ids=(c_env.field(native.F_MAP_ID) + 1).remainder(c_env.n_maps).to(torch.int32).contiguous())
+    for oc, ww in kept:                                                   # fresh arrays: all 60 still what they were
+        np.testing.assert_array_equal(oc, ww)
+    with pytest.raises(native.ShipSimError):
+        a_env.step_wait()                                                 # no step in flight
+    a_env.close(); b_env.close(); c_env.close()
+
+
 @pytest.mark.parametrize("hist", [2, 3])
 def test_rllib_flow_terminal_obs_and_single_reset(torch_cuda, native, hist):
     """RLlib VectorEnv flow (train/rllib/ppo.py:21-24,43): vector_step returns the TERMINAL observation of a done env,
@@ -780,17 +820,55 @@ def test_reference_random_rollout_configuration(torch_cuda, oracle, native, n_sh
     w.close()
 
 
-def test_trainer_glue_runs_end_to_end(torch_cuda, native):
-    """SURVEY §8f rank 1: a GPU-resident PPO loop (train/ppo_torch.py) drives ShipVecEnv through the zero-copy
-    tensor API for a few updates: finite losses/returns, episodes accumulate, policy-in-the-loop stepping works."""
+def _ppo_mod():
     import importlib.util, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("ppo_torch", os.path.join(root, "train", "ppo_torch.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def test_trainer_glue_runs_end_to_end(torch_cuda, native):
+    """SURVEY §8f rank 1: a GPU-resident PPO loop (train/ppo_torch.py) drives ShipVecEnv through the zero-copy
+    tensor API for a few updates: finite losses/returns, episodes accumulate, policy-in-the-loop stepping works — and the rollout
+    step captured as ONE HIP graph {policy forward + sampling + ssg_step + buffer writes} replays bit for bit what the eager loop
+    launches kernel by kernel (train/stable_baselines/ppo.py:84-100,122-123 is the loop being replaced): every rollout buffer of
+    every update, the env state at the end, and the trained parameters."""
+    import torch
+    mod = _ppo_mod()
     lines = []
-    hist = mod.train(envs=1024, updates=3, horizon=32, log=lines.append)
+    hist, ref = mod.train(envs=1024, updates=3, horizon=32, log=lines.append, mode="eager", return_details=True)
     assert len(hist) == 3 and all(np.isfinite(h[1]) and np.isfinite(h[3]) for h in hist)
     assert "env-steps/s" in lines[-1]
+    assert ref["snapshots"][0]["done"].sum() > 0                       # episodes ended (and were reset in-kernel) inside the rollouts
+    hist_g, got = mod.train(envs=1024, updates=3, horizon=32, log=lines.append, mode="graph", return_details=True)
+    assert hist_g == hist
+    for u in range(3):
+        for k, v in ref["snapshots"][u].items():
+            assert torch.equal(v, got["snapshots"][u][k]), (u, k)
+    assert torch.equal(ref["final_state"][0], got["final_state"][0])
+    for a, b in zip(ref["params"], got["params"]):
+        assert torch.equal(a, b)
+
+
+def test_trainer_glue_ping_pong_halves(torch_cuda, native):
+    """The two-half-batch ping-pong (half A's env step on one stream while half B's policy forward runs on another, one HIP graph
+    each): the halves are shards of the same batch (global env ids), so replaying the actions it took through ONE unsplit env
+    reproduces its observations, rewards and dones exactly."""
+    import torch
+    mod = _ppo_mod()
+    from ship_sim_gym_amd.vec_env import ShipVecEnv
+    n, H = 2048, 24
+    hist, got = mod.train(envs=n, updates=1, horizon=H, log=lambda s: None, mode="pingpong", return_details=True)
+    snap = got["snapshots"][0]
+    env = ShipVecEnv(n, n_maps=64)
+    obs = env.reset_tensor()
+    scale = float(max(env.bounds))
+    for t in range(H):
+        assert torch.equal((obs / scale).float(), snap["obs"][t]), t
+        obs, rew, done, _ = env.step_tensor(snap["act"][t].to(torch.int32))
+        assert torch.equal(rew.float(), snap["rew"][t]) and torch.equal(done.float(), snap["done"][t]), t
+    env.close()
 
 
 def test_device_bank_generation_matches_host_geometry(torch_cuda, oracle, native):

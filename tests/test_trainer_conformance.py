@@ -103,6 +103,7 @@ class _Stub(object):
         v._await_reset = np.zeros(n, dtype=bool)
         v._reset_obs_h = None
         v._closed, v._h = True, None
+        v.copy_host_outputs, v.host_slots, v._host = False, 4, None
         v.calls = []
         return v
 
