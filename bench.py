@@ -25,10 +25,11 @@ TEST-ONLY overrides (tests/test_sharding_gpu.py; never set by the driver): SSG_B
 on device 0 and SSG_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on a 1-GPU box; the
 line's `data` field then says "TEST RUN ... timings meaningless".
 
-Timing: an untimed, time-based device conditioning (`--precondition-ms`, default 300: launches of the same kernel on a SCRATCH env
-and scratch buffers, reported as `preconditioning_ms`; every trajectory buffer set is written once beforehand), then W untimed
-warm-up steps, then the K-step rollout is timed `--repeats` (default 5) times (`repeats_min_ms` / `repeats_median_ms` /
-`repeats_max_ms`, the shader clock probed in front of each repeat in `repeats_shader_clock_ghz`), every repeat
+Timing: an untimed, time-based device conditioning (`--precondition-ms`, default 300: the same K-step rollout on a SCRATCH env and
+scratch buffers, bracketed by synchronize exactly like a timed repeat and repeated until the time is up, reported as
+`preconditioning_ms`; every trajectory buffer set is written once beforehand), then W untimed warm-up steps, then the K-step
+rollout is timed `--repeats` (default 5) times (`repeats_min_ms` / `repeats_median_ms` / `repeats_max_ms`; the shader clock the
+step kernel recorded during each repeat in `repeats_shader_clock_ghz`: no probe kernel runs between repeats), every repeat
 bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's interval runs from the opening barrier + synchronize
 to its own closing synchronize; the closing barrier follows) and reduced with MAX over ranks; `value` is the
 MEDIAN repeat, all repeats are listed in `repeats_ms`.
@@ -246,7 +247,7 @@ def side_config(dev, n, n_beams, n_ships, K, W, map_mode="bank", ring=32, dyn_me
     return out
 
 
-def c4_policy_in_the_loop(dev, n, host_reset, ks=300):
+def c4_policy_in_the_loop(dev, n, host_reset, ks=300, terminal_obs=False):
     """Config 4 stepped one ssg_step at a time (what a trainer does), us per step (median of 5 x `ks` back-to-back steps):
     host_reset = False: VecEnv semantics, done envs are reset inside the step kernel; host_reset = True: the RLlib flow on the
     device — no in-kernel auto-reset, ONE masked ssg_reset(mask = done) after every step (its envs join the queue of the next
@@ -254,6 +255,8 @@ def c4_policy_in_the_loop(dev, n, host_reset, ks=300):
     import torch
     from ship_sim_gym_amd.vec_env import ShipVecEnv
     vec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=10, n_ships=4, auto_reset=not host_reset)
+    if terminal_obs:  # the RLlib flow without a reset launch: in-kernel reset + the terminal observations in a side buffer
+        vec.enable_terminal_obs()
     a1 = vec.random_actions(4242, 0, ks)
     rows = [a1[k] for k in range(ks)]
     vec.reset_tensor()
@@ -273,7 +276,9 @@ def c4_policy_in_the_loop(dev, n, host_reset, ks=300):
     steps, rebuilds = vec.dyn_counters()
     vec.close()
     torch.cuda.empty_cache()
-    return {"envs": n, "us_per_step": sorted(reps)[len(reps) // 2], "repeats_us": reps, "launch": "one ssg_step per step" + (" + one masked ssg_reset" if host_reset else ""),
+    return {"envs": n, "us_per_step": sorted(reps)[len(reps) // 2], "repeats_us": reps,
+            "launch": "one ssg_step per step" + (" + one masked ssg_reset" if host_reset else "") +
+                      (" (ssg_set_terminal_obs: reset observation in obs, terminal observation in a side buffer)" if terminal_obs else ""),
             "full_cpSpaceSteps": steps, "queue_rebuilds": rebuilds}
 
 
@@ -392,45 +397,76 @@ def launch_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def shader_clock_probe(dev, buf):
-    """GHz of the shader clock under an FP64 VALU load, right now (ssg_debug_clock_probe: 1 024 workgroups x ~25 us of double
-    mul + add chains; s_memtime cycles over s_memrealtime's constant 100 MHz ticks, median over the workgroups).  Outside every
-    timed region: it tells whether the repeat that follows starts on a GPU that has left its idle clocks."""
+def launch_clock(vec, buf_row):
+    """Ask the step kernel to record the shader clock of its own launches (ssg_debug_launch_clock: the first wave of workgroup 0
+    stores how far s_memtime and the constant 100 MHz s_memrealtime advanced over its lifetime) into buf_row (2 x int64 on the
+    device), or stop (None).  A host-side setting: nothing is launched around the timed region — a separate probe kernel between two
+    repeats, however light, leaves the GPU idle long enough for the next launch to start slower (tools/bench_probe_when.sh: 8.0
+    against 9.2 G env-steps/s in the driver's form), and one wide enough to load every CU with FP64 work pulls the chip into its
+    power-limited clocks (2.31 -> 2.04 GHz)."""
     import ctypes as C
-    import torch
     from ship_sim_gym_amd import _native as N
-    N.check(N.lib().ssg_debug_clock_probe(C.c_void_p(buf.data_ptr()), 1024, 1500, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-            None, "ssg_debug_clock_probe")
-    v = buf.view(1024, 2).to(torch.float64)
-    return float((v[:, 0] / v[:, 1].clamp(min=1.0)).median().item()) * 0.1
+    N.check(N.lib().ssg_debug_launch_clock(vec._h, C.c_void_p(buf_row.data_ptr()) if buf_row is not None else None), vec._h,
+            "ssg_debug_launch_clock")
 
 
-def precondition(pvec, pacts, pout, min_ms, dev):
-    """Time-based device conditioning BEFORE the warm-up steps: the same kernel, in the same output mode, on a SCRATCH env and
-    scratch trajectory buffers for at least `min_ms` of wall time, so that the W warm-up steps and the timed repeats start on a
-    GPU at its loaded clocks instead of one still ramping up from idle (a 20-step launch is 150 us; BENCH_r05's five repeats
-    fell 206 -> 158 us while the box was waking up).  Nothing it touches is read or written by the timed region."""
+def bracketed_rollout(vec, a, out, use_dist):
+    """ONE repeat: exactly a.shape[0] trajectory-mode steps bracketed by barrier + synchronize on both sides.  Returns (wall
+    seconds of this rank, HIP-event ms).  The device conditioning runs this very function on a scratch env, so the timed repeats
+    continue the launch / wait pattern the GPU is already in."""
     import torch
+    import torch.distributed as dist
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    vec.rollout_tensor(a, trajectory=True, out=out)  # exactly K steps: ceil(K / steps_per_launch) launches of the step kernel
+    ev1.record()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()  # this rank's K steps are complete; the job's time is the MAX over ranks (below), so the
+    if use_dist:              # closing barrier's own latency (an RCCL all-reduce: tens of us against a 150 us region at
+        dist.barrier()        # K = 20) is bracketing, not stepping, and stays outside the interval
+    return t1 - t0, ev0.elapsed_time(ev1)
+
+
+def precondition(pvec, pacts, pouts, min_ms, use_dist, dev):
+    """Time-based device conditioning BEFORE the warm-up steps: the same K-step rollout, bracketed exactly like a timed repeat
+    (bracketed_rollout), on a SCRATCH env and scratch trajectory buffers, repeated for at least `min_ms` of wall time — so that the
+    warm-up steps and the timed repeats start on a GPU that is already in the power / clock state this launch-and-wait pattern
+    settles in.  (Two things measured in round 6, tools/coldbuf_probe.py and tools/bench_probe_when.sh: after an idle stretch the
+    first launches run below the settled rate — BENCH_r05's repeats fell 206 -> 158 us — and after a stretch of back-to-back
+    launches with no waits in between, or an FP64 burst on every CU, they do too: the chip is then at its power-limited clocks
+    and takes two or three 150-us repeats to come back.)  Nothing it touches is read or written by the timed region.  The number
+    of rounds is agreed between the ranks (their barriers must pair up)."""
+    import torch
+    import torch.distributed as dist
     if min_ms <= 0:
         return 0.0, 0
     pvec.reset_tensor()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 0
-    while True:
-        for _ in range(8):
-            pvec.rollout_tensor(pacts, trajectory=True, out=pout)
-            n += 1
-        torch.cuda.synchronize()
-        if (time.perf_counter() - t0) * 1e3 >= min_ms:
+    rounds = 0
+    while True:  # chunks of 16 bracketed rollouts until EVERY rank has run for min_ms (the ranks' barriers must pair up)
+        for _ in range(16):
+            bracketed_rollout(pvec, pacts, pouts[rounds % len(pouts)], use_dist)  # (rotating over as many sets as the repeats do)
+            rounds += 1
+        more = (time.perf_counter() - t0) * 1e3 < min_ms
+        if use_dist:
+            t = torch.tensor([1 if more else 0], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            more = bool(int(t.item()))
+        if not more:
             break
-    return (time.perf_counter() - t0) * 1e3, n
+    return (time.perf_counter() - t0) * 1e3, rounds
 
 
 def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
-    """Device conditioning (untimed, scratch buffers), W untimed warm-up steps, then R timed repeats of exactly K trajectory-mode
-    steps, each bracketed by barrier + synchronize on both sides; returns (wall seconds per repeat, MAX over ranks; HIP-event ms
-    per repeat; buffer sets; shader clock GHz probed in front of every repeat; preconditioning info)."""
+    """Device conditioning (untimed, scratch env and buffers), W untimed warm-up steps, then R timed repeats of exactly K
+    trajectory-mode steps, each bracketed by barrier + synchronize on both sides; returns (wall seconds per repeat, MAX over ranks;
+    HIP-event ms per repeat; buffer sets; the shader clock GHz the step kernel itself recorded in every repeat; preconditioning info)."""
     import torch
     import torch.distributed as dist
     acts = vec.random_actions(12345, 0, W + K * R)  # int32 [W + R*K, n], generated on device before any timed region
@@ -440,39 +476,30 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
     for set_ in bufs:                     # pre-touch: no repeat is the first writer of its buffer set's pages
         for t in set_:
             t.zero_()
-    probe_buf = torch.zeros(2048, dtype=torch.int64, device=dev)
+    clk = torch.zeros((R, 2), dtype=torch.int64, device=dev)  # the step kernel's own clock stamps, one row per timed repeat
+    vec.reset_tensor()
     pre = {"preconditioning_ms": 0.0, "preconditioning_launches": 0}
     if precondition_ms > 0 and pvec is not None:
-        kp = min(K, 100)
-        pacts = pvec.random_actions(4321, 0, kp)
-        pout = traj_buffers(pvec, kp, 1)[0]
-        ms, nl = precondition(pvec, pacts, pout, precondition_ms, dev)
+        pacts = pvec.random_actions(4321, 0, K)
+        pouts = traj_buffers(pvec, K, n_bufs) if n_bufs > 1 else [bufs[0]]  # (a 30 GB set is not allocated twice)
+        for set_ in pouts:
+            for t in set_:
+                t.zero_()
+        ms, nl = precondition(pvec, pacts, pouts, precondition_ms, use_dist, dev)
         pre = {"preconditioning_ms": ms, "preconditioning_launches": nl,
-               "preconditioning": "%d launches of %d steps of the same kernel on a scratch env and scratch trajectory buffers, "
-                                  "untimed, before the warm-up steps" % (nl, kp)}
-    vec.reset_tensor()
-    for w0 in range(0, W, K):  # warm-up: the same kernel in the same output mode (chunks of <= K steps into the first set)
-        vec.rollout_tensor(acts[w0: min(W, w0 + K)], trajectory=True, out=bufs[0])
-    walls, evs, clocks = [], [], []
+               "preconditioning": "%d rollouts of %d steps of the same kernel on a scratch env and scratch trajectory buffers, each "
+                                  "bracketed by synchronize like a timed repeat, untimed, before the warm-up steps" % (nl, K)}
+    # warm-up: the same kernel in the same output mode, bracketed like a repeat (chunks of <= K steps into the first set)
+    for w0 in range(0, W, K):
+        bracketed_rollout(vec, acts[w0: min(W, w0 + K)], bufs[-1], use_dist)  # (the set the LAST repeat writes: no repeat finds its lines warm)
+    walls, evs = [], []
     for r in range(R):
-        a = acts[W + r * K: W + (r + 1) * K]
-        out = bufs[r % n_bufs]
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        clocks.append(shader_clock_probe(dev, probe_buf))  # (untimed; ends with a device -> host read, i.e. a synchronize)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev0.record()
-        vec.rollout_tensor(a, trajectory=True, out=out)  # exactly K steps: ceil(K / steps_per_launch) launches of the step kernel
-        ev1.record()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()  # this rank's K steps are complete; the job's time is the MAX over ranks (below), so the
-        if use_dist:              # closing barrier's own latency (an RCCL all-reduce: tens of us against a 150 us region at
-            dist.barrier()        # K = 20) is bracketing, not stepping, and stays outside the interval
-        walls.append(t1 - t0)
-        evs.append(ev0.elapsed_time(ev1))
+        launch_clock(vec, clk[r])
+        w, e = bracketed_rollout(vec, acts[W + r * K: W + (r + 1) * K], bufs[r % n_bufs], use_dist)
+        walls.append(w); evs.append(e)
+    launch_clock(vec, None)
+    ch = clk.cpu().double()
+    clocks = [float(ch[r, 0] / max(float(ch[r, 1]), 1.0)) * 0.1 for r in range(R)]
     if use_dist:
         t = torch.tensor(walls, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time, repeat by repeat
@@ -684,8 +711,8 @@ def main():
                                       "collective" % (world, world),
                        "ranks": ranks_info},
             "repeats": R, "repeats_ms": [w * 1e3 for w in walls], "timing": "median of %d repeats of the K-step rollout" % R,
-            # spread of the timed repeats (value = the median one), the shader clock probed in front of each (FP64 VALU load,
-            # s_memtime over the 100 MHz reference counter; rank 0) and the untimed device conditioning that preceded the warm-up
+            # spread of the timed repeats (value = the median one), the shader clock DURING each (recorded by the step kernel itself:
+            # s_memtime over the 100 MHz reference counter, rank 0) and the untimed device conditioning that preceded the warm-up
             "repeats_min_ms": min(walls) * 1e3, "repeats_median_ms": wall * 1e3, "repeats_max_ms": max(walls) * 1e3,
             "repeats_spread": (max(walls) - min(walls)) / wall,
             "value_min": total_steps / max(walls), "value_max": total_steps / min(walls),
@@ -751,6 +778,8 @@ def main():
                 other["c4_fresh_world_per_episode"]["ring"] = 32
                 other["c4_single_step_auto_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=False)
                 other["c4_host_masked_reset"] = c4_policy_in_the_loop(dev, 65536, host_reset=True)
+                # the RLlib flow as ShipVecEnv(rllib=True) runs it since round 6: no reset launch (ssg_set_terminal_obs)
+                other["c4_rllib_flow_terminal_obs"] = c4_policy_in_the_loop(dev, 65536, host_reset=False, terminal_obs=True)
                 # the numpy protocol stable-baselines / RLlib callers use, next to its PCIe bound
                 other["vecenv_numpy_path"] = {"65536_envs_8_beams": vecenv_numpy_path(dev, 65536, 8),
                                               "4096_envs_10_beams": vecenv_numpy_path(dev, 4096, 10)}

@@ -23,12 +23,13 @@
 extern "C" {
 #endif
 
-#define SSG_ABI_VERSION 7 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
+#define SSG_ABI_VERSION 8 /* 2: ssg_config.n_ships, SSG_F_TRAFFIC / SSG_F_GOAL_BODIES (config 4); 3: ssg_init_state;
                              4: map record without dtMin/dtMax (SSG_MAP_STRIDE 145, SSG_PLANE_DOUBLES 5);
                              5: ssg_config.map_ring, ssg_refill_worlds (a brand-new world per episode, generated on the device);
                              6: ssg_rollout_traj (every step of a fused rollout lands in its own slot of a trajectory buffer);
                              7: SSG_FLAG_DYN_MEMO_OFF, SSG_F_DYN_MEMO_STATS (config 4: the memo table of the full cpSpaceStep lives
-                                in the state blob, which grows by ~30 MB) */
+                                in the state blob, which grows by ~30 MB);
+                             8: ssg_set_terminal_obs (the RLlib flow without a reset launch), ssg_debug_launch_clock, ssg_debug_clock_probe */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -230,6 +231,15 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
 int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
              uint8_t *dev_flags /* nullable */, void *stream);
 
+/* Replaces: what RLlib's VectorEnv flow sees of an episode's end (train/rllib/ppo.py:21-44 over ShipEnv.step / ShipEnv.reset,
+ * ship_env.py:136-156,171-184): vector_step reports the TERMINAL observation of a done env, reset_at then resets it and returns the
+ * reset observation.  With SSG_FLAG_AUTO_RESET a done env is reset inside ssg_step and its row of dev_obs is the reset observation;
+ * with dev_term_obs != NULL (f64[n_envs][history*(6+n_beams)], caller-owned) the step kernel ALSO stores the terminal observation
+ * of every env it resets into that env's row of dev_term_obs (rows of other envs are left untouched): one step, no reset launch,
+ * both observations.  ssg_step / ssg_rollout only (a trajectory rollout keeps every step in its own slot and is not served);
+ * history <= 2 (SSG_ERR_UNSUPPORTED otherwise: reset the done envs with a masked ssg_reset there).  NULL switches it off. */
+int ssg_set_terminal_obs(ssg_handle *h, double *dev_term_obs);
+
 /* Per-env event bits written to dev_flags (the reference's ShipGame.colliding / goal_reached attributes that
  * tests reach through env.game.*, game.py:190-191,240,254, plus which is_done branch fired). */
 #define SSG_EV_COLLIDING 0x1u
@@ -333,10 +343,19 @@ int ssg_debug_launch_geometry(const ssg_handle *h, int *envs_per_workgroup, int 
  * step kernel's access width, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count. */
 int ssg_debug_copy8(const double *dev_src, double *dev_dst, size_t n_doubles, void *stream);
 
+/* Measurement aid (no reference counterpart): the shader clock DURING the step kernel's launches.  With dev_buf != NULL (two u64 of
+ * device memory), the first wave of workgroup 0 of every following step-kernel launch stores, when it ends, dev_buf[0] = shader-clock
+ * cycles (s_memtime) and dev_buf[1] = ticks of the constant 100 MHz reference counter (s_memrealtime) that passed since it started:
+ * clock = 100 MHz x cycles / ticks, measured inside the timed launch itself with nothing launched around it.  NULL switches it off
+ * (the default; the kernel then executes two scalar counter reads per wave and one untaken branch).  How bench.py reports
+ * `repeats_shader_clock_ghz`. */
+int ssg_debug_launch_clock(ssg_handle *h, uint64_t *dev_buf);
+
 /* Measurement aid (no reference counterpart): the shader clock under an FP64 VALU load.  n_blocks workgroups of 256 lanes run
  * `iters` rounds of eight independent double mul + add chains; dev_out[2*b] = shader-clock cycles (s_memtime) and dev_out[2*b+1] =
  * ticks of the constant 100 MHz reference counter (s_memrealtime) that workgroup b saw pass meanwhile: clock = 100 MHz x cycles /
- * ticks.  bench.py logs it in front of every timed repeat, so that a repeat timed on a GPU still leaving its idle clocks shows. */
+ * ticks.  (A probe wide enough to load every CU pulls the chip into its power-limited clocks and slows whatever is timed right
+ * after it: bench.py uses ssg_debug_launch_clock for the timed repeats instead.) */
 int ssg_debug_clock_probe(uint64_t *dev_out, int n_blocks, int iters, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSG_LIB_PATH: development override (tools/build_variant.sh builds diagnostic variants next to the product library)
 LIB_PATH = os.environ.get("SSG_LIB_PATH") or os.path.join(_HERE, "libshipsim.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_BEAMS, MAX_GOALS, MAX_HULL, SHIP_VERTS, N_TRAFFIC = 16, 6, 12, 5, 3
 MAP_STRIDE = 145
 MAP_OFF_COUNTS, MAP_OFF_AABB, MAP_OFF_GOALS, MAP_OFF_SPAWN_GOAL, MAP_OFF_PLANES, PLANE_DOUBLES = 0, 2, 10, 22, 24, 5
@@ -26,7 +26,7 @@ EXPORTS = (
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
     "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_rollout_traj", "ssg_debug_dyn_counters", "ssg_debug_kernel_times",
-    "ssg_debug_clock_probe",
+    "ssg_debug_clock_probe", "ssg_debug_launch_clock", "ssg_set_terminal_obs",
 )
 
 
@@ -96,6 +96,8 @@ def lib():
     L.ssg_generate_bank.argtypes = [vp, C.c_uint64, C.c_double, vp, C.c_int, vp, vp]
     L.ssg_debug_copy8.argtypes = [vp, vp, C.c_size_t, vp]
     L.ssg_debug_clock_probe.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.ssg_debug_launch_clock.argtypes = [vp, vp]
+    L.ssg_set_terminal_obs.argtypes = [vp, vp]
     L.ssg_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp]
     L.ssg_dyn_invalidate.argtypes = [vp, vp, vp]
     L.ssg_host_convex_hull.argtypes = [C.c_int, dp, dp, ip]

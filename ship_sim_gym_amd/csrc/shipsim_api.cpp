@@ -934,6 +934,28 @@ int ssg_fill_actions(ssg_handle *h, uint64_t seed, uint64_t step0, int K, int32_
     return SSG_OK;
 }
 
+int ssg_set_terminal_obs(ssg_handle *h, double *dev_term_obs)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    if (dev_term_obs && h->cfg.history > 2)
+        return fail(h, SSG_ERR_UNSUPPORTED, "ssg_set_terminal_obs: history > 2 builds its rows in the frame-shift kernel (reset the done envs with a masked ssg_reset instead)");
+    if (dev_term_obs && !(h->cfg.flags & SSG_FLAG_AUTO_RESET))
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_set_terminal_obs: only a handle that resets its done envs in-kernel (SSG_FLAG_AUTO_RESET) replaces terminal observations");
+    h->dev.term_obs = dev_term_obs;
+    return SSG_OK;
+}
+
+#ifndef SSG_STAMPS
+int ssg_debug_launch_clock(ssg_handle *h, uint64_t *dev_buf)
+{
+    if (!h) return SSG_ERR_BAD_ARG;
+    h->dev.dbg = reinterpret_cast<unsigned long long *>(dev_buf);
+    return SSG_OK;
+}
+#else
+int ssg_debug_launch_clock(ssg_handle *h, uint64_t *) { return fail(h, SSG_ERR_UNSUPPORTED, "ssg_debug_launch_clock: a -DSSG_STAMPS build uses the buffer for its own stamps"); }
+#endif
+
 #ifdef SSG_STAMPS
 // diagnostic builds only: where per-wave s_memtime stamps go (16 u64 per wave)
 int ssg_debug_set_stamp_buffer(ssg_handle *h, void *dev_buf)

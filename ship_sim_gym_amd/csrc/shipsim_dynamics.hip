@@ -55,11 +55,14 @@ extern __shared__ double lds[]; // [field][64 lanes] columns, then the wave-unif
 // one per CU; round 2 and the first half of round 3) -> 60.9 / 165, and 100 whenever the queue outgrew 16 384 envs.
 // (SSG_DYN_NONUNI_TU: this file compiled a second time for the per-lane-planes variant alone, with 32 envs per wave — see the end)
 #ifdef SSG_DYN_NONUNI_TU
-constexpr int kGrp = 32;
+#ifndef SSG_DYN_NONUNI_GRP
+#define SSG_DYN_NONUNI_GRP 32
+#endif
+constexpr int kGrp = SSG_DYN_NONUNI_GRP;
 #else
 constexpr int kGrp = kDynGrp;
 #endif
-static_assert(kGrp == 32 || kGrp == 48 || kGrp == 64, "lds[field * kGrp + lane]: at 32 / 64 a lane keeps its LDS banks whatever the field; 48 pays an occasional 2-way conflict on the solver's per-lane body slots");
+static_assert(kGrp == 8 || kGrp == 16 || kGrp == 32 || kGrp == 48 || kGrp == 64, "lds[field * kGrp + lane]: at 32 / 64 a lane keeps its LDS banks whatever the field; 48 pays an occasional 2-way conflict on the solver's per-lane body slots");
 constexpr int kIter = 10;          // cpSpace iterations
 constexpr int kPersist = 3;        // collisionPersistence
 constexpr int kMaxGjk = 30, kMaxEpa = 30;

@@ -129,7 +129,9 @@ struct DevCfg {
     uint8_t *mask;
     double *stats;
     const double *bank;
-    unsigned long long *dbg; // diagnostic builds only (-DSSG_STAMPS): per-wave s_memtime stamps
+    unsigned long long *dbg; // -DSSG_STAMPS builds: per-wave s_memtime stamps; product builds: the launch's clock stamps (ssg_debug_launch_clock)
+    double *term_obs;        // nullable: [n_envs][history * (6 + n_beams)] rows that receive the TERMINAL observation of an env the
+                             // step kernel auto-resets (ssg_set_terminal_obs)
     // config 4 (n_ships == 4): columns of the non-player bodies (shipsim_dynamics.hip); null otherwise
     int n_ships;
     double *dyn_f64;

@@ -53,6 +53,24 @@ __device__ __forceinline__ double *lds_base()
 __device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
+// The library is compiled with -ffp-contract=off: every product and sum of the state-advancing arithmetic rounds where
+// Chipmunk's does.  obs_fma(a, b, c) = a * b + c as ONE fused multiply-add is used only in functions whose results reach
+// OBSERVATIONS (lidar readings, the nearest goal's distance comparison) and never the state an env is stepped from: one
+// instruction where the state-advancing code issues a multiply and an add (round 6: 5.34 -> 5.23 us per fused step, interleaved on
+// one box; readings move by rounding only, ~1e-13, hit decisions unchanged over the parity soak).  Written out by hand, NOT left to
+// `#pragma clang fp contract(fast)`: the compiler then fuses different pairs in different instantiations of the kernel, and the
+// staged / gathered / 64- / 128- / 256-env layouts, fused and single-step launches, shards and the unsplit batch stop agreeing
+// bit for bit (tests/test_parity_gpu.py::test_ragged_sizes_and_bank_in_global caught exactly that).
+// -DSSG_NO_LIDAR_FMA (tools/build_variant.sh) builds with the multiply and the add kept apart.
+__device__ __forceinline__ double obs_fma(double a, double b, double c)
+{
+#ifndef SSG_NO_LIDAR_FMA
+    return __builtin_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) // src_lane must be wave-uniform
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -166,7 +184,7 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
             if (g >= c.n_goals) break;
             const double px = hG[(2 * g) * ld], py = hG[(2 * g + 1) * ld];
             const double dx = px - x, dy = py - y;
-            const double d = dx * dx + dy * dy;
+            const double d = obs_fma(dx, dx, dy * dy);
             const bool take = ((gm >> g) & 1u) & (d < best);
             best = take ? d : best;
             gx = take ? px : gx;
@@ -178,7 +196,7 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
         const double px = goal_at<LDS_BANK, DYN>(c, goff, g, 0);
         const double py = goal_at<LDS_BANK, DYN>(c, goff, g, 1);
         const double dx = px - x, dy = py - y;
-        const double d = dx * dx + dy * dy; // squared distance orders exactly like Vec2d.get_distance's sqrt
+        const double d = obs_fma(dx, dx, dy * dy); // squared distance orders exactly like Vec2d.get_distance's sqrt
         const bool take = ((gm >> g) & 1u) & (d < best); // first alive goal always beats +inf
         best = take ? d : best;
         gx = take ? px : gx;
@@ -196,7 +214,7 @@ __device__ __forceinline__ void nearest_goal_regs(int n_goals, unsigned gm, doub
     for (int g = 0; g < SSG_MAX_GOALS; ++g) {
         const double px = gp[2 * g], py = gp[2 * g + 1];
         const double dx = px - x, dy = py - y;
-        const double d = dx * dx + dy * dy;
+        const double d = obs_fma(dx, dx, dy * dy);
         const bool take = (g < n_goals) & (bool)((gm >> g) & 1u) & (d < best);
         best = take ? d : best;
         gx = take ? px : gx;
@@ -226,9 +244,9 @@ __device__ __forceinline__ int next_map(const DevCfg &c, int map_id, int env)
 __device__ __forceinline__ void beam_end(double cx, double cy, double ca, double sa, double cphi, double sphi, double dist,
                                          double &ex, double &ey)
 {
-    const double ux = ca * cphi - sa * sphi, uy = sa * cphi + ca * sphi;
-    ex = cx + dist * ux;
-    ey = cy + dist * uy;
+    const double ux = obs_fma(ca, cphi, -(sa * sphi)), uy = obs_fma(sa, cphi, ca * sphi);
+    ex = obs_fma(dist, ux, cx);
+    ey = obs_fma(dist, uy, cy);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -371,8 +389,8 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
                     const int jp = (j == 0) ? cnt - 1 : j - 1;
                     const int qp = pb + SSG_PLANE_DOUBLES * ((jp >= 0 && jp < SSG_MAX_HULL) ? jp : 0);
                     const double ux = bank_at<LDS_BANK>(c, qp + 0), uy = bank_at<LDS_BANK>(c, qp + 1);
-                    pdtmin[u] = pnx[u] * uy - pny[u] * ux;
-                    pdtmax[u] = pnx[u] * pv0y[u] - pny[u] * pv0x[u];
+                    pdtmin[u] = obs_fma(pnx[u], uy, -(pny[u] * ux));
+                    pdtmax[u] = obs_fma(pnx[u], pv0y[u], -(pny[u] * pv0x[u]));
                 }
             }
 #pragma unroll
@@ -380,7 +398,7 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
                 const int j = j0 + u;
                 const bool valid = act & (j < cnt);
                 const double nx = pnx[u], ny = pny[u], v0n = pv0n[u];
-                const double an = wcx * nx + wcy * ny;
+                const double an = obs_fma(wcx, nx, wcy * ny);
                 const double d = an - v0n;
                 if (EXACT) {
                     outside = outside | (valid & ((nx * (wcx - pv0x[u]) + ny * (wcy - pv0y[u])) > 0.0));
@@ -392,13 +410,13 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
                     maybe = maybe | (valid & !(d < -kSignEps));
                 }
                 const bool front = valid & !(d < 0.0);
-                const double bn = ex * nx + ey * ny;
+                const double bn = obs_fma(ex, nx, ey * ny);
                 const double den = dmax(an - bn, DBL_MIN);
                 if (EXACT) {
                     const double t = d / den;
                     const double omt = 1.0 - t;
-                    const double qx = wcx * omt + ex * t, qy = wcy * omt + ey * t; // cpvlerp(a,b,t)
-                    const double dtv = nx * qy - ny * qx;                           // cpvcross(n, point)
+                    const double qx = obs_fma(ex, t, wcx * omt), qy = obs_fma(ey, t, wcy * omt); // cpvlerp(a,b,t)
+                    const double dtv = obs_fma(nx, qy, -(ny * qx));                  // cpvcross(n, point)
                     const bool acc = front & !((t < 0.0) | (1.0 < t)) & (pdtmin[u] <= dtv) & (dtv <= pdtmax[u]);
                     ok = ok | acc;
                     ptx = acc ? qx : ptx;
@@ -435,20 +453,20 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             double2 nn = bank_at2<LDS_BANK>(c, q + 2), vj = bank_at2<LDS_BANK>(c, q + 0), vp = bank_at2<LDS_BANK>(c, qp + 0);
             if constexpr (!LDS_BANK) asm volatile("" : "+v"(nn.x), "+v"(nn.y), "+v"(vj.x), "+v"(vj.y), "+v"(vp.x), "+v"(vp.y));
             const double nx = nn.x, ny = nn.y;
-            const double dtmin = nx * vp.y - ny * vp.x;
-            const double dtmax = nx * vj.y - ny * vj.x;
+            const double dtmin = obs_fma(nx, vp.y, -(ny * vp.x));
+            const double dtmax = obs_fma(nx, vj.y, -(ny * vj.x));
             const double t = bd / bden;
             const double omt = 1.0 - t;
-            ptx = wcx * omt + ex * t;
-            pty = wcy * omt + ey * t;
-            const double dtv = nx * pty - ny * ptx;
+            ptx = obs_fma(ex, t, wcx * omt);
+            pty = obs_fma(ey, t, wcy * omt);
+            const double dtv = obs_fma(nx, pty, -(ny * ptx));
             ok = (bd >= 0.0) & (dtmin <= dtv) & (dtv <= dtmax);
         }
         // start point inside (or on) the polygon: hit at alpha 0 whose reported point is the FAR end b (App. A.7)
         const bool hit = act & (ok | !outside);
         const double px = outside ? ptx : ex, py = outside ? pty : ey;
         const double dx = px - wcx, dy = py - wcy;
-        const double dist = sqrt(dx * dx + dy * dy); // Vec2d.get_distance
+        const double dist = sqrt(obs_fma(dx, dx, dy * dy)); // Vec2d.get_distance
         if (hit) {
             const unsigned long long key = ((unsigned long long)s << 63) | (unsigned long long)__double_as_longlong(dist);
             atomicMin(&res[bi * 64 + src], key); // ds_min_u64: hull 0's hit beats hull 1's
@@ -504,6 +522,24 @@ __device__ __forceinline__ void st_out(T *p, T v)
 #define SSG_STAMP(k) do { } while (0)
 #define SSG_STAMP_K(i) do { } while (0)
 #define SSG_STAMP_FLUSH(n) do { } while (0)
+#endif
+
+// The shader clock DURING a launch (product builds; ssg_debug_launch_clock): every wave reads the shader-clock counter (s_memtime)
+// and the constant 100 MHz reference counter (s_memrealtime) when it starts; when the first wave of workgroup 0 ends it stores how
+// far both advanced — two scalar reads per wave and, with no buffer installed, one untaken branch.  (-DSSG_STAMPS builds use
+// c.dbg for their own stamps.)
+#ifdef SSG_STAMPS
+#define SSG_CLOCK_BEGIN() do { } while (0)
+#define SSG_CLOCK_END() do { } while (0)
+#else
+#define SSG_CLOCK_BEGIN() const unsigned long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
+#define SSG_CLOCK_END()                                                                            \
+    do {                                                                                           \
+        if (c.dbg && blockIdx.x == 0 && threadIdx.x == 0) {                                        \
+            c.dbg[0] = __builtin_amdgcn_s_memtime() - clk_c0_;                                     \
+            c.dbg[1] = __builtin_amdgcn_s_memrealtime() - clk_r0_;                                 \
+        }                                                                                          \
+    } while (0)
 #endif
 
 // Timing-only ablation switches (development builds with -DSSG_ABLATION; never in the product library): bits
@@ -895,6 +931,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
     // body role's queue entry, a returning atomic, otherwise counts as live around the step loop and is spilled, i.e. waited
     // for, the moment it is issued)
     const int K = DYN ? 1 : K_launch;
+    SSG_CLOCK_BEGIN();
     // K consecutive steps in one launch (K = 1 for ssg_step): the bank is staged once and role 3 keeps the body state in
     // registers.  Step k reads actions_kn + k*n_envs and writes its obs / reward / done / flags `k * traj` env rows past the
     // buffers' starts: traj = 0 rewrites the same [n_envs] rows every step (ssg_rollout), traj >= n_envs lays the steps of
@@ -1246,6 +1283,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         }
         SSG_STAMP(10);
         SSG_STAMP_FLUSH(3);
+        SSG_CLOCK_END(); // (thread 0 is a lidar wave's: its role ends with the launch's last step)
         return;
     }
 
@@ -1441,13 +1479,28 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     // smallest key = the first shape in list order that reported a hit (models.py:61-72); a miss keeps
-                    // the previous reading (sticky, models.py:68-72); a fresh episode starts from -1 (models.py:36)
+                    // the previous reading (sticky, models.py:68-72)
                     const unsigned long long key = rk[i * 64 + lane];
                     const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
-                    const double v = (key == kLidarMiss) ? pv[6 + i] : hitd;
-                    nv[6 + i] = do_reset ? -1.0 : v;
+                    nv[6 + i] = (key == kLidarMiss) ? pv[6 + i] : hitd;
                 }
             }
+            // The TERMINAL observation of an env that is reset here (ssg_set_terminal_obs; what RLlib's vector_step reports for a
+            // done env, train/rllib/ppo.py:21-44, while the reset observation — this step's row — is what its reset_at gets): the
+            // previous frame and the frame the episode ended on, stored by the reset lanes only.  Overwrite mode only (traj == 0).
+            if (c.term_obs != nullptr && traj == 0 && do_reset && live) {
+                double *trow = c.term_obs + (size_t)el_ * (size_t)(F * c.history) + (hist2 ? F : 0);
+                if (hist2) {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) st_out(&trow[j - F], pv[j]);
+                }
+                st_out(&trow[0], x); st_out(&trow[1], y); st_out(&trow[2], (double)rudder); st_out(&trow[3], ang);
+                st_out(&trow[4], nf_gx); st_out(&trow[5], nf_gy);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) st_out(&trow[6 + i], nv[6 + i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) nv[6 + i] = do_reset ? -1.0 : nv[6 + i]; // a fresh episode starts from -1 (models.py:36)
             SSG_STAMP_K(6);
             {
                 double *__restrict__ obase = obs + ((size_t)tile_e0 + (size_t)k * (size_t)traj) * (size_t)(F * c.history); // tile start in HBM, this step's slot

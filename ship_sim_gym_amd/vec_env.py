@@ -124,7 +124,12 @@ class ShipVecEnv(*_BASES):
         # rllib=True: the RLlib VectorEnv flow — vector_step returns the TERMINAL observation of a done env and the
         # caller's reset_at(i) is the one reset it gets (no in-kernel auto-reset underneath)
         self.rllib = bool(rllib)
-        self.auto_reset = bool(auto_reset) and not self.rllib
+        # The RLlib flow WITHOUT a reset launch (ssg_set_terminal_obs, history <= 2, worlds that live on the device): the step
+        # kernel resets a done env itself — its row of `obs` is then the reset observation reset_at(i) hands out — and also
+        # stores the env's TERMINAL observation in `term_obs`, which vector_step reports.  Otherwise (history > 2, host-drawn
+        # worlds) the rllib flow runs without in-kernel reset and resets its done envs with ONE masked ssg_reset per step.
+        self._rllib_fused = self.rllib and env_config.HISTORY_SIZE <= 2 and map_mode in ("bank", "fresh_device")
+        self.auto_reset = bool(auto_reset) and (not self.rllib or self._rllib_fused)
         self.env_id_base = int(env_id_base)
         self.game_config, self.env_config = game_config, env_config
 
@@ -193,6 +198,7 @@ class ShipVecEnv(*_BASES):
             self.obs, self.reward, self.done, self.flags = self._blob_views(self._out_blob)
             self._actions = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         self._host = None  # pinned host side of the numpy protocols, made by the first step_async (the tensor API never needs it)
+        self.term_obs = None
         N.check(L.ssg_bind_state(self._h, C.c_void_p(self.state.data_ptr())), self._h, "ssg_bind_state")
 
         # ---- map bank ----
@@ -220,6 +226,8 @@ class ShipVecEnv(*_BASES):
             self.refill_worlds(self.map_seed)  # fills every ring: episodes 0 .. ring-1 of every env
         else:
             raise ValueError("map_mode must be 'bank', 'fresh' or 'fresh_device'")
+        if self._rllib_fused:
+            self.enable_terminal_obs()
         self._pending = None
         self._closed = False
         self._handles = {}
@@ -289,6 +297,21 @@ class ShipVecEnv(*_BASES):
                               "events": [torch.cuda.Event() for _ in range(self.host_slots)], "slot": 0, "inflight": None,
                               "infos": [{} for _ in range(self.num_envs)]}
         return self._host
+
+    def enable_terminal_obs(self, on=True):
+        """ssg_set_terminal_obs: from now on every step ALSO stores the terminal observation of each env it auto-resets into that
+        env's row of `self.term_obs` ([N, D] float64 device tensor; rows of envs that were not done keep whatever they held).  A
+        GPU-resident caller gets both observations of an episode's end from one launch: `obs` (reset observation) and
+        `torch.where(done[:, None] != 0, term_obs, obs)` (what RLlib's vector_step reports).  Needs in-kernel auto-reset and
+        history <= 2."""
+        torch = _torch()
+        if on and self.term_obs is None:
+            with torch.cuda.device(self.device):
+                self.term_obs = torch.zeros((self.num_envs, self.states_history), dtype=torch.float64, device=self.device)
+        N.check(N.lib().ssg_set_terminal_obs(self._h, C.c_void_p(self.term_obs.data_ptr()) if on else None), self._h, "ssg_set_terminal_obs")
+        if not on:
+            self.term_obs = None
+        return self.term_obs
 
     def _fresh_world(self, e):
         rec, polys, goals = worldgen.generate_world(self.bounds, n_goals=self.cfg.n_goals, width_frac=self.width_frac)
@@ -788,10 +811,21 @@ class ShipVecEnv(*_BASES):
         if self._await_reset.any():
             raise N.ShipSimError("vector_step: envs %r were reported done and have not been reset_at()"
                                  % (np.nonzero(self._await_reset)[0][:8].tolist(),))
-        obs, rew, done, infos = self.step(np.asarray(actions))  # no auto-reset: obs rows of done envs are terminal
+        obs, rew, done, infos = self.step(np.asarray(actions))
         obs = obs if self.copy_host_outputs else obs.copy()
         if done.any():
-            self._reset_done_envs(done)
+            if self._rllib_fused:
+                # the step kernel has already reset the done envs: their rows of `obs` are the reset observations (kept for
+                # reset_at), their terminal observations are in term_obs — no reset launch
+                torch = _torch()
+                idx = np.nonzero(done)[0]
+                if self._reset_obs_h is None:
+                    self._reset_obs_h = np.empty((self.num_envs, self.states_history), dtype=np.float64)
+                self._reset_obs_h[idx] = obs[idx]
+                obs[idx] = self.term_obs[torch.from_numpy(idx).to(self.device)].cpu().numpy()
+                self._await_reset |= done
+            else:  # no in-kernel reset underneath: obs rows of done envs are terminal; ONE masked reset for all of them
+                self._reset_done_envs(done)
         return obs, rew, done, infos
 
     def get_unwrapped(self):

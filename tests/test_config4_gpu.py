@@ -562,6 +562,53 @@ def test_config4_masked_reset_of_queued_envs_never_steps_an_env_twice(mode):
     va.close(); vb.close()
 
 
+@pytest.mark.parametrize("n_ships,nb", [(4, 10), (1, 8)])
+def test_terminal_obs_side_buffer_is_the_rllib_flow_without_a_reset_launch(n_ships, nb):
+    """ssg_set_terminal_obs (train/rllib/ppo.py:21-44 over ship_env.py:136-156,171-184): with in-kernel auto-reset, ONE step hands out
+    both observations of an episode's end — the reset observation in the env's row of `obs`, the terminal observation in its row of
+    `term_obs` — against the oracle stepped WITHOUT auto-reset (terminal rows) and then reset (reset rows).  Single steps and fused
+    overwrite-mode rollouts; rows of envs that are not done are never touched."""
+    torch, O, N, ShipVecEnv = _mods()
+    from helpers import oracle_cfg
+    n, K = 1200, 150
+    vec = ShipVecEnv(n, n_beams=nb, n_maps=16, n_ships=n_ships)
+    ob = O.Batch(n, oracle_cfg(O, vec), vec.bank_polys, vec.bank_goals, map_ids=np.arange(n) % vec.n_maps)
+    np.testing.assert_array_equal(vec.reset_tensor().cpu().numpy(), ob.reset())
+    term = vec.enable_terminal_obs()
+    term.fill_(-7.0)
+    acts = vec.random_actions(808, 0, K)
+    acts_h = acts.cpu().numpy()
+    n_done, worst = 0, 0.0
+    for k in range(K):
+        if n_ships == 1 and k % 3 == 2:   # a fused overwrite-mode rollout of one step is the same launch path as K > 1
+            obs, rew, done, flags = vec.rollout_tensor(acts[k:k + 1])
+        else:
+            obs, rew, done, flags = vec.step_tensor(acts[k])
+        r_obs, r_rew, r_done = ob.step(acts_h[k], auto_reset=False, n_threads=8)      # terminal observations on done rows
+        d = r_done != 0
+        np.testing.assert_array_equal(done.cpu().numpy(), r_done)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_rew)
+        o_h, t_h = obs.cpu().numpy(), term.cpu().numpy()
+        worst = max(worst, float(np.max(np.abs(o_h[~d] - r_obs[~d]))) if (~d).any() else 0.0)
+        if d.any():
+            worst = max(worst, float(np.max(np.abs(t_h[d] - r_obs[d]))))                # the episode's last observation
+            r2 = ob.auto_reset_done()
+            np.testing.assert_array_equal(o_h[d], r2[d])                              # ... and the next episode's first
+            n_done += int(d.sum())
+        assert np.all(t_h[~d] == -7.0)
+        term.fill_(-7.0)
+    assert n_done > n // 2 and worst <= 1e-9, (n_done, worst)
+    # fused steps (1 ship): the rows of the LAST step's done envs, and of envs done at earlier steps of the launch (their rows stay
+    # until the env ends another episode)
+    if n_ships == 1:
+        a2 = vec.random_actions(809, 0, 40)
+        vec.rollout_tensor(a2)
+        assert (term != -7.0).any()
+    vec.enable_terminal_obs(False)
+    assert vec.term_obs is None
+    vec.close()
+
+
 def test_config4_snapshot_restore_of_the_state_blob():
     """The caller owns the state blob (include/shipsim.h): a copy taken between two steps and copied back later, followed by
     ssg_dyn_invalidate (the queue of the next full cpSpaceStep lives in the blob, its live counter set is named by the handle),

@@ -104,6 +104,7 @@ class _Stub(object):
         v._reset_obs_h = None
         v._closed, v._h = True, None
         v.copy_host_outputs, v.host_slots, v._host = False, 4, None
+        v._rllib_fused, v.term_obs = False, None
         v.calls = []
         return v
 

@@ -108,6 +108,14 @@ class Shard(object):
         self.graph = g
 
 
+def env_columns(env):
+    """The env's body / episode state columns (clones): what two runs that stepped the same envs the same way must agree on.  (Not the
+    whole state blob: its reset counters also count the extra reset a graph run does after its warm-up step.)"""
+    from ship_sim_gym_amd import _native as N
+    return {name: env.field(getattr(N, name)).clone() for name in
+            ("F_X", "F_Y", "F_VX", "F_VY", "F_ANGLE", "F_W", "F_LIDAR", "F_RUDDER", "F_STEP_COUNT", "F_MAP_ID", "F_GOAL_MASK", "F_CUM_REWARD")}
+
+
 def make_shards(envs, mode, net, device, horizon, n_maps=64, env_kw=None):
     """The rollout's env shards: one ShipVecEnv, or (pingpong) two halves that together are the same batch — global env ids,
     map assignment and therefore every result are those of the unsplit batch (ship_sim_gym_amd/sharding.py)."""
@@ -224,7 +232,7 @@ def train(envs=4096, updates=20, horizon=64, epochs=2, minibatches=4, lr=3e-4, g
         mode, steps / max(t_roll, 1e-9) / 1e6, steps / max(t_all, 1e-9) / 1e6))
     details = {"mode": mode, "rollout_env_steps_per_s": steps / max(t_roll, 1e-9), "training_env_steps_per_s": steps / max(t_all, 1e-9),
                "rollout_us_per_step": t_roll * 1e6 / (horizon * updates), "rollout_seconds": t_roll, "total_seconds": t_all,
-               "snapshots": snapshots, "final_state": [sh.env.state.clone() for sh in shards] if return_details is True else None,
+               "snapshots": snapshots, "final_state": [env_columns(sh.env) for sh in shards] if return_details is True else None,
                "params": [p.detach().clone() for p in net.parameters()] if return_details is True else None}
     for sh in shards:
         sh.graph = None
