@@ -473,9 +473,10 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
     per_set = traj_bytes_per_step(vec.num_envs, vec.states_history) * K
     n_bufs = max(1, min(R, int(TRAJ_RING_BYTES // per_set)))
     bufs = traj_buffers(vec, K, n_bufs)  # distinct slots per repeat: a repeat never rewrites lines still in the Infinity Cache
-    for set_ in bufs:                     # pre-touch: no repeat is the first writer of its buffer set's pages
-        for t in set_:
+    for set_ in bufs:                     # pre-touch: no repeat is the first writer of its buffer set's pages,
+        for t in set_:                    # nor the first call that hands this set to rollout_tensor (its checked slow path)
             t.zero_()
+        vec.rollout_tensor(acts[:1], trajectory=True, out=set_)  # (before the reset below: the env starts over afterwards)
     clk = torch.zeros((R, 2), dtype=torch.int64, device=dev)  # the step kernel's own clock stamps, one row per timed repeat
     vec.reset_tensor()
     pre = {"preconditioning_ms": 0.0, "preconditioning_launches": 0}
@@ -489,7 +490,12 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
         pre = {"preconditioning_ms": ms, "preconditioning_launches": nl,
                "preconditioning": "%d rollouts of %d steps of the same kernel on a scratch env and scratch trajectory buffers, each "
                                   "bracketed by synchronize like a timed repeat, untimed, before the warm-up steps" % (nl, K)}
-    # warm-up: the same kernel in the same output mode, bracketed like a repeat (chunks of <= K steps into the first set)
+    # the interpreter's cyclic garbage collector stays out of the timed repeats (a collection between ev0.record() and the launch
+    # is GPU idle time inside the interval: the second repeat of every run was 6 % slower than the others until it was switched off)
+    import gc
+    gc.collect()
+    gc.disable()
+    # warm-up: the same kernel in the same output mode, bracketed like a repeat (chunks of <= K steps into the LAST set)
     for w0 in range(0, W, K):
         bracketed_rollout(vec, acts[w0: min(W, w0 + K)], bufs[-1], use_dist)  # (the set the LAST repeat writes: no repeat finds its lines warm)
     walls, evs = [], []
@@ -497,6 +503,7 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
         launch_clock(vec, clk[r])
         w, e = bracketed_rollout(vec, acts[W + r * K: W + (r + 1) * K], bufs[r % n_bufs], use_dist)
         walls.append(w); evs.append(e)
+    gc.enable()
     launch_clock(vec, None)
     ch = clk.cpu().double()
     clocks = [float(ch[r, 0] / max(float(ch[r, 1]), 1.0)) * 0.1 for r in range(R)]

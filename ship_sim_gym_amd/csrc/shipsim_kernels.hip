@@ -1060,6 +1060,17 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
     auto ack_pose = [&]() {
         if (lane == 0) __hip_atomic_fetch_add(&sync_ack[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    // One-step launches only: the lidar waves say when their query — the launch's only one — has left its result keys in LDS, so
+    // that the observer can build this step's rows BEFORE the rendezvous (see `spec` in the observer).  The fourth word of the
+    // tile's sync block (zeroed with the others).
+    unsigned *sync_q = sync_bar + EPW / 64;
+    auto query_done = [&]() {
+        if (lane == 0) __hip_atomic_fetch_add(&sync_q[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_queries = [&]() {
+        while (__hip_atomic_load(&sync_q[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u)
+            __builtin_amdgcn_s_sleep(1);
+    };
     // The per-step rendezvous "B" of the tile's four waves (collide_ship, role 3's done bits and nearest goal, and this
     // step's lidar results are in; the result buffer of the other parity is free): an arrival counter in LDS instead of a
     // workgroup barrier — the four tiles of a workgroup share nothing but the staged bank, and at s_barrier each waited for
@@ -1211,6 +1222,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         // the first step's query needs nothing from role 3: it runs while role 3 integrates
         lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base), queue, beamtab, b_first, b_count,
                                          cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
+        if (K == 1) query_done();
         for (int k = 0; k < K; ++k) {
             if constexpr (NR == 4) wait_pose(k); // role 3 has published this step's post-step pose (six roles: collide_ship is roles 4 / 5's,
                                                  // this wave goes straight to the rendezvous and picks the pose up behind it)
@@ -1337,6 +1349,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         constexpr int F = 6 + NB;
         double pv[F];
         double ogp[DYN ? 2 * SSG_MAX_GOALS : 1];
+        unsigned gm_pre = 0u; // the goals listed BEFORE this launch's first step (what a one-step launch speculates its nearest goal on)
         {
             const int el = el_;
             const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
@@ -1357,6 +1370,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
             if constexpr (DYN) asm volatile("" : "+v"(pv[4]), "+v"(pv[5]));
             int map0_ = map0; unsigned gm0_ = gm0;
             asm volatile("" : "+v"(map0_), "+v"(gm0_));
+            gm_pre = gm0_;
             flush_tables();
             if (LDS_BANK) __builtin_amdgcn_s_waitcnt(0);
             __syncthreads(); // barrier 0
@@ -1418,6 +1432,45 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
             ack_pose();
             const int rec_off = map_id * SSG_MAP_STRIDE;
             SSG_STAMP_K(1);
+            // A ONE-step launch (ssg_step: every policy-in-the-loop caller, and every config-4 step) ends with this wave's rows,
+            // and used to build the new frame's half only after the rendezvous — ~5 k cycles (12 k in config 4) during which every
+            // other wave of the grid had finished.  Everything the new frame is made of is there BEFORE the rendezvous except what
+            // the rendezvous decides: whether the env is done (then the row is the next episode's first) and whether it reached a
+            // goal this step (then the nearest listed goal may be another).  So the half goes out now, speculating "neither", and the
+            // few lanes the rendezvous overrules rewrite their doubles afterwards (as the history half already does, below).
+#ifdef SSG_NO_SPEC /* tools/build_variant.sh nospec -DSSG_NO_SPEC: the round-5 schedule, for A/B timing */
+            const bool spec = false;
+#else
+            // (four-role tiles only: on the six-role tiles of the smaller batches the observer's row building is the longest chain
+            // of the step already, and waiting for the queries in front of it cost 0.25 us per step at 4 096 envs)
+            const bool spec = kSplitOk && NR == 4 && early && K == 1 && !SSG_ABL(7);
+#endif
+            double sp_gx = 0.0, sp_gy = 0.0;
+            if (kSplitOk && spec) {
+                wait_queries(); // both lidar waves' result keys are in LDS
+                const unsigned listed_pre = gm_pre & ((1u << c.n_goals) - 1u);
+                if constexpr (DYN) nearest_goal_regs(c.n_goals, listed_pre, x, y, ogp, sp_gx, sp_gy);
+                else nearest_goal<LDS_BANK, false>(c, rec_off + SSG_MAP_OFF_GOALS, listed_pre, x, y, sp_gx, sp_gy, hG, EPW);
+                double sv[F]; // (its own array, dead before the rendezvous: the frame kept across it would cost the fused path registers)
+                sv[0] = x; sv[1] = y; sv[2] = (double)rudder; sv[3] = ang; sv[4] = sp_gx; sv[5] = sp_gy;
+                int tw = __builtin_amdgcn_readfirstlane(tl >> 6);
+                int te0 = blockIdx.x * EPW + 64 * tw;
+                asm volatile("" : "+s"(tw), "+s"(te0));
+                const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(scratch0 + tw * lds_tile_bytes(NB)); // parity 0
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const unsigned long long key = rk[i * 64 + lane];
+                    const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
+                    sv[6 + i] = (key == kLidarMiss) ? pv[6 + i] : hitd;
+                }
+                double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + lds_res_bytes(NB)); // the other parity: free in a one-step launch
+                double *__restrict__ ob = obs + ((size_t)te0 + (size_t)k * (size_t)traj) * (size_t)(2 * F);
+                if constexpr (kPairs)
+                    write_obs_pairs<NB, true, F, 2 * F>(colbuf, [&](int j) -> double { return sv[(j < F) ? 0 : j - F]; }, ob, min(64, c.n_envs - te0), lane);
+                else
+                    write_obs_tile<NB, true, kSplitOk ? F / ObsTile<NB>::CP : 0, kObsPasses>(ot, colbuf, [&](int j) -> double {
+                        return sv[(j < F) ? 0 : j - F]; }, ob, min(64, c.n_envs - te0), lane);
+            }
             tile_barrier(k); // rendezvous B(k)
             SSG_STAMP_K(2);
 
@@ -1453,9 +1506,12 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
             }
             SSG_STAMP_K(4);
             // closest_goal (game.py:333-349) among the goals still listed, from the post-step position
-            double nf_gx = 0, nf_gy = 0;
-            if constexpr (DYN) nearest_goal_regs(c.n_goals, gd >> 8, x, y, ogp, nf_gx, nf_gy);
-            else if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
+            double nf_gx = sp_gx, nf_gy = sp_gy;
+            // (a speculating wave has computed it from the goals listed before the step: only a goal reached this step changes it)
+            if (!spec || __any((gd >> 8) != (gm_pre & ((1u << c.n_goals) - 1u)))) {
+                if constexpr (DYN) nearest_goal_regs(c.n_goals, gd >> 8, x, y, ogp, nf_gx, nf_gy);
+                else if (!SSG_ABL(0)) nearest_goal<LDS_BANK, false>(c, rec_off + SSG_MAP_OFF_GOALS, gd >> 8, x, y, nf_gx, nf_gy, hG, EPW);
+            }
             SSG_STAMP_K(5);
             int tile_w = __builtin_amdgcn_readfirstlane(tl >> 6);             // wave-uniform; laundered:
             int tile_e0 = blockIdx.x * EPW + 64 * tile_w;                    // no hoisted tile addresses
@@ -1509,7 +1565,25 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
                     // (the result keys are in registers by now; in a single-step launch the lidar waves still read them for
                     // the sticky columns, and the other parity's buffer is free)
                     double *colbuf = reinterpret_cast<double *>((K == 1) ? res_k + lds_res_bytes(NB) : res_k);
-                    if (kSplitOk && early) {
+                    if (kSplitOk && spec) {
+                        // the rows went out before the rendezvous; what it overruled: a reset env shows the next episode's first
+                        // observation (a history of -1, the spawn frame), an env that reached a goal may have another nearest goal
+                        const bool goal_moved = !do_reset & ((nf_gx != sp_gx) | (nf_gy != sp_gy));
+                        if (__any(do_reset | goal_moved)) {
+                            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the speculative stores of these addresses have completed
+                            if (lane < rows_live) {
+                                if (do_reset) {
+#pragma unroll
+                                    for (int j = 0; j < F; ++j) st_out(&obase[(unsigned)(lane * 2 * F + j)], -1.0);
+#pragma unroll
+                                    for (int j = 0; j < F; ++j) st_out(&obase[(unsigned)(lane * 2 * F + F + j)], nv[j]);
+                                } else if (goal_moved) {
+                                    st_out(&obase[(unsigned)(lane * 2 * F + F + 4)], nv[4]);
+                                    st_out(&obase[(unsigned)(lane * 2 * F + F + 5)], nv[5]);
+                                }
+                            }
+                        }
+                    } else if (kSplitOk && early) {
                         // the history of an env that starts a new episode: -1 over what went out early.  BEFORE this step's own
                         // stores: the early ones were issued a rendezvous ago and the wait below is for nothing, where after the
                         // new frame's stores it drained them too — a tile's whole write burst, at the moment every tile of the
