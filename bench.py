@@ -25,7 +25,8 @@ TEST-ONLY overrides (tests/test_sharding_gpu.py; never set by the driver): SSG_B
 on device 0 and SSG_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on a 1-GPU box; the
 line's `data` field then says "TEST RUN ... timings meaningless".
 
-Timing: an untimed, time-based device conditioning (`--precondition-ms`, default 300: the same K-step rollout on a SCRATCH env and
+Timing: the timed env is reset and stepped `--burn-in-steps` (default 1 000, `burn_in_steps`) untimed random-action steps, so that
+its episodes are no longer phase-locked; then an untimed, time-based device conditioning (`--precondition-ms`, default 300: the same K-step rollout on a SCRATCH env and
 scratch buffers, bracketed by synchronize exactly like a timed repeat and repeated until the time is up, reported as
 `preconditioning_ms`; every trajectory buffer set is written once beforehand), then W untimed warm-up steps, then the K-step
 rollout is timed `--repeats` (default 5) times (`repeats_min_ms` / `repeats_median_ms` / `repeats_max_ms`; the shader clock the
@@ -463,7 +464,7 @@ def precondition(pvec, pacts, pouts, min_ms, use_dist, dev):
     return (time.perf_counter() - t0) * 1e3, rounds
 
 
-def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
+def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, burn_in=0):
     """Device conditioning (untimed, scratch env and buffers), W untimed warm-up steps, then R timed repeats of exactly K
     trajectory-mode steps, each bracketed by barrier + synchronize on both sides; returns (wall seconds per repeat, MAX over ranks;
     HIP-event ms per repeat; buffer sets; the shader clock GHz the step kernel itself recorded in every repeat; preconditioning info)."""
@@ -479,6 +480,13 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
         vec.rollout_tensor(acts[:1], trajectory=True, out=set_)  # (before the reset below: the env starts over afterwards)
     clk = torch.zeros((R, 2), dtype=torch.int64, device=dev)  # the step kernel's own clock stamps, one row per timed repeat
     vec.reset_tensor()
+    # Burn-in of the timed env's STATE (untimed, declared as `burn_in_steps`): a freshly reset batch is phase-locked — every env
+    # starts its first episode in the same step, so steps 5-25 (no ship within lidar range of a bank yet) are ~4 % cheaper and
+    # steps 25-45 (every ship reaches the first goal and the banks at once) ~5 % dearer than the stationary mix a long rollout
+    # runs in (tools/phase_probe.py; it is what made the second of the driver form's five repeats the slowest in every run).
+    # `burn_in` random-action steps (~16 episodes per env at the default 1 000) desynchronise the episodes first.
+    for b0 in range(0, burn_in, 250):
+        vec.rollout_tensor(vec.random_actions(777, b0, min(250, burn_in - b0)))
     pre = {"preconditioning_ms": 0.0, "preconditioning_launches": 0}
     if precondition_ms > 0 and pvec is not None:
         pacts = pvec.random_actions(4321, 0, K)
@@ -491,7 +499,7 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None):
                "preconditioning": "%d rollouts of %d steps of the same kernel on a scratch env and scratch trajectory buffers, each "
                                   "bracketed by synchronize like a timed repeat, untimed, before the warm-up steps" % (nl, K)}
     # the interpreter's cyclic garbage collector stays out of the timed repeats (a collection between ev0.record() and the launch
-    # is GPU idle time inside the interval: the second repeat of every run was 6 % slower than the others until it was switched off)
+    # would be GPU idle time inside a 150-us interval)
     import gc
     gc.collect()
     gc.disable()
@@ -526,6 +534,10 @@ def main():
     ap.add_argument("--precondition-ms", type=float, default=300.0,
                     help="untimed device conditioning before the warm-up steps: the same kernel on a scratch env and scratch buffers "
                          "for at least this many ms of wall time (reported as preconditioning_ms; 0 = none)")
+    ap.add_argument("--burn-in-steps", type=int, default=1000,
+                    help="untimed random-action steps of the timed env after its reset and before the device conditioning and the "
+                         "warm-up steps, so that the timed steps run on a stationary mix of episode phases instead of a phase-locked "
+                         "batch (reported as burn_in_steps; 0 = time the steps right after the reset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true", help="skip the informational one-launch-per-step timing")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C4 timings")
@@ -618,7 +630,7 @@ def main():
     if args.precondition_ms > 0:
         pvec = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, env_id_base=rank * n,
                           n_ships=4 if c4 else 1)
-    walls, evs, n_bufs, clocks, pre = timed_rollouts(vec, K, W, R, use_dist, dev, args.precondition_ms, pvec)
+    walls, evs, n_bufs, clocks, pre = timed_rollouts(vec, K, W, R, use_dist, dev, args.precondition_ms, pvec, max(0, args.burn_in_steps))
     if pvec is not None:
         pvec.close()
         del pvec
@@ -725,6 +737,9 @@ def main():
             "value_min": total_steps / max(walls), "value_max": total_steps / min(walls),
             "repeats_event_ms": evs, "repeats_shader_clock_ghz": clocks,
             "preconditioning_ms": pre["preconditioning_ms"], "preconditioning": pre.get("preconditioning"),
+            "burn_in_steps": max(0, args.burn_in_steps),
+            "burn_in": "untimed random-action steps of the timed env between its reset and the warm-up steps: the timed steps run on a "
+                       "stationary mix of episode phases, not on a batch whose envs all started their first episode together",
             "roofline": dict({"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS,
                               "frac_note": "SURVEY 8d's algorithmic bytes per env-step (single-step API with persistent state) over "
@@ -792,6 +807,8 @@ def main():
                                               "4096_envs_10_beams": vecenv_numpy_path(dev, 4096, 10)}
                 # an end-to-end PPO loop over the zero-copy API: eager / HIP graph / two-half-batch ping-pong
                 other["ppo_torch_end_to_end"] = ppo_end_to_end(dev, n, out.get("single_step_launch_us"))
+                # (the same loop at BASELINE configs[1]'s size, where a rollout step is launch-bound and the graph pays)
+                other["ppo_torch_end_to_end_4096_envs"] = ppo_end_to_end(dev, 4096, None, updates=6, horizon=64)
                 other["c5_share_131072_envs_10_beams"] = side_config(dev, 131072, 10, 1, 500, 100)
                 # the headline's envs on a bank of 120 records, which the LDS only holds beside 64-env workgroups (four rounds per
                 # launch): gathered from L2 on 256-env workgroups instead (ssg_set_map_bank weighs the two)

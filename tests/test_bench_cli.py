@@ -49,6 +49,19 @@ def test_dry_launch_shows_the_child_job_and_starts_nothing():
     j = json.loads(p.stdout.strip())
     cmd = j["cmd"]
     assert j["dry_launch"] and j["n_ranks"] == 8
+    # the EXACT child command: the driver's own line for N > 1, nothing more
+    port = cmd[cmd.index("--master-port") + 1]
+    assert port.isdigit() and 1024 <= int(port) <= 65535
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", port, BENCH, "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # ... and the communication environment of the ranks: what the parent adds (dmabuf IPC, the loopback rendezvous) plus whatever
+    # HSA_ / HIP_ / ROCR_ / NCCL_ / RCCL_ / GPU_ / MASTER_ / CUDA_VISIBLE variables the caller had set — no rank variables (the
+    # launcher of torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE per rank)
+    want = {k: v for k, v in _env(NCCL_DEBUG="INFO").items()
+            if k.startswith(("HSA_", "HIP_", "ROCR_", "NCCL_", "RCCL_", "GPU_", "MASTER_", "TORCH_NCCL", "CUDA_VISIBLE"))}
+    want.update(HSA_ENABLE_IPC_MODE_LEGACY=want.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    assert j["env"] == want, (j["env"], want)
+    assert not {"RANK", "LOCAL_RANK", "WORLD_SIZE"} & set(j["env"])
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     tail = cmd[cmd.index(BENCH) + 1:]
