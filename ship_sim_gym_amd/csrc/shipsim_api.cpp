@@ -705,8 +705,10 @@ static int ring_refill(ssg_handle *h, double *dev_raw, void *stream)
                                              const_cast<double *>(h->bank), dev_raw, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ring refill launch: ") + hipGetErrorString(e));
     h->ring_credit = h->cfg.map_ring - 1;
-    h->dyn.bank_epoch++;
-    h->dyn_queue_valid = false;
+    // (A refill draws the worlds of FUTURE episodes — episodes current+1 .. current+R-1 of every env, into the R-1 slots its current
+    // episode does not occupy — so no env's current world changes: the rest bits (tagged with the bank epoch) and the queue of the
+    // next full cpSpaceStep stay valid.  Until round 6 a refill bumped the epoch and dropped the queue: every env of a config-4
+    // handle was classified and stepped in full once per refill cycle, ~13 us per step on rings of 32.)
     return SSG_OK;
 }
 

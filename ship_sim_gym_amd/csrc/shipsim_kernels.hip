@@ -1060,9 +1060,9 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
     auto ack_pose = [&]() {
         if (lane == 0) __hip_atomic_fetch_add(&sync_ack[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    // One-step launches only: the lidar waves say when their query — the launch's only one — has left its result keys in LDS, so
-    // that the observer can build this step's rows BEFORE the rendezvous (see `spec` in the observer).  The fourth word of the
-    // tile's sync block (zeroed with the others).
+    // The lidar waves say when the query of the launch's LAST step (a one-step launch's only one) has left its result keys in LDS,
+    // so that the observer can build that step's rows BEFORE its rendezvous (see `spec` in the observer).  The fourth word of the
+    // tile's sync block (zeroed with the others); raised once per launch by each of the two lidar waves.
     unsigned *sync_q = sync_bar + EPW / 64;
     auto query_done = [&]() {
         if (lane == 0) __hip_atomic_fetch_add(&sync_q[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1277,6 +1277,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
                 }
                 lidar_query<NB, LDS_BANK, EXACT>(c, reinterpret_cast<unsigned long long *>(tile_base + ((k + 1) & 1) * lds_res_bytes(NB)),
                                                  queue, beamtab, b_first, b_count, cx, cy, ca, sa, map_id * SSG_MAP_STRIDE, live, lane, hL, EPW);
+                if (k + 1 == K - 1) query_done(); // the launch's last query: the observer builds the last step's rows before its rendezvous
             }
             SSG_STAMP_K(2);
         }
@@ -1349,7 +1350,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         constexpr int F = 6 + NB;
         double pv[F];
         double ogp[DYN ? 2 * SSG_MAX_GOALS : 1];
-        unsigned gm_pre = 0u; // the goals listed BEFORE this launch's first step (what a one-step launch speculates its nearest goal on)
+        unsigned gm_pre = 0u; // the goals listed BEFORE the step at hand (what the launch's last step speculates its nearest goal on)
         {
             const int el = el_;
             const double x0 = colX[el], y0 = colY[el], a0 = colA[el];
@@ -1432,9 +1433,9 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
             ack_pose();
             const int rec_off = map_id * SSG_MAP_STRIDE;
             SSG_STAMP_K(1);
-            // A ONE-step launch (ssg_step: every policy-in-the-loop caller, and every config-4 step) ends with this wave's rows,
-            // and used to build the new frame's half only after the rendezvous — ~5 k cycles (12 k in config 4) during which every
-            // other wave of the grid had finished.  Everything the new frame is made of is there BEFORE the rendezvous except what
+            // A launch ends with this wave's rows of its LAST step (in a one-step launch — ssg_step: every policy-in-the-loop
+            // caller, every config-4 step — that is all there is), and used to build the new frame's half only after the
+            // rendezvous — ~5 k cycles (12 k in config 4) during which every other wave of the grid had finished.  Everything the new frame is made of is there BEFORE the rendezvous except what
             // the rendezvous decides: whether the env is done (then the row is the next episode's first) and whether it reached a
             // goal this step (then the nearest listed goal may be another).  So the half goes out now, speculating "neither", and the
             // few lanes the rendezvous overrules rewrite their doubles afterwards (as the history half already does, below).
@@ -1443,7 +1444,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
 #else
             // (four-role tiles only: on the six-role tiles of the smaller batches the observer's row building is the longest chain
             // of the step already, and waiting for the queries in front of it cost 0.25 us per step at 4 096 envs)
-            const bool spec = kSplitOk && NR == 4 && early && K == 1 && !SSG_ABL(7);
+            const bool spec = kSplitOk && NR == 4 && early && !SSG_ABL(7);
 #endif
             double sp_gx = 0.0, sp_gy = 0.0;
             if (kSplitOk && spec) {
@@ -1456,14 +1457,15 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
                 int tw = __builtin_amdgcn_readfirstlane(tl >> 6);
                 int te0 = blockIdx.x * EPW + 64 * tw;
                 asm volatile("" : "+s"(tw), "+s"(te0));
-                const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(scratch0 + tw * lds_tile_bytes(NB)); // parity 0
+                const unsigned long long *rk = reinterpret_cast<const unsigned long long *>(scratch0 + tw * lds_tile_bytes(NB) + (k & 1) * lds_res_bytes(NB));
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const unsigned long long key = rk[i * 64 + lane];
                     const double hitd = __longlong_as_double((long long)(key & 0x7FFFFFFFFFFFFFFFull));
                     sv[6 + i] = (key == kLidarMiss) ? pv[6 + i] : hitd;
                 }
-                double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + lds_res_bytes(NB)); // the other parity: free in a one-step launch
+                // the other parity's buffer: nobody queries into it any more (this is the launch's last step)
+                double *colbuf = reinterpret_cast<double *>(scratch0 + tw * lds_tile_bytes(NB) + ((k + 1) & 1) * lds_res_bytes(NB));
                 double *__restrict__ ob = obs + ((size_t)te0 + (size_t)k * (size_t)traj) * (size_t)(2 * F);
                 if constexpr (kPairs)
                     write_obs_pairs<NB, true, F, 2 * F>(colbuf, [&](int j) -> double { return sv[(j < F) ? 0 : j - F]; }, ob, min(64, c.n_envs - te0), lane);
@@ -1625,6 +1627,7 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
             }
 #pragma unroll
             for (int i = 0; i < F; ++i) pv[i] = nv[i];
+            gm_pre = do_reset ? ((1u << c.n_goals) - 1u) : (gd >> 8); // the goals listed before the next step (a fresh episode: all)
             if (k == K - 1 && K > 1 && live && !SSG_ABL(9)) { // the sticky readings go back to the state columns with the last step
                 int el = el_; // (laundered: the addresses of the head's loads are not kept live — and spilled — around the step loop)
                 asm volatile("" : "+v"(el));

@@ -43,3 +43,9 @@ def test_bench_line_carries_the_contract_fields():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["single_thread"]["cores"] == 1
     assert j["single_step_launch_us"] > 0 and len(j["single_step_launch_us_repeats"]) >= 5
+    # the timed repeats: spread, the shader clock the step kernel recorded in each, and what preceded them (all untimed, all declared)
+    assert len(j["repeats_ms"]) == j["repeats"] == len(j["repeats_shader_clock_ghz"]) == len(j["repeats_event_ms"])
+    assert j["repeats_min_ms"] <= j["repeats_median_ms"] <= j["repeats_max_ms"]
+    assert abs(j["repeats_median_ms"] - j["ms_per_step"] * 20) < 1e-9 and j["value_min"] <= j["value"] <= j["value_max"]
+    assert all(0.5 < g < 3.0 for g in j["repeats_shader_clock_ghz"]), j["repeats_shader_clock_ghz"]   # GHz, from s_memtime / s_memrealtime
+    assert j["preconditioning_ms"] >= 300.0 and j["burn_in_steps"] == 1000 and "scratch" in j["preconditioning"]

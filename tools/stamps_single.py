@@ -7,7 +7,8 @@ import numpy as np, torch
 from ship_sim_gym_amd import _native as N
 from ship_sim_gym_amd.vec_env import ShipVecEnv
 n = int(os.environ.get("SSG_N", "65536")); nb = int(os.environ.get("SSG_NB", "8"))
-vec = ShipVecEnv(n, n_maps=64, n_beams=nb, n_ships=int(os.environ.get("SSG_SHIPS", "1")))
+mode = os.environ.get("SSG_MODE", "bank")  # "fresh_device": per-env rings of worlds (RING records each), the bank gathered from L2 / HBM
+vec = ShipVecEnv(n, n_maps=64, n_beams=nb, n_ships=int(os.environ.get("SSG_SHIPS", "1")), map_mode=mode, ring=int(os.environ.get("RING", "32")))
 L = N.lib()
 epw = 64 if n <= 64 * 256 else (128 if n <= 128 * 256 else 256)
 nw = 4 * ((n + epw - 1) // epw) * epw // 64
