@@ -29,7 +29,8 @@ extern "C" {
                              6: ssg_rollout_traj (every step of a fused rollout lands in its own slot of a trajectory buffer);
                              7: SSG_FLAG_DYN_MEMO_OFF, SSG_F_DYN_MEMO_STATS (config 4: the memo table of the full cpSpaceStep lives
                                 in the state blob, which grows by ~30 MB);
-                             8: ssg_set_terminal_obs (the RLlib flow without a reset launch), ssg_debug_launch_clock, ssg_debug_clock_probe */
+                             8: ssg_set_terminal_obs (the RLlib flow without a reset launch), ssg_step_host / ssg_wait_host (a numpy-protocol step in one
+                                call), ssg_debug_launch_clock, ssg_debug_clock_probe */
 
 typedef enum ssg_status {
     SSG_OK = 0,
@@ -230,6 +231,20 @@ int ssg_reset(ssg_handle *h, const uint8_t *dev_mask, const int32_t *dev_map_ids
  * dev_flags u8[n_envs] event bits SSG_EV_* or NULL. */
 int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
              uint8_t *dev_flags /* nullable */, void *stream);
+
+/* Replaces: one `env.step(actions)` of the reference's trainers on HOST arrays (train/stable_baselines/ppo.py:122-123: SubprocVecEnv's
+ * pipe round trip per step; train/rllib/ppo.py:21-44) — the whole step of the numpy protocols in ONE call, all asynchronous on `stream`:
+ * host_actions (i32[n_envs], pinned host memory) -> dev_actions, ssg_step into dev_obs / dev_reward / dev_done / dev_flags, then ONE copy
+ * of the caller's packed output block [dev_block, dev_block + block_bytes) — which those four buffers are sections of — into host_block
+ * (pinned host memory), and a completion event of the handle's `slot` (0..7: callers rotate host blocks so that the arrays of one step
+ * stay valid while the next steps run).  ssg_wait_host(h, slot) blocks the calling thread until that step's host block is complete.
+ * What ShipVecEnv.step_async / step_wait are made of: one foreign call each instead of a dozen interpreter-level stream / copy / event
+ * operations (which cost more than the 14-us step at small batches). */
+int ssg_step_host(ssg_handle *h, const int32_t *host_actions, int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
+                  uint8_t *dev_flags /* nullable */, const void *dev_block, void *host_block, size_t block_bytes, int slot, void *stream);
+/* Replaces: the blocking half of that step — SubprocVecEnv.step_wait's `remote.recv()` (train/stable_baselines/ppo.py:122-123) — for
+ * the step issued into `slot`: returns when its host block is complete. */
+int ssg_wait_host(ssg_handle *h, int slot);
 
 /* Replaces: what RLlib's VectorEnv flow sees of an episode's end (train/rllib/ppo.py:21-44 over ShipEnv.step / ShipEnv.reset,
  * ship_env.py:136-156,171-184): vector_step reports the TERMINAL observation of a done env, reset_at then resets it and returns the

@@ -26,7 +26,7 @@ EXPORTS = (
     "ssg_step", "ssg_rollout", "ssg_fill_actions", "ssg_host_convex_hull", "ssg_host_moment_for_poly", "ssg_host_goal_x_range",
     "ssg_host_build_map", "ssg_host_segment_query", "ssg_debug_copy8", "ssg_generate_bank", "ssg_render", "ssg_dyn_invalidate",
     "ssg_init_state", "ssg_refill_worlds", "ssg_debug_launch_geometry", "ssg_rollout_traj", "ssg_debug_dyn_counters", "ssg_debug_kernel_times",
-    "ssg_debug_clock_probe", "ssg_debug_launch_clock", "ssg_set_terminal_obs",
+    "ssg_debug_clock_probe", "ssg_debug_launch_clock", "ssg_set_terminal_obs", "ssg_step_host", "ssg_wait_host",
 )
 
 
@@ -98,6 +98,8 @@ def lib():
     L.ssg_debug_clock_probe.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ssg_debug_launch_clock.argtypes = [vp, vp]
     L.ssg_set_terminal_obs.argtypes = [vp, vp]
+    L.ssg_step_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
+    L.ssg_wait_host.argtypes = [vp, C.c_int]
     L.ssg_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp]
     L.ssg_dyn_invalidate.argtypes = [vp, vp, vp]
     L.ssg_host_convex_hull.argtypes = [C.c_int, dp, dp, ip]

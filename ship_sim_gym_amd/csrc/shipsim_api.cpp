@@ -48,6 +48,10 @@ struct ssg_handle {
     int ring_credit = 0;
     size_t off_ring_queue = 0, off_ring_count = 0;
     bool remap_pending = false; // the bank shrank: ICOL_MAP must be taken modulo n_maps before the next kernel reads it
+    // ssg_step_host / ssg_wait_host: one completion event per host block slot, created on first use
+    static constexpr int kHostSlots = 8;
+    hipEvent_t host_ev[kHostSlots] = {};
+    bool host_ev_made[kHostSlots] = {};
     std::string err;
 };
 
@@ -572,6 +576,9 @@ int ssg_create(const ssg_config *cfg, ssg_handle **out)
 
 int ssg_destroy(ssg_handle *h)
 {
+    if (h)
+        for (int i = 0; i < ssg_handle::kHostSlots; ++i)
+            if (h->host_ev_made[i]) (void)hipEventDestroy(h->host_ev[i]);
     delete h;
     return SSG_OK;
 }
@@ -781,6 +788,34 @@ int ssg_step(ssg_handle *h, const int32_t *dev_actions, double *dev_obs, double 
              uint8_t *dev_flags, void *stream)
 {
     return ssg_rollout_traj(h, dev_actions, 1, dev_obs, dev_reward, dev_done, dev_flags, 0, stream);
+}
+
+int ssg_step_host(ssg_handle *h, const int32_t *host_actions, int32_t *dev_actions, double *dev_obs, double *dev_reward, uint8_t *dev_done,
+                  uint8_t *dev_flags, const void *dev_block, void *host_block, size_t block_bytes, int slot, void *stream)
+{
+    if (!h || !host_actions || !dev_actions || !dev_block || !host_block || block_bytes == 0 || slot < 0 || slot >= ssg_handle::kHostSlots)
+        return fail(h, SSG_ERR_BAD_ARG, "ssg_step_host: NULL buffer, empty block or slot out of range");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!h->host_ev_made[slot]) {
+        if (hipEventCreateWithFlags(&h->host_ev[slot], hipEventDisableTiming) != hipSuccess) return fail(h, SSG_ERR_HIP, "ssg_step_host: hipEventCreate failed");
+        h->host_ev_made[slot] = true;
+    }
+    hipError_t e = hipMemcpyAsync(dev_actions, host_actions, (size_t)h->cfg.n_envs * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_step_host: actions host -> device: ") + hipGetErrorString(e));
+    int rc = ssg_step(h, dev_actions, dev_obs, dev_reward, dev_done, dev_flags, stream);
+    if (rc != SSG_OK) return rc;
+    e = hipMemcpyAsync(host_block, dev_block, block_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(h->host_ev[slot], st);
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_step_host: outputs device -> host: ") + hipGetErrorString(e));
+    return SSG_OK;
+}
+
+int ssg_wait_host(ssg_handle *h, int slot)
+{
+    if (!h || slot < 0 || slot >= ssg_handle::kHostSlots || !h->host_ev_made[slot]) return fail(h, SSG_ERR_BAD_ARG, "ssg_wait_host: no ssg_step_host was issued into this slot");
+    hipError_t e = hipEventSynchronize(h->host_ev[slot]);
+    if (e != hipSuccess) return fail(h, SSG_ERR_HIP, std::string("ssg_wait_host: ") + hipGetErrorString(e));
+    return SSG_OK;
 }
 
 int ssg_rollout(ssg_handle *h, const int32_t *dev_actions, int K, double *dev_obs, double *dev_reward,

@@ -597,6 +597,35 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
         ar[s] = rt.x + eps;
         at[s] = rt.y + eps;
     }
+#ifdef SSG_QUEUE_BEAM_MAJOR /* the round-2..5 order (tools/build_variant.sh beammajor -DSSG_QUEUE_BEAM_MAJOR), for A/B timing */
+#pragma unroll
+    for (int k = 0; k < NB0; ++k) {
+        if (k < b_count) { // wave-uniform
+            const int i = b_first + k;
+            res[i * 64 + lane] = kLidarMiss;
+            if (!SSG_ABL(1)) {
+                double ex, ey;
+                beam_end(cx, cy, ca, sa, beamtab[i], beamtab[SSG_MAX_BEAMS + i], c.lidar_dist, ex, ey);
+                const double lox = dmin(cx, ex), hix = dmax(cx, ex), loy = dmin(cy, ey), hiy = dmax(cy, ey);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bool need = live & (lox <= ar[s]) & (al[s] <= hix) & (loy <= at[s]) & (ab[s] <= hiy);
+                    const unsigned long long m = __ballot(need);
+                    const int pos = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (k << 6) | (s << 10));
+                    n_items += __popcll(m);
+                }
+            }
+        }
+    }
+#else
+    // ENV-MAJOR queue (round 6): every lane first collects which of its 2 x NB0 (beam, hull) pairs survive the cull in a bit
+    // mask, an inclusive scan of the counts over the wave (six DPP adds, no LDS) gives every lane the slot of its first pair,
+    // and it writes its pairs back to back.  The worker lanes of a pass then serve the pairs of ONE env side by side: they read
+    // the same record's planes at the same LDS addresses (a broadcast) where the beam-major order put 64 different envs —
+    // 64 records, several to a bank — next to each other (rocprofv3 SQ_LDS_BANK_CONFLICT: 27 % of the LDS pipe's busy cycles).
+    unsigned needmask = 0u;
 #pragma unroll
     for (int k = 0; k < NB0; ++k) {
         if (k < b_count) { // wave-uniform
@@ -613,15 +642,35 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
                 for (int s = 0; s < 2; ++s) {
                     // keep the pair unless the beam's box and the hull's (widened) box are disjoint
                     const bool need = live & (lox <= ar[s]) & (al[s] <= hix) & (loy <= at[s]) & (ab[s] <= hiy);
-                    const unsigned long long m = __ballot(need);
-                    const int pos = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (k << 6) | (s << 10));
-                    n_items += __popcll(m);
+                    needmask |= need ? (1u << (2 * k + s)) : 0u;
                 }
             }
         }
     }
+    {
+        const int cnt = __popc(needmask);
+        int incl = cnt; // inclusive scan over the wave: row_shr 1, 2, 4, 8 inside the rows of 16, then the rows' totals forwarded
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+        n_items = __builtin_amdgcn_readlane(incl, 63);
+        int pos = incl - cnt;
+#pragma unroll
+        for (int k = 0; k < NB0; ++k) {
+            if (k < b_count) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bool need = (needmask >> (2 * k + s)) & 1u;
+                    queue[need ? pos : (kTrash + lane)] = (unsigned short)(lane | (k << 6) | (s << 10));
+                    pos += need ? 1 : 0;
+                }
+            }
+        }
+    }
+#endif
     if (!SSG_ABL(3))
         lidar_pass<LDS_BANK, EXACT>(c, n_items, queue, res + b_first * 64, beamtab + b_first, cx, cy, ca, sa, rec_off, lane,
                                     hL ? hL - lane : nullptr, ld);

@@ -190,7 +190,7 @@ class ShipVecEnv(*_BASES):
         self._o_done = self._o_rew + up(n_ * 8)
         self._o_flags = self._o_done + up(n_)
         self._out_nbytes = self._o_flags + up(n_)
-        self.host_slots = max(2, int(host_slots))
+        self.host_slots = max(2, min(8, int(host_slots)))  # (ssg_step_host has eight completion-event slots)
         self.copy_host_outputs = bool(copy_host_outputs)
         with torch.cuda.device(self.device):
             self.state = torch.zeros(nbytes.value, dtype=torch.uint8, device=self.device)
@@ -285,7 +285,8 @@ class ShipVecEnv(*_BASES):
 
     def _host_side(self):
         """The host half of the numpy protocols, made once: `host_slots` pinned output blocks (rotated, so that the arrays of
-        one step stay valid while the next steps run), a pinned action buffer, a side stream and one event per slot."""
+        one step stay valid while the next steps run), a pinned action buffer and a side stream (the completion events live
+        in the handle: ssg_step_host / ssg_wait_host)."""
         if self._host is None:
             torch = _torch()
             with torch.cuda.device(self.device):
@@ -293,8 +294,9 @@ class ShipVecEnv(*_BASES):
                 acts = torch.empty(self.num_envs, dtype=torch.int32, pin_memory=True)
                 self._host = {"blocks": blocks,
                               "np": [tuple(v.numpy() for v in self._blob_views(b)) for b in blocks],
-                              "acts": acts, "acts_np": acts.numpy(), "stream": torch.cuda.Stream(device=self.device),
-                              "events": [torch.cuda.Event() for _ in range(self.host_slots)], "slot": 0, "inflight": None,
+                              "acts": acts, "acts_np": acts.numpy(), "acts_ptr": acts.data_ptr(),
+                              "block_ptrs": [b.data_ptr() for b in blocks], "stream": torch.cuda.Stream(device=self.device),
+                              "step_host": N.lib().ssg_step_host, "wait_host": N.lib().ssg_wait_host, "slot": 0, "inflight": None,
                               "infos": [{} for _ in range(self.num_envs)]}
         return self._host
 
@@ -610,17 +612,23 @@ class ShipVecEnv(*_BASES):
         self._pending = a.astype(np.int32).reshape(self.num_envs)
         if self._closed:
             return
-        torch = _torch()
         hs = self._host_side()
         np.copyto(hs["acts_np"], self._pending)
         slot = hs["slot"]
+        torch = _torch()
         io = hs["stream"]
         io.wait_stream(torch.cuda.current_stream(self.device))  # after whatever the tensor API queued (a reset, say)
-        with torch.cuda.stream(io):
-            self._actions.copy_(hs["acts"], non_blocking=True)
-            self.step_tensor(self._actions)
-            hs["blocks"][slot].copy_(self._out_blob, non_blocking=True)
-            hs["events"][slot].record(io)
+        # ONE foreign call: actions host -> device, ssg_step, the packed block device -> host, the slot's completion event
+        rc = hs["step_host"](self._h, hs["acts_ptr"], self._actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                             self.done.data_ptr(), self.flags.data_ptr(), self._out_blob.data_ptr(), hs["block_ptrs"][slot],
+                             self._out_nbytes, slot, io.cuda_stream)
+        if rc:
+            with torch.cuda.device(self.device):  # (called with another device current: switch and repeat, then report)
+                rc = hs["step_host"](self._h, hs["acts_ptr"], self._actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                     self.done.data_ptr(), self.flags.data_ptr(), self._out_blob.data_ptr(), hs["block_ptrs"][slot],
+                                     self._out_nbytes, slot, io.cuda_stream)
+            if rc:
+                N.check(rc, self._h, "ssg_step_host")
         hs["inflight"] = slot
         hs["slot"] = (slot + 1) % self.host_slots
 
@@ -636,8 +644,8 @@ class ShipVecEnv(*_BASES):
         if slot is None:
             raise N.ShipSimError("step_wait without a step_async")
         hs["inflight"] = None
-        hs["events"][slot].synchronize()
-        torch.cuda.current_stream(self.device).wait_stream(hs["stream"])  # later tensor-API calls see this step
+        # (the step is COMPLETE when this returns — a host-side wait on the slot's event — so later tensor-API calls on any stream see it)
+        N.check(hs["wait_host"](self._h, slot), self._h, "ssg_wait_host")
         obs_h, rew_h, done_u8, _ = hs["np"][slot]
         done_h = done_u8.view(np.bool_).copy()
         if self.map_mode == "fresh" and self.auto_reset and done_h.any():
