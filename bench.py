@@ -485,8 +485,8 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, 
     # steps 25-45 (every ship reaches the first goal and the banks at once) ~5 % dearer than the stationary mix a long rollout
     # runs in (tools/phase_probe.py; it is what made the second of the driver form's five repeats the slowest in every run).
     # `burn_in` random-action steps (~16 episodes per env at the default 1 000) desynchronise the episodes first.
-    for b0 in range(0, burn_in, 250):
-        vec.rollout_tensor(vec.random_actions(777, b0, min(250, burn_in - b0)))
+    for b0 in range(0, burn_in, 200):  # (whole 100-step launches: a kernel trace of this command averages over equal launches)
+        vec.rollout_tensor(vec.random_actions(777, b0, min(200, burn_in - b0)))
     pre = {"preconditioning_ms": 0.0, "preconditioning_launches": 0}
     if precondition_ms > 0 and pvec is not None:
         pacts = pvec.random_actions(4321, 0, K)
