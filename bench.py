@@ -478,6 +478,12 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, 
         for t in set_:                    # nor the first call that hands this set to rollout_tensor (its checked slow path)
             t.zero_()
         vec.rollout_tensor(acts[:1], trajectory=True, out=set_)  # (before the reset below: the env starts over afterwards)
+    wbuf = bufs[0]
+    if n_bufs > 1:  # the warm-up steps get a set of their own: no repeat finds lines of ITS set still in the Infinity Cache
+        wbuf = traj_buffers(vec, K, 1)[0]
+        for t in wbuf:
+            t.zero_()
+        vec.rollout_tensor(acts[:1], trajectory=True, out=wbuf)
     clk = torch.zeros((R, 2), dtype=torch.int64, device=dev)  # the step kernel's own clock stamps, one row per timed repeat
     vec.reset_tensor()
     # Burn-in of the timed env's STATE (untimed, declared as `burn_in_steps`): a freshly reset batch is phase-locked — every env
@@ -503,9 +509,9 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, 
     import gc
     gc.collect()
     gc.disable()
-    # warm-up: the same kernel in the same output mode, bracketed like a repeat (chunks of <= K steps into the LAST set)
+    # warm-up: the same kernel in the same output mode, bracketed like a repeat (chunks of <= K steps into a set of their own)
     for w0 in range(0, W, K):
-        bracketed_rollout(vec, acts[w0: min(W, w0 + K)], bufs[-1], use_dist)  # (the set the LAST repeat writes: no repeat finds its lines warm)
+        bracketed_rollout(vec, acts[w0: min(W, w0 + K)], wbuf, use_dist)
     walls, evs = [], []
     for r in range(R):
         launch_clock(vec, clk[r])
@@ -519,7 +525,7 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, 
         t = torch.tensor(walls, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time, repeat by repeat
         walls = [float(v) for v in t.tolist()]
-    del bufs, acts
+    del bufs, acts, wbuf
     torch.cuda.empty_cache()
     return walls, evs, n_bufs, clocks, pre
 

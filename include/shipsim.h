@@ -326,7 +326,9 @@ int ssg_refill_worlds(ssg_handle *h, uint64_t seed, double width_frac, double *d
  * columns are recomputed for every env whatever the mask says.)
  * The caller-owned state blob also holds the queue of the next full cpSpaceStep, whose live counter set is named by the HANDLE:
  * a blob that is copied, restored in place or bound to another handle between two steps must be followed by ssg_bind_state or
- * ssg_dyn_invalidate(h, NULL, ...) — both make the next step rebuild the queue from the per-env flags. */
+ * ssg_dyn_invalidate(h, NULL, ...) — both make the next step rebuild the queue from the per-env flags AND start the memo tables
+ * inside the blob empty (a memo key names the bank RECORD, not the bank's contents: entries another handle stored over another bank
+ * must never answer for this one). */
 int ssg_dyn_invalidate(ssg_handle *h, const uint8_t *dev_mask, void *stream);
 
 /* Replaces: ShipGame.render + ShipGame.get_screen (game.py:133-138,197-229) for ONE env: an RGB frame of `width` x
