@@ -29,6 +29,10 @@ for r in range(R):
     span += (b[..., 10].max(axis=(1, 2)) - b[..., 8].min(axis=(1, 2))).mean()
 acc /= R
 print("workgroup span (first wave start -> last wave end): %.0f cycles" % (span / R))
+sp = (b[..., 10].max(axis=(1, 2)) - b[..., 8].min(axis=(1, 2)))
+st = b[..., 8].min(axis=(1, 2)); en = b[..., 10].max(axis=(1, 2))
+print("last launch: span per workgroup min %.0f median %.0f p99 %.0f max %.0f | first start -> last end over the whole grid: %.0f cycles | start skew (max - min of the workgroups' first-wave starts) %.0f" % (
+    sp.min(), np.median(sp), np.percentile(sp, 99), sp.max(), en.max() - st.min(), st.max() - st.min()))
 for role, nm in ((0, "lidar lo"), (1, "lidar hi"), (2, "observer"), (3, "body")):
     a = acc[role]
     print("role %d %-9s start %6.0f | after barrier 0 %6.0f | stamps %s | end %6.0f" % (
