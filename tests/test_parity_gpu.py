@@ -603,6 +603,35 @@ def test_numpy_protocol_is_the_tensor_path_through_pinned_blocks(torch_cuda, nat
     a_env.close(); b_env.close(); c_env.close()
 
 
+def test_terminal_obs_is_refused_where_it_cannot_be_served(torch_cuda, native):
+    """ssg_set_terminal_obs needs the in-kernel auto-reset (otherwise a done env's row of `obs` already IS its terminal observation) and
+    history <= 2 (longer histories are assembled by the frame-shift kernel); a trajectory rollout keeps every step in its own slot and
+    never writes the side buffer."""
+    import torch
+    from ship_sim_gym_amd.config import EnvConfig
+
+    class H3(EnvConfig):
+        HISTORY_SIZE = 3
+
+    v = _vec(64, n_maps=4, auto_reset=False)
+    with pytest.raises(native.ShipSimError):
+        v.enable_terminal_obs()
+    v.close()
+    v = _vec(64, n_maps=4, env_config=H3)
+    with pytest.raises(native.ShipSimError):
+        v.enable_terminal_obs()
+    v.close()
+    v = _vec(512, n_maps=4)
+    term = v.enable_terminal_obs()
+    term.fill_(-7.0)
+    v.reset_tensor()
+    to, tr, td, tf = v.rollout_tensor(v.random_actions(3, 0, 150), trajectory=True)
+    assert td.sum() > 0 and bool((term == -7.0).all())          # episodes ended, the side buffer was not touched
+    v.rollout_tensor(v.random_actions(4, 0, 150))                # overwrite mode: it is
+    assert bool((term != -7.0).any())
+    v.close()
+
+
 @pytest.mark.parametrize("hist", [2, 3])
 def test_rllib_flow_terminal_obs_and_single_reset(torch_cuda, native, hist):
     """RLlib VectorEnv flow (train/rllib/ppo.py:21-24,43): vector_step returns the TERMINAL observation of a done env,
