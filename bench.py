@@ -485,6 +485,13 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, 
             t.zero_()
         vec.rollout_tensor(acts[:1], trajectory=True, out=wbuf)
     clk = torch.zeros((R, 2), dtype=torch.int64, device=dev)  # the step kernel's own clock stamps, one row per timed repeat
+    # The interpreter's cyclic garbage collector stays out of the conditioning and the timed repeats: collected and switched off HERE,
+    # before anything is conditioned.  (Round 6 first did this between the conditioning and the warm-up steps: a gc.collect() with
+    # torch loaded takes tens of milliseconds, the GPU idled through it, and every timed repeat then ran at the 2.13 GHz of a GPU
+    # that has just woken up instead of the 2.39 GHz the conditioning had brought it to — 8.7 instead of 9.3 G env-steps/s.)
+    import gc
+    gc.collect()
+    gc.disable()
     vec.reset_tensor()
     # Burn-in of the timed env's STATE (untimed, declared as `burn_in_steps`): a freshly reset batch is phase-locked — every env
     # starts its first episode in the same step, so steps 5-25 (no ship within lidar range of a bank yet) are ~4 % cheaper and
@@ -504,11 +511,6 @@ def timed_rollouts(vec, K, W, R, use_dist, dev, precondition_ms=0.0, pvec=None, 
         pre = {"preconditioning_ms": ms, "preconditioning_launches": nl,
                "preconditioning": "%d rollouts of %d steps of the same kernel on a scratch env and scratch trajectory buffers, each "
                                   "bracketed by synchronize like a timed repeat, untimed, before the warm-up steps" % (nl, K)}
-    # the interpreter's cyclic garbage collector stays out of the timed repeats (a collection between ev0.record() and the launch
-    # would be GPU idle time inside a 150-us interval)
-    import gc
-    gc.collect()
-    gc.disable()
     # warm-up: the same kernel in the same output mode, bracketed like a repeat (chunks of <= K steps into a set of their own)
     for w0 in range(0, W, K):
         bracketed_rollout(vec, acts[w0: min(W, w0 + K)], wbuf, use_dist)
