@@ -597,6 +597,7 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
         ar[s] = rt.x + eps;
         at[s] = rt.y + eps;
     }
+    (void)ab; (void)at; // (only the -DSSG_QUEUE_BEAM_MAJOR / -DSSG_CULL_XY variants test the y ranges)
 #ifdef SSG_QUEUE_BEAM_MAJOR /* the round-2..5 order (tools/build_variant.sh beammajor -DSSG_QUEUE_BEAM_MAJOR), for A/B timing */
 #pragma unroll
     for (int k = 0; k < NB0; ++k) {
@@ -637,11 +638,14 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
                 // reference's per-beam cos/sin to ~1e-13 and only feeds lidar readings, never the dynamics.
                 double ex, ey;
                 beam_end(cx, cy, ca, sa, beamtab[i], beamtab[SSG_MAX_BEAMS + i], c.lidar_dist, ex, ey);
-                const double lox = dmin(cx, ex), hix = dmax(cx, ex), loy = dmin(cy, ey), hiy = dmax(cy, ey);
+                const double lox = dmin(cx, ex), hix = dmax(cx, ex);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    // keep the pair unless the beam's box and the hull's (widened) box are disjoint
-                    const bool need = live & (lox <= ar[s]) & (al[s] <= hix) & (loy <= at[s]) & (ab[s] <= hiy);
+                    // keep the pair unless the beam's box and the hull's (widened) box are disjoint IN X.  (A cull only has to be
+                    // conservative: a pair it keeps in vain runs through the segment query and reports a miss.  The banks span the
+                    // whole height of the world — game_map.py:22-73: y from -100 to 1.2 H — so the y half of the box test rejected
+                    // nothing and cost four compares and two min / max per pair: 80 of the cull's ~290 wave-instructions.)
+                    const bool need = live & (lox <= ar[s]) & (al[s] <= hix);
                     needmask |= need ? (1u << (2 * k + s)) : 0u;
                 }
             }
