@@ -178,6 +178,9 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
     gx = -1.0;
     gy = -1.0;
     double best = INFINITY;
+    // (the loops track the winner's INDEX and fetch its centre once at the end — two selects per goal instead of six; the
+    // centre reported is the stored one either way)
+    int gi = -1;
     if constexpr (!LDS_BANK && !DYN) { // gathered record: the goal centres are in this env's LDS columns
 #pragma unroll
         for (int g = 0; g < SSG_MAX_GOALS; ++g) {
@@ -187,9 +190,9 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
             const double d = obs_fma(dx, dx, dy * dy);
             const bool take = ((gm >> g) & 1u) & (d < best);
             best = take ? d : best;
-            gx = take ? px : gx;
-            gy = take ? py : gy;
+            gi = take ? g : gi;
         }
+        if (gi >= 0) { gx = hG[(2 * gi) * ld]; gy = hG[(2 * gi + 1) * ld]; }
         return;
     }
     for (int g = 0; g < c.n_goals; ++g) {
@@ -199,9 +202,9 @@ __device__ __forceinline__ void nearest_goal(const DevCfg &c, int goff, unsigned
         const double d = obs_fma(dx, dx, dy * dy); // squared distance orders exactly like Vec2d.get_distance's sqrt
         const bool take = ((gm >> g) & 1u) & (d < best); // first alive goal always beats +inf
         best = take ? d : best;
-        gx = take ? px : gx;
-        gy = take ? py : gy;
+        gi = take ? g : gi;
     }
+    if (gi >= 0) { gx = goal_at<LDS_BANK, DYN>(c, goff, gi, 0); gy = goal_at<LDS_BANK, DYN>(c, goff, gi, 1); }
 }
 
 // The same over goal centres held in registers (config 4: gp[2g], gp[2g+1], requested in one batch at the head of the launch).
@@ -366,7 +369,7 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
         constexpr double kSignEps = 1e-9;
         bool ok = false;
         double ptx = ex, pty = ey;
-        double bd = -1.0, bden = 1.0;
+        double bd = -1.0, bden = 1.0, t_hit = 0.0;
         int bj = 0;
         constexpr int kPlaneChunk = PlaneChunk<LDS_BANK>::n;
         for (int j0 = 0; __any(act & (j0 < cnt)); j0 += kPlaneChunk) {
@@ -461,12 +464,21 @@ __device__ __forceinline__ void lidar_pass(const DevCfg &c, const int n_items, c
             pty = obs_fma(ey, t, wcy * omt);
             const double dtv = obs_fma(nx, pty, -(ny * ptx));
             ok = (bd >= 0.0) & (dtmin <= dtv) & (dtv <= dtmax);
+            t_hit = t;
         }
         // start point inside (or on) the polygon: hit at alpha 0 whose reported point is the FAR end b (App. A.7)
         const bool hit = act & (ok | !outside);
-        const double px = outside ? ptx : ex, py = outside ? pty : ey;
-        const double dx = px - wcx, dy = py - wcy;
-        const double dist = sqrt(obs_fma(dx, dx, dy * dy)); // Vec2d.get_distance
+        double dist;
+        if constexpr (EXACT) {
+            const double px = outside ? ptx : ex, py = outside ? pty : ey;
+            const double dx = px - wcx, dy = py - wcy;
+            dist = sqrt(obs_fma(dx, dx, dy * dy)); // Vec2d.get_distance, literally
+        } else {
+            // |cpvlerp(a, b, t) - a| = t |b - a| = t x the beam's length (the far end itself when the origin is inside the hull):
+            // the reading without the point difference and the square root (~20 wave-instructions per pass); it differs from the
+            // literal form by rounding only (~1e-13, held to 1e-9 by test_exact_and_one_division_lidar_agree)
+            dist = outside ? t_hit * c.lidar_dist : c.lidar_dist;
+        }
         if (hit) {
             const unsigned long long key = ((unsigned long long)s << 63) | (unsigned long long)__double_as_longlong(dist);
             atomicMin(&res[bi * 64 + src], key); // ds_min_u64: hull 0's hit beats hull 1's
@@ -848,7 +860,11 @@ __device__ __forceinline__ bool bank_narrowphase(const DevCfg &c, const double *
             ar = hL[(SSG_MAP_OFF_AABB + 4 * s + 2) * ld]; at = hL[(SSG_MAP_OFF_AABB + 4 * s + 3) * ld];
             cn = hL[(SSG_MAP_OFF_COUNTS + s) * ld];
         }
-        const bool near = live & !SSG_ABL(4) & ((only < 0) | (only == s)) & (sbl <= ar) & (al <= sbr) & (sbb <= at) & (ab <= sbt);
+        // (the reject in front of the exact SAT, on the x ranges only: a reject only has to be conservative — boxes that are disjoint
+        // mean polygons that are disjoint, which the SAT below finds by itself — and the banks span the whole height of the world
+        // (game_map.py:22-73), so the y half rejected nothing; without it the ship's y extent is not computed at all)
+        const bool near = live & !SSG_ABL(4) & ((only < 0) | (only == s)) & (sbl <= ar) & (al <= sbr);
+        (void)ab; (void)at; (void)sbb; (void)sbt;
         nearbits |= near ? (1u << s) : 0u;
         cnts |= ((int)cn) << (8 * s);
     }
