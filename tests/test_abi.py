@@ -100,7 +100,22 @@ def test_state_layout_and_unbound_errors(native):
     assert b"ssg_bind_state" in L.ssg_last_error(h)
     assert L.ssg_reset(h, None, None, None, None) == -3
     assert L.ssg_bind_state(h, C.c_void_p(0x1008)) < 0  # misaligned blob
+    # the host-array step (ssg_step_host / ssg_wait_host) and the round-6 setters validate before they touch a device
+    assert L.ssg_step_host(h, None, None, None, None, None, None, None, None, 0, 0, None) == -1
+    assert L.ssg_step_host(h, C.c_void_p(0x1000), C.c_void_p(0x1000), None, None, None, None, C.c_void_p(0x1000), C.c_void_p(0x1000), 64, 8, None) == -1  # slot 0..7
+    assert L.ssg_wait_host(h, 0) == -1 and b"no ssg_step_host" in L.ssg_last_error(h)  # nothing was issued into that slot
+    assert L.ssg_wait_host(h, -1) == -1 and L.ssg_wait_host(h, 8) == -1
+    assert L.ssg_set_terminal_obs(h, None) == 0 and L.ssg_debug_launch_clock(h, None) == 0
+    assert L.ssg_debug_clock_probe(None, 8, 100, None) == -1
     L.ssg_destroy(h)
+    for flags, hist, code, text in ((0, 2, -1, b"SSG_FLAG_AUTO_RESET"), (native.FLAG_AUTO_RESET, 3, -4, b"history > 2")):
+        c2 = native.default_config()
+        c2.n_envs, c2.flags, c2.history = 64, flags, hist
+        h2 = C.c_void_p()
+        native.check(L.ssg_create(C.byref(c2), C.byref(h2)))
+        assert L.ssg_set_terminal_obs(h2, C.c_void_p(0x1000)) == code and text in L.ssg_last_error(h2)  # refused; NULL always passes
+        assert L.ssg_set_terminal_obs(h2, None) == 0
+        L.ssg_destroy(h2)
 
 
 def test_host_geometry_agrees_with_oracle(native, oracle):
