@@ -1765,6 +1765,11 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
 #endif
 
     bool q_need = false; // config 4: this env's entry in the next step's queue (see the classification after the rendezvous)
+    // episode statistics of this lane's env over the launch: summed over the wave and added to the handle's counters ONCE, after
+    // the launch's last step (per done lane and step they were three global atomics in the middle of the body role's chain:
+    // 3.6 % of a fused step by the timing-only ablation)
+    long long st_ret = 0;
+    int st_len = 0, st_eps = 0, st_goals = 0;
     unsigned q_bucket = 0, q_arrival = 0;
     for (int k = 0; k < K; ++k) {
 #ifdef SSG_STAMPS_ITER
@@ -2004,13 +2009,12 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         // Episode statistics, per handle.  Integer counters in kStatsSlots slots (slot = workgroup mod slots): no
         // single hot address, and integer adds commute, so the totals are bitwise reproducible run to run.
         // cum is a sum of {1, -1, -0.01} terms, so round(100*cum) is the exact return in hundredths.
-        unsigned long long *slot = reinterpret_cast<unsigned long long *>(c.stats) + 4 * (blockIdx.x % kStatsSlots);
         if (done) {
-            atomicAdd(slot + 0, (unsigned long long)(long long)llrint(cum * 100.0));
-            atomicAdd(slot + 1, (unsigned long long)steps);
-            atomicAdd(slot + 2, 1ull);
+            st_ret += (long long)llrint(cum * 100.0);
+            st_len += steps;
+            st_eps += 1;
         }
-        if (goal_reached) atomicAdd(slot + 3, 1ull);
+        st_goals += goal_reached ? 1 : 0;
     }
     // (reward / done / flags go to HBM from the observer, which holds the same bits)
     if (do_reset) {
@@ -2037,6 +2041,35 @@ __global__ __launch_bounds__(tile_roles(EPW, DYN) * EPW) void step_kernel(const 
         if (k < K - 1 && q_need && q_arrival < (unsigned)c.n_pad) c.dyn_bucket[(size_t)q_bucket * np + q_arrival] = el_; // (DYN launches are single steps: never taken)
     }
     } // k
+    if (!SSG_ABL(6)) {
+        // the wave's episode statistics -> the handle's counters (integer adds commute: the totals are bitwise reproducible)
+        if (__any((st_eps | st_goals) != 0)) {
+            auto wave_sum = [&](int v) -> int {
+                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+                return __builtin_amdgcn_readlane(v, 63);
+            };
+            // (the return in hundredths of a wave over a launch: |sum| <= 64 envs x 127 steps x 100 — it fits 32 bits... but an
+            // episode's return can reach max_steps x 1, so the per-lane term goes through two 32-bit halves of a biased value)
+            const unsigned long long biased = (unsigned long long)(st_ret + (1ll << 40)); // >= 0: |st_ret| < 2^40 by far
+            const int lo = wave_sum((int)(biased & 0xFFFFu)), mid = wave_sum((int)((biased >> 16) & 0xFFFFu)), hi = wave_sum((int)(biased >> 32));
+            const int len = wave_sum(st_len), eps = wave_sum(st_eps), goals = wave_sum(st_goals);
+            if (lane == 0) {
+                unsigned long long *slot = reinterpret_cast<unsigned long long *>(c.stats) + 4 * (blockIdx.x % kStatsSlots);
+                const long long ret = (long long)lo + ((long long)mid << 16) + ((long long)hi << 32) - 64ll * (1ll << 40);
+                if (eps) {
+                    atomicAdd(slot + 0, (unsigned long long)ret);
+                    atomicAdd(slot + 1, (unsigned long long)(long long)len);
+                    atomicAdd(slot + 2, (unsigned long long)(long long)eps);
+                }
+                if (goals) atomicAdd(slot + 3, (unsigned long long)(long long)goals);
+            }
+        }
+    }
     if (live) {
         // The last step's outputs (the observer wrote those of the steps before), from the same LDS words the observer
         // reads: determine_reward (ship_env.py:62-77) and is_done (ship_env.py:115-134).
