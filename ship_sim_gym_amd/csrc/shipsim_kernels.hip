@@ -609,7 +609,7 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
         ar[s] = rt.x + eps;
         at[s] = rt.y + eps;
     }
-    (void)ab; (void)at; // (only the -DSSG_QUEUE_BEAM_MAJOR / -DSSG_CULL_XY variants test the y ranges)
+    (void)ab; (void)at; (void)al; (void)ar; // (the -DSSG_QUEUE_BEAM_MAJOR variant tests all four ranges)
 #ifdef SSG_QUEUE_BEAM_MAJOR /* the round-2..5 order (tools/build_variant.sh beammajor -DSSG_QUEUE_BEAM_MAJOR), for A/B timing */
 #pragma unroll
     for (int k = 0; k < NB0; ++k) {
@@ -639,6 +639,8 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
     // the same record's planes at the same LDS addresses (a broadcast) where the beam-major order put 64 different envs —
     // 64 records, several to a bank — next to each other (rocprofv3 SQ_LDS_BANK_CONFLICT: 27 % of the LDS pipe's busy cycles).
     unsigned needmask = 0u;
+    const double lca = c.lidar_dist * ca, lsa = c.lidar_dist * sa;
+    const bool org0 = live & (cx <= ar[0]), org1 = live & (al[1] <= cx); // the origin itself is within the hull's x range
 #pragma unroll
     for (int k = 0; k < NB0; ++k) {
         if (k < b_count) { // wave-uniform
@@ -648,18 +650,16 @@ __device__ __forceinline__ void lidar_query(const DevCfg &c, unsigned long long 
                 // Beam i points along heading + phi_i, phi_i = rad(90 - spread/2) + i*rad(spread/n_beams)
                 // (models.py:48-49,62-64); endpoint via the angle-addition identity (beam_end): agrees with the
                 // reference's per-beam cos/sin to ~1e-13 and only feeds lidar readings, never the dynamics.
-                double ex, ey;
-                beam_end(cx, cy, ca, sa, beamtab[i], beamtab[SSG_MAX_BEAMS + i], c.lidar_dist, ex, ey);
-                const double lox = dmin(cx, ex), hix = dmax(cx, ex);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    // keep the pair unless the beam's box and the hull's (widened) box are disjoint IN X.  (A cull only has to be
-                    // conservative: a pair it keeps in vain runs through the segment query and reports a miss.  The banks span the
-                    // whole height of the world — game_map.py:22-73: y from -100 to 1.2 H — so the y half of the box test rejected
-                    // nothing and cost four compares and two min / max per pair: 80 of the cull's ~290 wave-instructions.)
-                    const bool need = live & (lox <= ar[s]) & (al[s] <= hix);
-                    needmask |= need ? (1u << (2 * k + s)) : 0u;
-                }
+                // keep a pair unless the beam and the hull's (widened) box are disjoint IN X, tested from ONE side per hull.  (A cull
+                // only has to be conservative: a pair it keeps in vain runs through the segment query and reports a miss.  The
+                // banks span the whole height of the world — game_map.py:22-73: y from -100 to 1.2 H — so the y half of the box
+                // test rejected nothing; hull 0 is the left bank, which a beam can only reach by getting as far LEFT as the bank's
+                // right edge, hull 1 the right bank (game_map.py:67-71, models.py:172-182: the list order lidar readings depend
+                // on).  For banks laid out otherwise the test stays correct — it never drops a pair that could hit — and merely
+                // culls less.  Four compares, two min / max and the beam end's y per pair before; one compare now.)
+                const double ex = obs_fma(lca, beamtab[i], obs_fma(-lsa, beamtab[SSG_MAX_BEAMS + i], cx)); // cx + dist * cos(heading + phi_i)
+                needmask |= (org0 | (live & (ex <= ar[0]))) ? (1u << (2 * k + 0)) : 0u;
+                needmask |= (org1 | (live & (al[1] <= ex))) ? (1u << (2 * k + 1)) : 0u;
             }
         }
     }
