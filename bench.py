@@ -328,6 +328,29 @@ def vecenv_numpy_path(dev, n, n_beams, ks=300):
            "path": "ShipVecEnv.step_async (pinned actions -> H2D, ssg_step, one D2H of the packed block, side stream) + step_wait "
                    "(event wait, numpy views of the pinned block)"}
     vec.close()
+    # the RLlib VectorEnv flow on the same bytes (train/rllib/ppo.py:21-44): vector_step reports terminal observations (a fresh
+    # observation array per step: RLlib's sample builders keep rows by reference), every done env gets its reset_at(i) — one Python
+    # call per done env, as RLlib's own adapter makes them; no reset launch underneath (ssg_set_terminal_obs)
+    rl = ShipVecEnv(n, device=dev, map_mode="bank", n_maps=N_MAPS, map_seed=1000, n_beams=n_beams, rllib=True)
+    rl.vector_reset()
+    kr = min(ks, 100)
+    for a in rows[:5]:
+        _, _, d, _ = rl.vector_step(a)
+        for i in np.nonzero(d)[0]:
+            rl.reset_at(int(i))
+    t0 = time.perf_counter()
+    n_resets = 0
+    for a in rows[:kr]:
+        _, _, d, _ = rl.vector_step(a)
+        idx = np.nonzero(d)[0]
+        n_resets += len(idx)
+        for i in idx:
+            rl.reset_at(int(i))
+    per_rl = (time.perf_counter() - t0) / kr
+    out["rllib_vector_step"] = {"us_per_step": per_rl * 1e6, "env_steps_per_s": n / per_rl, "steps": kr, "reset_at_calls_per_step": n_resets / kr,
+                                "path": "ShipVecEnv(rllib=True).vector_step (terminal observations, a fresh obs array per step) + one reset_at(i) "
+                                        "per done env; no reset launch (ssg_set_terminal_obs)"}
+    rl.close()
     torch.cuda.empty_cache()
     return out
 
