@@ -7,7 +7,8 @@ import numpy as np
 from ship_sim_gym_amd.vec_env import ShipVecEnv
 from ship_sim_gym_amd import _native as N
 n = int(os.environ.get("N", "4096"))
-vec = ShipVecEnv(n, n_beams=10, n_maps=64, n_ships=4)
+vec = ShipVecEnv(n, n_beams=10, n_maps=int(os.environ.get("MAPS", "64")), n_ships=4, map_mode=os.environ.get("MAP_MODE", "bank"),
+                 ring=int(os.environ.get("RING", "8")), dyn_memo=os.environ.get("MEMO", "1") != "0")
 acts = vec.random_actions(12345, 0, 120)
 vec.reset_tensor()
 vec.rollout_tensor(acts)
